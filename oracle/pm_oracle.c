@@ -1,0 +1,207 @@
+/*
+ * pm_oracle.c — CPU restatement of the PlatyMatch estimate_transform hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker the HIP path is compared
+ * against.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may build, load or call it.  Nothing under platymatch_amd/ imports it,
+ * links it or falls back to it.
+ *
+ * Parity status: PINNED.  Every function below is checked against outputs of
+ * the unmodified reference run in the build container (the .npz fixtures under tests/golden/,
+ * produced by tests/golden/gen_golden.py) by tests/test_oracle_golden.py.
+ *
+ * Plain scalar C, IEEE-754 binary64, one rounding per written operation:
+ * build with -ffp-contract=off and without -ffast-math (oracle/Makefile).
+ * Each function cites the reference lines it follows (paths relative to the
+ * reference checkout, juglab/PlatyMatch setup.py version 0.0.4).
+ *
+ * Third-party arithmetic on the path that is not in the reference tree
+ * (requirements.txt pins no versions; versions of the build container):
+ *   numpy 2.2.6   floor_divide on float64 (npy_divmod), np.linalg.norm, np.cross
+ *   scipy 1.15.3  spatial.distance_matrix (minkowski p=2), optimize.linear_sum_assignment
+ * Their published algorithms are restated where used.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PM_NBINS 360
+#ifndef M_PI
+#define M_PI 0x1.921fb54442d18p+1 /* np.pi */
+#endif
+
+/* r_edges = np.logspace(np.log10(1/8), np.log10(2), 5)   (shape_context.py:24)
+ * The exact float64 values numpy 2.2.6 produces (tests/golden/micro.npz:r_edges);
+ * note edges 1 and 2 are one ulp above 1/4 and 1/2. */
+static const double R_EDGES[5] = {0x1.0000000000000p-3, 0x1.0000000000001p-2,
+                                  0x1.0000000000001p-1, 0x1.0000000000000p+0,
+                                  0x1.0000000000000p+1};
+
+/* numpy float64 `//`: npy_divmod (numpy/_core/src/npymath/npy_math_internal.h.src),
+ * used at shape_context.py:51-52. */
+static double np_floor_divide(double a, double b) {
+    if (b == 0.0) return a / b;
+    double mod = fmod(a, b);
+    double div = (a - mod) / b;
+    if (mod) { /* true for NaN too, as in the C original */
+        if ((b < 0) != (mod < 0)) { mod += b; div -= 1.0; }
+    } else {
+        mod = copysign(0.0, b);
+    }
+    double fd;
+    if (div) {
+        fd = floor(div);
+        if (div - fd > 0.5) fd += 1.0;
+    } else {
+        fd = copysign(0.0, a / b);
+    }
+    return fd;
+}
+
+/* np.linalg.norm of a 3-vector: sqrt(x.dot(x)) (numpy/linalg/_linalg.py norm, ord=None). */
+static double norm3(double a, double b, double c) { return sqrt((a * a + b * b) + c * c); }
+static double dot3(const double *a, const double *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+/* One neighbour, already expressed in the local frame: the loop body of
+ * get_shape_context (shape_context.py:25-35) followed by get_bin_index
+ * (shape_context.py:46-58).  Returns the float bin index (may be NaN, may be >= 360). */
+static double bin_index(double x_, double y_, double z_, double mean_dist) {
+    double r_ = norm3(x_, y_, z_);                 /* :29 */
+    double r = r_ / mean_dist;                     /* :30 */
+    double theta = acos(z_ / r_);                  /* :31 */
+    double at = atan2(y_, x_);                     /* :32-35 */
+    double phi = (at < 0) ? (2 * M_PI + at) : at;
+    double r_index = 5 - 1;                        /* :49 */
+    double theta_index = np_floor_divide(theta, M_PI / 6);      /* :51 */
+    double phi_index = np_floor_divide(phi, 2 * M_PI / 12);     /* :52 */
+    for (int k = 0; k < 5; ++k)                    /* :53-56 */
+        if (r < R_EDGES[k]) { r_index = k; break; }
+    return r_index * 6 * 12 + theta_index * 12 + phi_index;     /* :57 */
+}
+
+/* get_shape_context + get_bin_index on an explicit neighbour list (n x 3, row-major). */
+int pmo_bin_index(const double *nb, int n, double mean_dist, double *idx_out) {
+    for (int i = 0; i < n; ++i) idx_out[i] = bin_index(nb[3 * i], nb[3 * i + 1], nb[3 * i + 2], mean_dist);
+    return 0;
+}
+
+/* get_mean_distance (utils/utils.py:58-75): mean of ||p_i - p_j|| over i<j.
+ * The reference averages a Python list with np.average (pairwise summation);
+ * this restatement sums per row then over rows — equal to ~1e-14 relative. */
+int pmo_mean_distance(const double *xyz, int n, double *out) {
+    const double *X = xyz, *Y = xyz + n, *Z = xyz + 2 * (size_t)n;
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double row = 0.0;
+        for (int j = i + 1; j < n; ++j) row += norm3(X[i] - X[j], Y[i] - Y[j], Z[i] - Z[j]);
+        total += row;
+    }
+    *out = total / (0.5 * (double)n * (double)(n - 1));
+    return 0;
+}
+
+/* get_unary (shape_context.py:144-188) for one cloud, as integer histograms.
+ *   xyz       3 x n, row-major (the reference's 3 x N layout, transposed=False)
+ *   centroid  3, x0 3 (first PCA axis, shape_context.py:162-165), mean_dist
+ *   n_frames  2 ('moving') or 4 ('fixed')
+ *   counts    [n_frames][n][360] int32: index.count(i) (shape_context.py:39-40)
+ *   totals    [n_frames][n]      int32: sc.sum() before normalisation (:41)
+ * The local frame follows :169-175 and :180-181; `transform` (:61-84) maps
+ * p_i -> 0 and p_i+x,y,z -> e1,e2,e3, i.e. neighbour -> [x y z]^T (p_j - p_i):
+ * this restatement projects directly (measured identical
+ * integer histograms). */
+int pmo_shape_context_counts(const double *xyz, int n, const double *centroid, const double *x0,
+                             double mean_dist, int n_frames, int32_t *counts, int32_t *totals) {
+    const double *P0 = xyz, *P1 = xyz + n, *P2 = xyz + 2 * (size_t)n;
+    memset(counts, 0, sizeof(int32_t) * (size_t)n_frames * n * PM_NBINS);
+    memset(totals, 0, sizeof(int32_t) * (size_t)n_frames * n);
+    for (int i = 0; i < n; ++i) {
+        double p[3] = {P0[i], P1[i], P2[i]};
+        double w[3] = {p[0] - centroid[0], p[1] - centroid[1], p[2] - centroid[2]};
+        double nw = norm3(w[0], w[1], w[2]);
+        double z[3] = {w[0] / nw, w[1] / nw, w[2] / nw};                  /* :169 */
+        double d = dot3(x0, z);
+        double x[3] = {x0[0] - z[0] * d, x0[1] - z[1] * d, x0[2] - z[2] * d}; /* :170 */
+        double nx = norm3(x[0], x[1], x[2]);
+        x[0] /= nx; x[1] /= nx; x[2] /= nx;                                /* :171 */
+        double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]}; /* get_Y :6-8 */
+        double ny = norm3(y[0], y[1], y[2]);
+        y[0] /= ny; y[1] /= ny; y[2] /= ny;
+        /* frame 2: x0 -> -x0 gives (-x, -y) exactly (:172-175); frame 3: (x, -y); frame 4: (-x, +y) (:180-181) */
+        static const double SX[4] = {1, -1, 1, -1}, SY[4] = {1, -1, -1, 1};
+        for (int j = 0; j < n; ++j) {
+            if (j == i) continue;                                          /* np.delete :168 */
+            double v[3] = {P0[j] - p[0], P1[j] - p[1], P2[j] - p[2]};
+            double vx = dot3(x, v), vy = dot3(y, v), vz = dot3(z, v);
+            for (int f = 0; f < n_frames; ++f) {
+                double idx = bin_index(SX[f] * vx, SY[f] * vy, vz, mean_dist);
+                if (idx >= 0 && idx < PM_NBINS && idx == floor(idx)) {
+                    counts[((size_t)f * n + i) * PM_NBINS + (int)idx] += 1;
+                    totals[(size_t)f * n + i] += 1;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* get_unary_distance (shape_context.py:88-99) for every (i, j): the widget's
+ * N x M double loops (_dock_widget.py:547-602).  Sequential sum over the 360
+ * bins in index order, bins with a == b skipped. */
+int pmo_chi2(const double *a, int n, const double *b, int m, double *out) {
+    for (int i = 0; i < n; ++i) {
+        const double *ai = a + (size_t)i * PM_NBINS;
+        for (int j = 0; j < m; ++j) {
+            const double *bj = b + (size_t)j * PM_NBINS;
+            double dist = 0.0;
+            for (int k = 0; k < PM_NBINS; ++k) {
+                if (ai[k] != bj[k]) {
+                    double df = ai[k] - bj[k];
+                    dist = dist + (df * df) / (ai[k] + bj[k]);
+                }
+            }
+            out[(size_t)i * m + j] = 0.5 * dist;
+        }
+    }
+    return 0;
+}
+
+/* perform_icp's correspondence step (perform_icp.py:15-16):
+ * scipy.spatial.distance_matrix = sum(|x-y|**2, axis=-1)**0.5 (scipy/spatial/_kdtree.py
+ * minkowski_distance, p=2), then np.argmin(axis=1) — first index on ties. */
+int pmo_nn_argmin(const double *mov, int n, const double *fix, int m, int32_t *idx, double *dist) {
+    for (int i = 0; i < n; ++i) {
+        double best = INFINITY;
+        int bj = 0;
+        for (int j = 0; j < m; ++j) {
+            double d0 = fix[j] - mov[i], d1 = fix[m + j] - mov[n + i], d2 = fix[2 * (size_t)m + j] - mov[2 * (size_t)n + i];
+            double d = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+            if (d < best) { best = d; bj = j; }
+        }
+        idx[i] = bj;
+        if (dist) dist[i] = best;
+    }
+    return 0;
+}
+
+/* do_ransac's scoring loop (shape_context.py:130-135) for a batch of candidate
+ * transforms: predicted = A . [moving; 1] (apply_affine_transform, apply_transform.py:13-16),
+ * inliers = #{ ||fixed - predicted|| <= error }. */
+int pmo_ransac_score(const double *mov, const double *fix, int n, const double *A, int trials,
+                     double error, int32_t *inliers) {
+    for (int t = 0; t < trials; ++t) {
+        const double *a = A + 16 * (size_t)t;
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            double m0 = mov[i], m1 = mov[n + i], m2 = mov[2 * (size_t)n + i];
+            double p0 = ((a[0] * m0 + a[1] * m1) + a[2] * m2) + a[3];
+            double p1 = ((a[4] * m0 + a[5] * m1) + a[6] * m2) + a[7];
+            double p2 = ((a[8] * m0 + a[9] * m1) + a[10] * m2) + a[11];
+            double d = norm3(fix[i] - p0, fix[n + i] - p1, fix[2 * (size_t)n + i] - p2);
+            if (d <= error) ++cnt;
+        }
+        inliers[t] = cnt;
+    }
+    return 0;
+}

@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the UNMODIFIED reference (juglab/PlatyMatch).
+
+Runs only in the build container, where the reference is mounted read-only at
+/root/reference.  Nothing here is used at test time: the tests read the .npz
+files this script writes next to itself.  The fixtures are data only (inputs
+and the reference's outputs); no reference source travels with them.
+
+Import recipe: `platymatch/__init__.py` pulls in napari/Qt,
+which are not installed, so a bare package stub with the right __path__ is
+registered first, plus a stub `qtpy.QtWidgets` (utils/utils.py:3 imports
+QFileDialog at module top).  The hot-path modules then import and run as is.
+
+The widget's orchestration (`_dock_widget.py:526-718`) cannot be imported
+(Qt); `run_pipeline` below drives the reference's own functions in the same
+stage order with the same arguments (the reference's test-suite does the same,
+`_tests/test_estimate_transform.py:11-72`).
+
+Usage:  python tests/golden/gen_golden.py [scenario ...]
+"""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    pkg = types.ModuleType("platymatch")
+    pkg.__path__ = [os.path.join(REF, "platymatch")]
+    sys.modules["platymatch"] = pkg
+    qtpy = types.ModuleType("qtpy")
+    qtw = types.ModuleType("qtpy.QtWidgets")
+    qtw.QFileDialog = type("QFileDialog", (), {})
+    qtpy.QtWidgets = qtw
+    sys.modules["qtpy"] = qtpy
+    sys.modules["qtpy.QtWidgets"] = qtw
+    from platymatch.estimate_transform import (apply_transform, find_transform,
+                                               perform_icp, shape_context)
+    from platymatch.utils import utils
+    return shape_context, find_transform, apply_transform, perform_icp, utils
+
+
+# Ground-truth affine used by the reference's own tests
+# (data literal at _tests/test_estimate_transform.py:88-91 and 156-159).
+A_GT = np.array([[9.08173020e-01, -2.58092254e-01, 2.21387350e-01, 4.98532315e+00],
+                 [-2.85490902e-02, 5.66865806e-01, 7.60292965e-01, -2.13218259e+02],
+                 [-2.53059848e-01, -7.49475117e-01, 4.48778146e-01, 5.56203489e+02],
+                 [1.73472348e-17, 2.42861287e-17, -4.16333634e-17, 1.00000000e+00]])
+
+
+def load_asset(name):
+    """`id x y z` rows, space separated -> 3 x N in (z, y, x) order, as the
+    reference's tests load it (test_estimate_transform.py:17-21)."""
+    import pandas as pd
+    arr = pd.read_csv(os.path.join(REF, "platymatch/_tests/assets", name),
+                      header=None, delimiter=" ").to_numpy()
+    return np.ascontiguousarray(np.flip(arr[:, 1:4], 1).transpose().astype(np.float64))
+
+
+def counts_from_sc(sc):
+    """Recover the integer histogram and its total from a normalised descriptor
+    row set, and prove counts/total regenerates the reference floats bit for bit."""
+    n = sc.shape[0]
+    counts = np.zeros(sc.shape, dtype=np.int32)
+    totals = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        row = sc[i]
+        if np.isnan(row).any():
+            totals[i] = 0
+            continue
+        ok = False
+        for t in range(n + 2, 0, -1):  # N-1 unless neighbours were dropped
+            c = np.rint(row * t)
+            if c.sum() == t and np.array_equal(c / c.sum(), row):
+                counts[i] = c.astype(np.int32)
+                totals[i] = t
+                ok = True
+                break
+        if not ok:
+            raise RuntimeError("row %d: no integer total reproduces the descriptor" % i)
+    return counts, totals
+
+
+def run_pipeline(ref, moving, fixed, ransac_trials, ransac_error, icp_iters, u_row_step, tag):
+    sc_mod, ft, at, icp_mod, utils = ref
+    from scipy.optimize import linear_sum_assignment
+    from sklearn.decomposition import PCA
+    out = {"moving": moving, "fixed": fixed}
+    t0 = time.time()
+    cm = utils.get_centroid(moving, transposed=False)
+    cf = utils.get_centroid(fixed, transposed=False)
+    mdm = utils.get_mean_distance(moving, transposed=False)
+    mdf = utils.get_mean_distance(fixed, transposed=False)
+    out.update(centroid_m=cm, centroid_f=cf, mean_dist_m=np.float64(mdm), mean_dist_f=np.float64(mdf))
+    # the PCA axis get_unary derives internally (shape_context.py:162-165)
+    out["x0_m"] = PCA(n_components=3).fit(moving.T).components_[0].copy()
+    out["x0_f"] = PCA(n_components=3).fit(fixed.T).components_[0].copy()
+
+    um = sc_mod.get_unary(cm, mean_distance=mdm, detections=moving, type="moving", transposed=False)
+    uf = sc_mod.get_unary(cf, mean_distance=mdf, detections=fixed, type="fixed", transposed=False)
+    assert um[2].shape == (0,) and um[3].shape == (0,)
+    for k in range(2):
+        c, t = counts_from_sc(um[k])
+        out["counts_m%d" % (k + 1)] = c.astype(np.int16)
+        out["total_m%d" % (k + 1)] = t
+    for k in range(4):
+        c, t = counts_from_sc(uf[k])
+        out["counts_f%d" % (k + 1)] = c.astype(np.int16)
+        out["total_f%d" % (k + 1)] = t
+    print("[%s] descriptors %.1fs" % (tag, time.time() - t0), flush=True)
+
+    n, m = moving.shape[1], fixed.shape[1]
+    names = ["11", "12", "13", "14", "21", "22", "23", "24"]
+    U = {}
+    t0 = time.time()
+    for nm in names:
+        a = um[int(nm[0]) - 1]
+        b = uf[int(nm[1]) - 1]
+        mat = np.zeros((n, m))
+        for i in range(n):
+            for j in range(m):
+                mat[i, j] = sc_mod.get_unary_distance(a[i], b[j])
+        U[nm] = mat
+    print("[%s] chi2 %.1fs" % (tag, time.time() - t0), flush=True)
+    rows_kept = np.arange(0, n, u_row_step)
+    out["U_rows"] = rows_kept
+    out["U"] = np.stack([U[nm][rows_kept] for nm in names])          # 8 x R x M, exact float64
+    out["U_sum"] = np.array([U[nm].sum() for nm in names])
+    out["U_rowmin_idx"] = np.stack([U[nm].argmin(1) for nm in names]).astype(np.int32)
+
+    lsa = [linear_sum_assignment(U[nm]) for nm in names]
+    out["lsa_rows"] = np.stack([r for r, _ in lsa]).astype(np.int32)
+    out["lsa_cols"] = np.stack([c for _, c in lsa]).astype(np.int32)
+
+    t0 = time.time()
+    np.random.seed(0)
+    A_r, inl = [], []
+    for r, c in lsa:
+        A, k = sc_mod.do_ransac(moving[:, r], fixed[:, c], min_samples=4, trials=ransac_trials,
+                                error=ransac_error, transform="Affine")
+        A_r.append(np.asarray(A, dtype=np.float64))
+        inl.append(k)
+    out["ransac_seed"] = np.int64(0)
+    out["ransac_trials"] = np.int64(ransac_trials)
+    out["ransac_error"] = np.float64(ransac_error)
+    out["ransac_A"] = np.stack(A_r)
+    out["ransac_inliers"] = np.array(inl, dtype=np.int64)
+    best = int(np.argmax(out["ransac_inliers"]))
+    A_sc = A_r[best]
+    out["best_hypothesis"] = np.int64(best)
+    out["A_sc"] = A_sc
+    print("[%s] ransac %.1fs inliers %s" % (tag, time.time() - t0, inl), flush=True)
+
+    # ICP, with the reference's own distance_matrix/get_error calls observed
+    nn_log, res_log = [], []
+    real_dm, real_err = icp_mod.distance_matrix, icp_mod.get_error
+
+    def dm_spy(a, b):
+        d = real_dm(a, b)
+        nn_log.append(np.argmin(d, 1).astype(np.int32))
+        return d
+
+    def err_spy(a, b):
+        e = real_err(a, b)
+        res_log.append(e)
+        return e
+
+    icp_mod.distance_matrix, icp_mod.get_error = dm_spy, err_spy
+    try:
+        moved = at.apply_affine_transform(moving.copy(), A_sc)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            A_icp = icp_mod.perform_icp(moved, fixed.copy(), icp_iters, "Affine")
+    finally:
+        icp_mod.distance_matrix, icp_mod.get_error = real_dm, real_err
+    out["icp_iters"] = np.int64(icp_iters)
+    out["icp_nn"] = np.stack(nn_log)
+    out["icp_residuals"] = np.array(res_log)
+    out["A_icp"] = A_icp
+    out["A_final"] = A_icp @ A_sc
+    return out
+
+
+def synth_cloud(n, seed):
+    rng = np.random.default_rng(seed)
+    moving = rng.normal(size=(3, n)) * np.array([[60.0], [40.0], [25.0]]) + 200.0
+    return rng, moving
+
+
+def scenario(ref, name):
+    at = ref[2]
+    if name == "insitu02_identity":
+        mv = load_asset("02-insitu.csv")
+        return run_pipeline(ref, mv, at.apply_affine_transform(mv, np.identity(4)), 2000, 16, 50, 16, name), np.identity(4)
+    if name == "insitu02_affine":
+        mv = load_asset("02-insitu.csv")
+        return run_pipeline(ref, mv, at.apply_affine_transform(mv, A_GT), 2000, 16, 50, 16, name), A_GT
+    if name == "insitu04_affine":
+        mv = load_asset("04-insitu.csv")
+        return run_pipeline(ref, mv, at.apply_affine_transform(mv, A_GT), 2000, 16, 50, 16, name), A_GT
+    if name == "synth128":
+        rng, mv = synth_cloud(128, 0)
+        fx = at.apply_affine_transform(mv, A_GT) + rng.normal(scale=1.0, size=mv.shape)
+        fx = np.ascontiguousarray(fx[:, rng.permutation(128)])
+        return run_pipeline(ref, mv, fx, 1000, 16, 30, 1, name), A_GT
+    if name == "synth96x128":
+        rng, mv = synth_cloud(128, 1)
+        fx = at.apply_affine_transform(mv, A_GT) + rng.normal(scale=0.5, size=mv.shape)
+        fx = np.ascontiguousarray(fx[:, rng.permutation(128)])
+        mv = np.ascontiguousarray(mv[:, :96])
+        return run_pipeline(ref, mv, fx, 500, 16, 20, 1, name), A_GT
+    raise KeyError(name)
+
+
+def micro(ref):
+    """Unit-level known answers for the binning edge cases and small helpers."""
+    sc_mod, ft, at, icp_mod, utils = ref
+    out = {}
+    # every integer vector in {-2..2}^3: exact ring edges, theta = 0, pi/2, pi, phi on bin edges, the zero vector
+    g = np.arange(-2, 3, dtype=np.float64)
+    grid = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    out["grid_neighbors"] = grid
+    with np.errstate(all="ignore"):
+        out["grid_sc_md1"] = sc_mod.get_shape_context(grid, 1.0)
+        out["grid_sc_md3"] = sc_mod.get_shape_context(grid, 3.0)
+    rng = np.random.default_rng(7)
+    nb = rng.normal(size=(500, 3)) * 40.0
+    out["rand_neighbors"] = nb
+    out["rand_sc"] = sc_mod.get_shape_context(nb, 55.0)
+    # raw bin indices for the random neighbours (get_bin_index called exactly as get_shape_context does)
+    r = [np.linalg.norm(v) / 55.0 for v in nb]
+    th = [np.arccos(v[2] / np.linalg.norm(v)) for v in nb]
+    ph = [(2 * np.pi + np.arctan2(v[1], v[0])) if np.arctan2(v[1], v[0]) < 0 else np.arctan2(v[1], v[0]) for v in nb]
+    edges = np.logspace(np.log10(1 / 8), np.log10(2), 5)
+    out["r_edges"] = edges
+    out["rand_bin_index"] = np.array(sc_mod.get_bin_index(r, th, ph, edges, 5, 6, 12))
+    # chi2 on two descriptor rows incl. equal and zero bins
+    a = out["rand_sc"]
+    b = sc_mod.get_shape_context(rng.normal(size=(300, 3)) * 30.0, 40.0)
+    out["chi2_a"], out["chi2_b"] = a, b
+    out["chi2_ab"] = np.float64(sc_mod.get_unary_distance(a, b))
+    out["chi2_aa"] = np.float64(sc_mod.get_unary_distance(a, a))
+    # transform fitting / application
+    P = rng.normal(size=(3, 40)) * 50 + 100
+    Q = at.apply_affine_transform(P, A_GT) + rng.normal(scale=0.3, size=(3, 40))
+    out["fit_moving"], out["fit_fixed"] = P, Q
+    out["fit_affine"] = ft.get_affine_transform(P, Q)
+    out["fit_affine4"] = ft.get_affine_transform(P[:, :4], Q[:, :4])
+    out["fit_similar"] = ft.get_similar_transform(P, Q)
+    out["fit_similar4"] = ft.get_similar_transform(P[:, :4], Q[:, :4])
+    out["apply_affine"] = at.apply_affine_transform(P, A_GT)
+    out["apply_affine_4row"] = at.apply_affine_transform(np.vstack([P, np.ones((1, 40))]), A_GT)
+    out["apply_similar"] = at.apply_similar_transform(P, 1.3, A_GT[:3, :3], A_GT[:3, 3:4])
+    out["error_PQ"] = np.float64(utils.get_error(P, Q))
+    out["centroid_T"] = utils.get_centroid(P.T, transposed=True)
+    out["centroid_F"] = utils.get_centroid(P, transposed=False)
+    out["mean_distance"] = np.float64(utils.get_mean_distance(P, transposed=False))
+    cube = np.array([[0, 0, 0], [1, 0, 0], [0, 0, 1], [1, 0, 1], [1, 1, 0], [1, 1, 1], [0, 1, 1], [0, 1, 0]], dtype=np.float64)
+    out["cube"] = cube
+    out["cube_centroid"] = utils.get_centroid(cube, transposed=True)  # _tests/test_utils.py:5-8 expects 0.5,0.5,0.5
+    # degenerate cloud: integer coordinates, symmetric about the origin (centroid is exactly a point),
+    # one duplicated pair of points -> NaN row and dropped neighbours
+    half = rng.integers(-60, 61, size=(3, 20)).astype(np.float64)
+    deg = np.concatenate([half, -half, np.zeros((3, 1)), half[:, :1], -half[:, :1]], axis=1)
+    out["degenerate_cloud"] = deg
+    with np.errstate(all="ignore"):
+        c = utils.get_centroid(deg, transposed=False)
+        md = utils.get_mean_distance(deg, transposed=False)
+        d = sc_mod.get_unary(c, md, deg, "fixed", transposed=False)
+    out["degenerate_centroid"] = c
+    out["degenerate_mean_dist"] = np.float64(md)
+    for k in range(4):
+        out["degenerate_sc%d" % (k + 1)] = d[k]
+    # ICP on its own (supervised tail, _dock_widget.py:707-717)
+    kp_m = P[:, :10]
+    kp_f = Q[:, :10]
+    out["sup_A_sc"] = ft.get_affine_transform(kp_m, kp_f)
+    return out
+
+
+ALL = ["micro", "synth128", "synth96x128", "insitu02_identity", "insitu02_affine", "insitu04_affine"]
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or ALL
+    ref = import_reference()
+    import scipy
+    import sklearn
+    versions = "numpy %s scipy %s sklearn %s python %s" % (np.__version__, scipy.__version__, sklearn.__version__, sys.version.split()[0])
+    for name in todo:
+        t0 = time.time()
+        if name == "micro":
+            res = micro(ref)
+        else:
+            res, a_gt = scenario(ref, name)
+            res["A_gt"] = a_gt
+        res["versions"] = np.array(versions)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **res)
+        print("wrote %s (%.1f KB) in %.1fs" % (path, os.path.getsize(path) / 1024, time.time() - t0), flush=True)
