@@ -1,0 +1,196 @@
+/*
+ * platymatch_hip.h — C ABI of libplatymatch_hip.so, the MI355X (gfx950) implementation of
+ * PlatyMatch's estimate_transform hot path.
+ *
+ * The reference (juglab/PlatyMatch 0.0.4) is pure Python and has no FFI; its boundary is a set
+ * of module-level functions the napari widget imports by name (_dock_widget.py:15-21).  Each
+ * entry point below names the reference function (file:line) whose inner loops it replaces; the
+ * Python mirror of those functions (the modules under platymatch_amd/estimate_transform/ and platymatch_amd/utils/)
+ * binds these symbols with ctypes.  INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd or a torch ROCm tensor's data_ptr());
+ *     scalars the kernels consume (centroid, PCA axis, mean distance, 4x4 matrices) are also
+ *     read from device memory, so a pipeline can be enqueued without host round trips;
+ *   - point clouds are float64, 3 x N row-major — the reference's own layout (rows z, y, x;
+ *     `transposed=False`), i.e. structure-of-arrays, so every coordinate load is coalesced;
+ *   - descriptors are float64 [N][360] row-major per frame, as get_unary returns them;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue
+ *     work and return; no entry point allocates, frees or synchronises (graph-capture safe);
+ *   - scratch comes from the caller: ask pm_*_workspace() for the size (bytes), pass a device
+ *     buffer at least that large; workspace contents need not be initialised;
+ *   - re-entrant: no global mutable state; safe from any host thread, any device, any stream;
+ *   - return value: PM_OK or a negative PM_ERR_* code; never throws, aborts or prints.
+ *     Argument errors are detected before anything is enqueued.
+ */
+#ifndef PLATYMATCH_HIP_H
+#define PLATYMATCH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_ABI_VERSION 1
+#define PM_NBINS 360 /* 5 r x 6 theta x 12 phi: the only binning the reference uses (shape_context.py:10) */
+
+#define PM_OK 0
+#define PM_ERR_INVALID_ARG (-1)   /* NULL pointer, non-positive size, bad enum */
+#define PM_ERR_WORKSPACE (-2)     /* workspace missing or too small */
+#define PM_ERR_LAUNCH (-3)        /* HIP reported an error enqueuing work; see pm_last_hip_error() */
+#define PM_ERR_UNSUPPORTED (-4)   /* valid in the reference, not implemented on the device path */
+
+#define PM_AFFINE 0  /* transform='Affine'  (find_transform.py:4-17)  */
+#define PM_SIMILAR 1 /* transform='Similar' (find_transform.py:21-99) — host-side only, see DESIGN.md */
+
+int pm_version(void);
+const char *pm_error_string(int code);
+int pm_last_hip_error(void); /* hipError_t of the calling thread's most recent PM_ERR_LAUNCH */
+
+/* ---- cloud statistics --------------------------------------------------------------------- */
+
+/* get_centroid (utils/utils.py:48-56): out[3] = mean of each coordinate row. */
+size_t pm_centroid_workspace(int n);
+int pm_centroid(const double *xyz, int n, double *out3, void *ws, size_t ws_bytes, void *stream);
+
+/* get_mean_distance (utils/utils.py:58-75): out[1] = mean of ||p_i - p_j|| over all i < j.
+ * Deterministic (fixed reduction tree); equal to the reference to ~1e-14 relative. */
+size_t pm_mean_distance_workspace(int n);
+int pm_mean_distance(const double *xyz, int n, double *out1, void *ws, size_t ws_bytes, void *stream);
+
+/* First principal axis as sklearn PCA(3).fit(X).components_[0] (shape_context.py:162-165):
+ * unit eigenvector of the sample covariance with the largest eigenvalue, sign chosen so that its
+ * largest-magnitude entry is positive.  out[3]. */
+size_t pm_pca_axis_workspace(int n);
+int pm_pca_axis(const double *xyz, int n, double *out3, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- shape context ------------------------------------------------------------------------- */
+
+/* get_unary (shape_context.py:144-188) for rows [row0, row0+nrows) of one cloud of n points:
+ * local frame per point (:169-175, 180-181), neighbours expressed in it (transform, :61-84),
+ * log-spherical histogram (get_shape_context :10-42, get_bin_index :46-58).
+ *   n_frames  2 (type='moving': sc, sc2) or 4 (type='fixed': sc, sc2, sc3, sc4)
+ *   counts    [n_frames][nrows][360] int32 — index.count(i) (:39-40); may be NULL
+ *   totals    [n_frames][nrows]      int32 — sc.sum() before normalising (:41); may be NULL
+ *   hist      [n_frames][nrows][360] float64 = counts / total (:41); may be NULL
+ * A row with nothing counted (point == centroid, axis parallel to z) is NaN in `hist`, as the
+ * reference's 0/0 is.  Row-block form: ranks of a multi-GPU run pass disjoint [row0, nrows). */
+int pm_shape_context(const double *xyz, int n, int row0, int nrows, const double *centroid3,
+                     const double *x0_3, const double *mean_dist1, int n_frames, int32_t *counts,
+                     int32_t *totals, double *hist, void *stream);
+
+/* get_shape_context (shape_context.py:10-42) on an explicit neighbour list already expressed in the
+ * local frame: nb is n x 3 row-major (x_, y_, z_ per row, as the reference passes it); counts[360]
+ * int32 and/or hist[360] float64 (= counts / counts.sum()); total[1] int32 may be NULL. */
+int pm_shape_context_neighbors(const double *nb, int n, double mean_dist, int32_t *counts, int32_t *total,
+                               double *hist, void *stream);
+
+/* ---- chi-square cost ----------------------------------------------------------------------- */
+
+/* get_unary_distance (shape_context.py:88-99) for every pair: out[i*ld + j] =
+ * 0.5 * sum_k (a_ik - b_jk)^2 / (a_ik + b_jk), bins with a == b skipped, summed k = 0..359
+ * in order in float64 — bit-identical to the reference's scalar loop. */
+int pm_chi2_cost(const double *scA, int nA, const double *scB, int nB, double *out, size_t ld,
+                 void *stream);
+
+/* The widget's eight N x M loops (_dock_widget.py:547-602) in one launch, for a row block of
+ * the moving cloud: out + h*matrix_stride is U_h[nM][ld] for h = 0..7 in the widget's order
+ * 11,12,13,14,21,22,23,24 (U_ab = moving frame a vs fixed frame b).
+ *   sc_m1, sc_m2          [nM][360]  this rank's rows of get_unary(moving) frames 1, 2
+ *   sc_f1 .. sc_f4        [nF][360]  all of get_unary(fixed) frames 1..4
+ * Every matrix is bit-identical to pm_chi2_cost on the same two descriptor sets. */
+int pm_chi2_cost8(const double *sc_m1, const double *sc_m2, int nM, const double *sc_f1,
+                  const double *sc_f2, const double *sc_f3, const double *sc_f4, int nF,
+                  double *out, size_t ld, size_t matrix_stride, void *stream);
+
+/* ---- RANSAC -------------------------------------------------------------------------------- */
+
+/* do_ransac's trial loop (shape_context.py:121-138) with the index sets drawn by the caller
+ * (the reference draws them with np.random.choice; the host mirror does the same, in the same
+ * order, so a seeded run sees identical sets).  Matched clouds are given indirectly:
+ * point k of the matched pair list is (mov[:, rows[k]], fix[:, cols[k]]) — the widget's
+ * moving[:, row_indices], fixed[:, col_indices] (_dock_widget.py:622-675); rows/cols may be NULL
+ * for the identity.  Per trial t: fit the affine through its `min_samples` (= 4) pairs
+ * (get_affine_transform, find_transform.py:4-17), apply it to all n pairs and count
+ * ||fixed - predicted|| <= error.
+ *   samples   [trials][4] int32 indices into the matched list
+ *   A_out     [trials][16] float64 row-major 4x4 (last row 0 0 0 1)
+ *   inliers   [trials] int32 */
+int pm_ransac_affine(const double *mov, int n_mov, const double *fix, int n_fix, const int32_t *rows,
+                     const int32_t *cols, int n, const int32_t *samples, int trials, double error,
+                     double *A_out, int32_t *inliers, void *stream);
+
+/* Score caller-supplied transforms instead of fitting (used for transform='Similar', whose fit
+ * stays on the host): A_in [trials][16]. */
+int pm_ransac_score(const double *mov, int n_mov, const double *fix, int n_fix, const int32_t *rows,
+                    const int32_t *cols, int n, const double *A_in, int trials, double error,
+                    int32_t *inliers, void *stream);
+
+/* ---- transforms ---------------------------------------------------------------------------- */
+
+/* apply_affine_transform (apply_transform.py:3-17): out(3 x n) = (A . [in; 1])[:3].  A is 16
+ * float64 row-major on the device.  in == out is allowed. */
+int pm_apply_affine(const double *A16, const double *in, int n, double *out, void *stream);
+
+/* get_affine_transform (find_transform.py:4-17) for full-rank input: least-squares 4x4 with
+ * [fixed;1] ~ A [moving;1], solved as centred normal equations (3x3 SPD solve + translation).
+ * If nn != NULL the pairing is (mov[:, i], fix[:, nn[i]]), i < n (ICP, perform_icp.py:18);
+ * else (mov[:, i], fix[:, i]).  A_out[16]. */
+size_t pm_fit_affine_workspace(int n);
+int pm_fit_affine(const double *mov, int n, const double *fix, int n_fix, const int32_t *nn,
+                  double *A_out16, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- ICP ----------------------------------------------------------------------------------- */
+
+/* perform_icp's correspondence step (perform_icp.py:15-16): nn[i] = argmin_j
+ * sqrt(sum((fix[:,j]-mov[:,i])**2)), first index on ties (scipy distance_matrix + np.argmin);
+ * dist[i] (may be NULL) = that distance.  The N x M matrix is never materialised. */
+size_t pm_icp_nn_workspace(int n, int m);
+int pm_icp_nn(const double *mov, int n, const double *fix, int m, int32_t *nn, double *dist,
+              void *ws, size_t ws_bytes, void *stream);
+
+/* Partial sums of one rank's block for the affine refit: sums[PM_ICP_NSUMS] =
+ * { n, sum m(3), sum f(3), sum m m^T (6: 00 01 02 11 12 22), sum f m^T (9 row-major), sum |f|^2, 0 } with
+ * m = mov[:, i] - origin_m, f = fix[:, nn[i]] - origin_f (origin6 = 3+3 doubles on the device:
+ * any fixed shift, e.g. the first points; improves conditioning, cancels in the solve).
+ * Multi-GPU ICP: every rank accumulates its rows, the 24 doubles are all-gathered and added in
+ * rank order, then pm_icp_update runs identically on every rank. */
+#define PM_ICP_NSUMS 24
+size_t pm_icp_accumulate_workspace(int n);
+int pm_icp_accumulate(const double *mov, int n, const double *fix, int m, const int32_t *nn,
+                      const double *origin6, double *sums, void *ws, size_t ws_bytes, void *stream);
+
+/* From (globally summed) sums: A_est = least-squares affine (perform_icp.py:18), mov <- A_est.mov
+ * in place (:23), A_icp <- A_est . A_icp (:25), residual1[0] += nothing; residual_parts receives
+ * this block's sum of ||mov_new - fix[nn]|| and count so the caller can form get_error (:24,
+ * utils.py:77-88) across ranks: residual_parts[2] = { sum, n }. */
+size_t pm_icp_update_workspace(int n);
+int pm_icp_update(const double *sums, const double *origin6, double *mov, int n, const double *fix,
+                  int m, const int32_t *nn, double *A_icp16, double *A_est16, double *residual_parts2,
+                  void *ws, size_t ws_bytes, void *stream);
+
+/* Same as pm_icp_update with the 4x4 given by the caller instead of solved from sums
+ * (transform='Similar': the quaternion eigen-problem of find_transform.py:55-66 stays on the host). */
+int pm_icp_apply(const double *A_est16, double *mov, int n, const double *fix, int m, const int32_t *nn,
+                 double *A_icp16, double *residual_parts2, void *ws, size_t ws_bytes, void *stream);
+
+/* get_error (utils/utils.py:77-88): out[1] = mean over columns of ||a[:, i] - b[:, i]||, a and b 3 x n. */
+size_t pm_get_error_workspace(int n);
+int pm_get_error(const double *a, const double *b, int n, double *out1, void *ws, size_t ws_bytes, void *stream);
+
+/* perform_icp (perform_icp.py:7-26), transform='Affine', whole loop on one device:
+ *   mov        3 x n, updated in place to the final moved cloud
+ *   A_icp      16 doubles out (starts from identity)
+ *   residuals  [iters] mean ||moving - fixed[:, nn]|| after each update (the value the reference prints); may be NULL
+ *   nn_all     [iters][n] int32 NN indices of every iteration; may be NULL
+ * iters == 0 returns the identity. */
+size_t pm_icp_workspace(int n, int m);
+int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_icp16,
+           double *residuals, int32_t *nn_all, void *ws, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLATYMATCH_HIP_H */

@@ -1,0 +1,300 @@
+"""Device-level wrappers: GPU tensors in, GPU tensors out, one C-ABI call each.
+
+Every function validates shapes, dtypes and index ranges on the host before a kernel is
+enqueued (a faulting kernel can take the whole node down), allocates outputs/workspace with
+torch, and launches on torch's current stream.  Clouds are float64 [3, N] contiguous.
+"""
+import numpy as np
+
+from . import _native as nat
+from ._native import NBINS, ICP_NSUMS, check, ptr
+
+
+def _t():
+    return nat.torch_mod()
+
+
+def _cloud(x, name="cloud"):
+    torch = _t()
+    if not (nat.is_torch(x) and x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.shape[0] == 3
+            and x.is_contiguous()):
+        raise ValueError("%s must be a contiguous float64 GPU tensor of shape [3, N]" % name)
+    if x.shape[1] < 1:
+        raise ValueError("%s is empty" % name)
+    if x.shape[1] >= 2 ** 31:
+        raise ValueError("%s too large" % name)
+    return x
+
+
+def _vec(x, n, name):
+    torch = _t()
+    if not (nat.is_torch(x) and x.is_cuda and x.dtype == torch.float64 and x.numel() == n and x.is_contiguous()):
+        raise ValueError("%s must be a contiguous float64 GPU tensor with %d elements" % (name, n))
+    return x
+
+
+def _idx(x, n, hi, name):
+    """int32 GPU index vector of length n with values in [0, hi) — range-checked here, not in the kernel."""
+    torch = _t()
+    if not (nat.is_torch(x) and x.is_cuda and x.dtype == torch.int32 and x.is_contiguous() and x.numel() == n):
+        raise ValueError("%s must be a contiguous int32 GPU tensor with %d elements" % (name, n))
+    if n and (int(x.min()) < 0 or int(x.max()) >= hi):
+        raise IndexError("%s has entries outside [0, %d)" % (name, hi))
+    return x
+
+
+def centroid(xyz):
+    xyz = _cloud(xyz)
+    out = _t().empty(3, dtype=_t().float64, device=xyz.device)
+    check(nat.load().pm_centroid(ptr(xyz), xyz.shape[1], ptr(out), 0, 0, nat.stream_ptr()))
+    return out
+
+
+def mean_distance(xyz):
+    xyz = _cloud(xyz)
+    n = xyz.shape[1]
+    if n < 2:
+        raise ValueError("mean distance needs at least two points")
+    lib = nat.load()
+    ws = nat.workspace(lib.pm_mean_distance_workspace(n), xyz.device)
+    out = _t().empty(1, dtype=_t().float64, device=xyz.device)
+    check(lib.pm_mean_distance(ptr(xyz), n, ptr(out), ptr(ws), ws.numel(), nat.stream_ptr()))
+    return out
+
+
+def pca_axis(xyz):
+    xyz = _cloud(xyz)
+    if xyz.shape[1] < 2:
+        raise ValueError("PCA axis needs at least two points")
+    out = _t().empty(3, dtype=_t().float64, device=xyz.device)
+    check(nat.load().pm_pca_axis(ptr(xyz), xyz.shape[1], ptr(out), 0, 0, nat.stream_ptr()))
+    return out
+
+
+def shape_context(xyz, centroid3, x0_3, mean_dist1, n_frames, row0=0, nrows=None, want_counts=False, want_hist=True):
+    """-> dict(hist=[F, nrows, 360] float64, counts=[F, nrows, 360] int32, totals=[F, nrows] int32)."""
+    torch = _t()
+    xyz = _cloud(xyz)
+    n = xyz.shape[1]
+    nrows = n - row0 if nrows is None else nrows
+    if n_frames not in (2, 4) or row0 < 0 or nrows < 0 or row0 + nrows > n:
+        raise ValueError("bad frame count or row block")
+    c = _vec(centroid3, 3, "centroid")
+    a = _vec(x0_3, 3, "x0")
+    md = _vec(mean_dist1, 1, "mean_dist")
+    hist = torch.empty((n_frames, nrows, NBINS), dtype=torch.float64, device=xyz.device) if want_hist else None
+    counts = torch.empty((n_frames, nrows, NBINS), dtype=torch.int32, device=xyz.device) if want_counts else None
+    totals = torch.empty((n_frames, nrows), dtype=torch.int32, device=xyz.device) if want_counts else None
+    if not (want_hist or want_counts):
+        raise ValueError("nothing requested")
+    check(nat.load().pm_shape_context(ptr(xyz), n, row0, nrows, ptr(c), ptr(a), ptr(md), n_frames, ptr(counts), ptr(totals),
+                                      ptr(hist), nat.stream_ptr()))
+    return {"hist": hist, "counts": counts, "totals": totals}
+
+
+def shape_context_neighbors(nb, mean_dist):
+    """nb: [n, 3] float64 GPU (frame coordinates) -> (hist[360] float64, counts[360] int32, total[1] int32)."""
+    torch = _t()
+    if not (nat.is_torch(nb) and nb.is_cuda and nb.dtype == torch.float64 and nb.dim() == 2 and nb.shape[1] == 3
+            and nb.is_contiguous() and nb.shape[0] >= 1):
+        raise ValueError("neighbors must be a contiguous float64 GPU tensor [n, 3]")
+    hist = torch.empty(NBINS, dtype=torch.float64, device=nb.device)
+    counts = torch.empty(NBINS, dtype=torch.int32, device=nb.device)
+    total = torch.empty(1, dtype=torch.int32, device=nb.device)
+    check(nat.load().pm_shape_context_neighbors(ptr(nb), nb.shape[0], float(mean_dist), ptr(counts), ptr(total), ptr(hist),
+                                                nat.stream_ptr()))
+    return hist, counts, total
+
+
+def _desc(x, name):
+    torch = _t()
+    if not (nat.is_torch(x) and x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.shape[1] == NBINS
+            and x.is_contiguous() and x.shape[0] >= 1):
+        raise ValueError("%s must be a contiguous float64 GPU tensor [N, 360]" % name)
+    return x
+
+
+def chi2_cost(scA, scB, out=None):
+    torch = _t()
+    a, b = _desc(scA, "scA"), _desc(scB, "scB")
+    nA, nB = a.shape[0], b.shape[0]
+    if out is None:
+        out = torch.empty((nA, nB), dtype=torch.float64, device=a.device)
+    elif not (out.is_cuda and out.dtype == torch.float64 and tuple(out.shape) == (nA, nB) and out.stride(1) == 1):
+        raise ValueError("out must be float64 GPU [nA, nB] with unit column stride")
+    check(nat.load().pm_chi2_cost(ptr(a), nA, ptr(b), nB, ptr(out), out.stride(0), nat.stream_ptr()))
+    return out
+
+
+def chi2_cost8(sc_m, sc_f, out=None):
+    """sc_m: [2, nM, 360], sc_f: [4, nF, 360] -> out [8, nM, nF] in the widget's order 11..14, 21..24."""
+    torch = _t()
+    if not (nat.is_torch(sc_m) and sc_m.dim() == 3 and sc_m.shape[0] == 2 and nat.is_torch(sc_f) and sc_f.dim() == 3
+            and sc_f.shape[0] == 4):
+        raise ValueError("sc_m must be [2, nM, 360] and sc_f [4, nF, 360]")
+    m = [_desc(sc_m[k], "sc_m[%d]" % k) for k in range(2)]
+    f = [_desc(sc_f[k], "sc_f[%d]" % k) for k in range(4)]
+    nM, nF = m[0].shape[0], f[0].shape[0]
+    if out is None:
+        out = torch.empty((8, nM, nF), dtype=torch.float64, device=sc_m.device)
+    elif not (out.is_cuda and out.dtype == torch.float64 and tuple(out.shape) == (8, nM, nF) and out.stride(2) == 1
+              and out.stride(0) >= nM * out.stride(1) and out.stride(1) >= nF):
+        raise ValueError("out must be float64 GPU [8, nM, nF] with unit column stride")
+    check(nat.load().pm_chi2_cost8(ptr(m[0]), ptr(m[1]), nM, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), nF, ptr(out),
+                                   out.stride(1), out.stride(0), nat.stream_ptr()))
+    return out
+
+
+def _pairs(mov, fix, rows, cols):
+    mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
+    if (rows is None) != (cols is None):
+        raise ValueError("rows and cols go together")
+    if rows is None:
+        if mov.shape[1] != fix.shape[1]:
+            raise ValueError("identity pairing needs clouds of equal size")
+        n = mov.shape[1]
+    else:
+        n = rows.numel()
+        rows = _idx(rows, n, mov.shape[1], "rows")
+        cols = _idx(cols, n, fix.shape[1], "cols")
+    return mov, fix, rows, cols, n
+
+
+def ransac_affine(mov, fix, rows, cols, samples, error):
+    """samples: [trials, 4] int32 GPU -> (A [trials, 4, 4] float64, inliers [trials] int32)."""
+    torch = _t()
+    mov, fix, rows, cols, n = _pairs(mov, fix, rows, cols)
+    if not (nat.is_torch(samples) and samples.dim() == 2 and samples.shape[1] == 4):
+        raise ValueError("samples must be [trials, 4] (min_samples = 4 is the only size the affine fit interpolates)")
+    trials = samples.shape[0]
+    samples = _idx(samples.reshape(-1), trials * 4, n, "samples")
+    A = torch.empty((trials, 4, 4), dtype=torch.float64, device=mov.device)
+    inl = torch.empty(trials, dtype=torch.int32, device=mov.device)
+    check(nat.load().pm_ransac_affine(ptr(mov), mov.shape[1], ptr(fix), fix.shape[1], ptr(rows), ptr(cols), n, ptr(samples),
+                                      trials, float(error), ptr(A), ptr(inl), nat.stream_ptr()))
+    return A, inl
+
+
+def ransac_score(mov, fix, rows, cols, A, error):
+    torch = _t()
+    mov, fix, rows, cols, n = _pairs(mov, fix, rows, cols)
+    if not (nat.is_torch(A) and A.is_cuda and A.dtype == torch.float64 and A.dim() == 3 and tuple(A.shape[1:]) == (4, 4)
+            and A.is_contiguous() and A.shape[0] >= 1):
+        raise ValueError("A must be a contiguous float64 GPU tensor [trials, 4, 4]")
+    inl = torch.empty(A.shape[0], dtype=torch.int32, device=mov.device)
+    check(nat.load().pm_ransac_score(ptr(mov), mov.shape[1], ptr(fix), fix.shape[1], ptr(rows), ptr(cols), n, ptr(A),
+                                     A.shape[0], float(error), ptr(inl), nat.stream_ptr()))
+    return inl
+
+
+def apply_affine(A, xyz, out=None):
+    xyz = _cloud(xyz)
+    A = _vec(A, 16, "A")
+    out = _t().empty_like(xyz) if out is None else _cloud(out, "out")
+    if out.shape != xyz.shape:
+        raise ValueError("out shape mismatch")
+    check(nat.load().pm_apply_affine(ptr(A), ptr(xyz), xyz.shape[1], ptr(out), nat.stream_ptr()))
+    return out
+
+
+def fit_affine(mov, fix, nn=None):
+    torch = _t()
+    mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
+    n = mov.shape[1]
+    if nn is None:
+        if fix.shape[1] != n:
+            raise ValueError("moving and fixed must pair up one to one")
+    else:
+        nn = _idx(nn, n, fix.shape[1], "nn")
+    lib = nat.load()
+    ws = nat.workspace(lib.pm_fit_affine_workspace(n), mov.device)
+    A = torch.empty((4, 4), dtype=torch.float64, device=mov.device)
+    check(lib.pm_fit_affine(ptr(mov), n, ptr(fix), fix.shape[1], ptr(nn), ptr(A), ptr(ws), ws.numel(), nat.stream_ptr()))
+    return A
+
+
+def icp_nn(mov, fix, want_dist=True):
+    torch = _t()
+    mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
+    n, m = mov.shape[1], fix.shape[1]
+    lib = nat.load()
+    ws = nat.workspace(lib.pm_icp_nn_workspace(n, m), mov.device)
+    nn = torch.empty(n, dtype=torch.int32, device=mov.device)
+    dist = torch.empty(n, dtype=torch.float64, device=mov.device) if want_dist else None
+    check(lib.pm_icp_nn(ptr(mov), n, ptr(fix), m, ptr(nn), ptr(dist), ptr(ws), ws.numel(), nat.stream_ptr()))
+    return nn, dist
+
+
+def icp_accumulate(mov, fix, nn, origin6):
+    torch = _t()
+    mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
+    n = mov.shape[1]
+    nn = None if nn is None else _idx(nn, n, fix.shape[1], "nn")
+    origin6 = _vec(origin6, 6, "origin")
+    lib = nat.load()
+    ws = nat.workspace(lib.pm_icp_accumulate_workspace(n), mov.device)
+    sums = torch.empty(ICP_NSUMS, dtype=torch.float64, device=mov.device)
+    check(lib.pm_icp_accumulate(ptr(mov), n, ptr(fix), fix.shape[1], ptr(nn), ptr(origin6), ptr(sums), ptr(ws), ws.numel(),
+                                nat.stream_ptr()))
+    return sums
+
+
+def icp_update(sums, origin6, mov, fix, nn, A_icp):
+    """In place: mov <- A_est mov, A_icp <- A_est A_icp.  -> (A_est [4,4], residual_parts [2] = (sum, n))."""
+    torch = _t()
+    mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
+    n = mov.shape[1]
+    nn = None if nn is None else _idx(nn, n, fix.shape[1], "nn")
+    sums, origin6 = _vec(sums, ICP_NSUMS, "sums"), _vec(origin6, 6, "origin")
+    A_icp = _vec(A_icp, 16, "A_icp")
+    lib = nat.load()
+    ws = nat.workspace(lib.pm_icp_update_workspace(n), mov.device)
+    A_est = torch.empty((4, 4), dtype=torch.float64, device=mov.device)
+    parts = torch.empty(2, dtype=torch.float64, device=mov.device)
+    check(lib.pm_icp_update(ptr(sums), ptr(origin6), ptr(mov), n, ptr(fix), fix.shape[1], ptr(nn), ptr(A_icp), ptr(A_est),
+                            ptr(parts), ptr(ws), ws.numel(), nat.stream_ptr()))
+    return A_est, parts
+
+
+def icp_apply(A_est, mov, fix, nn, A_icp):
+    torch = _t()
+    mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
+    n = mov.shape[1]
+    nn = None if nn is None else _idx(nn, n, fix.shape[1], "nn")
+    A_est, A_icp = _vec(A_est, 16, "A_est"), _vec(A_icp, 16, "A_icp")
+    lib = nat.load()
+    ws = nat.workspace(lib.pm_icp_update_workspace(n), mov.device)
+    parts = torch.empty(2, dtype=torch.float64, device=mov.device)
+    check(lib.pm_icp_apply(ptr(A_est), ptr(mov), n, ptr(fix), fix.shape[1], ptr(nn), ptr(A_icp), ptr(parts), ptr(ws),
+                           ws.numel(), nat.stream_ptr()))
+    return parts
+
+
+def get_error(a, b):
+    a, b = _cloud(a, "moving"), _cloud(b, "fixed")
+    if a.shape != b.shape:
+        raise ValueError("clouds must have equal shape")
+    lib = nat.load()
+    ws = nat.workspace(lib.pm_get_error_workspace(a.shape[1]), a.device)
+    out = _t().empty(1, dtype=_t().float64, device=a.device)
+    check(lib.pm_get_error(ptr(a), ptr(b), a.shape[1], ptr(out), ptr(ws), ws.numel(), nat.stream_ptr()))
+    return out
+
+
+def icp(mov, fix, iters, want_nn=False, ws=None):
+    """Affine ICP loop on the device.  `mov` is updated IN PLACE.
+    -> (A_icp [4,4], residuals [iters], nn_all [iters, n] or None)."""
+    torch = _t()
+    mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
+    n, m = mov.shape[1], fix.shape[1]
+    if iters < 0:
+        raise ValueError("iterations must be >= 0")
+    lib = nat.load()
+    need = lib.pm_icp_workspace(n, m)
+    if ws is None or ws.numel() < need:
+        ws = nat.workspace(need, mov.device)
+    A = torch.empty((4, 4), dtype=torch.float64, device=mov.device)
+    res = torch.empty(max(iters, 1), dtype=torch.float64, device=mov.device)
+    nn_all = torch.empty((max(iters, 1), n), dtype=torch.int32, device=mov.device) if want_nn else None
+    check(lib.pm_icp(ptr(mov), n, ptr(fix), m, iters, ptr(A), ptr(res), ptr(nn_all), ptr(ws), ws.numel(), nat.stream_ptr()))
+    return A, res[:iters], (nn_all[:iters] if want_nn else None)

@@ -1,0 +1,147 @@
+"""ctypes binding of libplatymatch_hip.so (include/platymatch_hip.h) and device plumbing.
+
+There is no CPU fallback: if the library cannot be loaded, or no ROCm device is visible, every
+product entry point raises.  torch is used for device memory, streams and (elsewhere)
+torch.distributed only; every number is produced by the HIP kernels.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplatymatch_hip.so")
+NBINS = 360
+ICP_NSUMS = 24
+_lib = None
+_lock = threading.Lock()
+
+_c_void_p, _c_int, _c_size_t, _c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_double
+
+# name -> (restype, argtypes); mirrors include/platymatch_hip.h one to one
+SIGNATURES = {
+    "pm_version": (_c_int, []),
+    "pm_error_string": (ctypes.c_char_p, [_c_int]),
+    "pm_last_hip_error": (_c_int, []),
+    "pm_centroid_workspace": (_c_size_t, [_c_int]),
+    "pm_centroid": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_mean_distance_workspace": (_c_size_t, [_c_int]),
+    "pm_mean_distance": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_pca_axis_workspace": (_c_size_t, [_c_int]),
+    "pm_pca_axis": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_shape_context": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int,
+                                  _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_shape_context_neighbors": (_c_int, [_c_void_p, _c_int, _c_double, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_chi2_cost": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_chi2_cost8": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
+                               _c_void_p, _c_size_t, _c_size_t, _c_void_p]),
+    "pm_ransac_affine": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int,
+                                  _c_double, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_ransac_score": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int,
+                                 _c_double, _c_void_p, _c_void_p]),
+    "pm_apply_affine": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p]),
+    "pm_fit_affine_workspace": (_c_size_t, [_c_int]),
+    "pm_fit_affine": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_icp_nn_workspace": (_c_size_t, [_c_int, _c_int]),
+    "pm_icp_nn": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_icp_accumulate_workspace": (_c_size_t, [_c_int]),
+    "pm_icp_accumulate": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                   _c_size_t, _c_void_p]),
+    "pm_icp_update_workspace": (_c_size_t, [_c_int]),
+    "pm_icp_update": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
+                               _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_icp_apply": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                              _c_size_t, _c_void_p]),
+    "pm_get_error_workspace": (_c_size_t, [_c_int]),
+    "pm_get_error": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_icp_workspace": (_c_size_t, [_c_int, _c_int]),
+    "pm_icp": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                        _c_size_t, _c_void_p]),
+}
+
+
+class NativeError(RuntimeError):
+    """libplatymatch_hip.so returned a PM_ERR_* code."""
+
+
+def load():
+    """Load the C-ABI library and declare every prototype.  Raises if it is missing:
+    the product has no other implementation to fall back to."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NativeError(
+                    "%s not found. Build it with `python -m platymatch_amd.build` (needs hipcc); "
+                    "platymatch_amd has no CPU fallback." % LIB_PATH)
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
+                fn.restype = res
+                fn.argtypes = args
+            if lib.pm_version() != 1:
+                raise NativeError("libplatymatch_hip.so ABI version %d, expected 1" % lib.pm_version())
+            _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        lib = load()
+        msg = lib.pm_error_string(rc).decode()
+        if rc == -3:
+            msg += " [hipError %d]" % lib.pm_last_hip_error()
+        if rc == -1:
+            raise ValueError("platymatch_hip: " + msg)
+        raise NativeError("platymatch_hip: " + msg)
+
+
+# ------------------------------------------------------------------------------------------- device
+def torch_mod():
+    import torch
+    return torch
+
+
+def device(dev=None):
+    torch = torch_mod()
+    if not torch.cuda.is_available():
+        raise NativeError("no ROCm device visible: platymatch_amd runs on an AMD GPU only (no CPU fallback)")
+    if dev is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device(dev)
+
+
+def stream_ptr():
+    return torch_mod().cuda.current_stream().cuda_stream
+
+
+def is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def to_dev(x, dtype=None, dev=None):
+    """numpy / torch (any device) -> contiguous torch tensor on the GPU."""
+    torch = torch_mod()
+    dtype = dtype or torch.float64
+    if is_torch(x):
+        t = x.to(device=device(dev) if not x.is_cuda else x.device, dtype=dtype)
+    else:
+        t = torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(device(dev))
+    return t.contiguous()
+
+
+def like_input(t, ref):
+    """Return `t` (a GPU tensor) as the kind of array `ref` was: numpy in -> numpy out."""
+    if is_torch(ref):
+        return t
+    return t.cpu().numpy()
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def workspace(nbytes, dev):
+    torch = torch_mod()
+    return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=dev)

@@ -1,0 +1,131 @@
+// pm_ransac.hip — RANSAC trial scoring.
+// Reference: do_ransac (shape_context.py:103-139), called on the matched pair lists
+// moving[:, row_indices], fixed[:, col_indices] (_dock_widget.py:622-675).
+//
+// The reference runs `trials` sequential iterations of {draw 4 pairs, fit, apply to all, count
+// inliers}.  Trials are independent given their index sets, so the host draws every set first (same
+// RNG calls, same order) and one launch evaluates them all: lane <-> trial (its 4x4 stays in
+// registers), the matched pairs stream through LDS as wave-uniform broadcasts, the four waves of a
+// workgroup split each staged chunk and their counts are added at the end.
+// The 4-pair fit is the exact interpolating affine (find_transform.py:4-17 on a square, full-rank
+// system), obtained like every other fit here from centred moments (pm_solve.h).
+#include "pm_common.h"
+#include "pm_solve.h"
+
+namespace pm {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = 4;
+constexpr int RS_CHUNK = 512;
+constexpr int RS_SUB = RS_CHUNK / RS_WAVES;
+
+template <bool FIT>
+__global__ __launch_bounds__(RS_THREADS) void ransac_kernel(const double *__restrict__ mov, int n_mov,
+                                                            const double *__restrict__ fix, int n_fix,
+                                                            const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
+                                                            int n, const int32_t *__restrict__ samples,
+                                                            const double *__restrict__ A_in, int trials, double error,
+                                                            double *__restrict__ A_out, int32_t *__restrict__ inliers) {
+    __shared__ double Pm[3][RS_CHUNK];
+    __shared__ double Pf[3][RS_CHUNK];
+    __shared__ int cnt_s[RS_WAVES][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = blockIdx.x * 64 + lane;
+    const int tc = min(t, trials - 1);
+
+    double A[16];
+    if (FIT) {
+        // moments of the four sampled pairs about the first of them
+        double sums[PM_ICP_NSUMS], origin[6];
+#pragma unroll
+        for (int k = 0; k < PM_ICP_NSUMS; ++k) sums[k] = 0.0;
+        sums[0] = 4.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = samples[(size_t)tc * 4 + q];
+            const int im = rows ? rows[k] : k, jf = cols ? cols[k] : k;
+            double a[3], f[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a[c] = mov[(size_t)c * n_mov + im]; f[c] = fix[(size_t)c * n_fix + jf]; }
+            if (q == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { origin[c] = a[c]; origin[3 + c] = f[c]; }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a[c] -= origin[c]; f[c] -= origin[3 + c]; }
+            sums[1] += a[0]; sums[2] += a[1]; sums[3] += a[2];
+            sums[4] += f[0]; sums[5] += f[1]; sums[6] += f[2];
+            sums[7] += a[0] * a[0]; sums[8] += a[0] * a[1]; sums[9] += a[0] * a[2];
+            sums[10] += a[1] * a[1]; sums[11] += a[1] * a[2]; sums[12] += a[2] * a[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sums[13 + 3 * r + c] += f[r] * a[c];
+            sums[22] += (f[0] * f[0] + f[1] * f[1]) + f[2] * f[2];
+        }
+        affine_from_sums(sums, origin, A);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) A[k] = A_in[(size_t)tc * 16 + k];
+    }
+
+    int cnt = 0;
+    for (int c0 = 0; c0 < n; c0 += RS_CHUNK) {
+        __syncthreads();
+        for (int e = tid; e < RS_CHUNK; e += RS_THREADS) {
+            const int k = c0 + e;
+            if (k < n) {
+                const int im = rows ? rows[k] : k, jf = cols ? cols[k] : k;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { Pm[c][e] = mov[(size_t)c * n_mov + im]; Pf[c][e] = fix[(size_t)c * n_fix + jf]; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { Pm[c][e] = 0.0; Pf[c][e] = NAN; }   // NaN distance: never an inlier
+            }
+        }
+        __syncthreads();
+        const int e0 = wave * RS_SUB;
+#pragma unroll 4
+        for (int e = e0; e < e0 + RS_SUB; ++e) {
+            const double x = Pm[0][e], y = Pm[1][e], z = Pm[2][e];
+            const double d0 = Pf[0][e] - (((A[0] * x + A[1] * y) + A[2] * z) + A[3]);
+            const double d1 = Pf[1][e] - (((A[4] * x + A[5] * y) + A[6] * z) + A[7]);
+            const double d2 = Pf[2][e] - (((A[8] * x + A[9] * y) + A[10] * z) + A[11]);
+            const double d = __builtin_sqrt((d0 * d0 + d1 * d1) + d2 * d2);   // np.linalg.norm (:133)
+            cnt += (d <= error) ? 1 : 0;                                        // :134
+        }
+    }
+    cnt_s[wave][lane] = cnt;
+    __syncthreads();
+    if (wave == 0 && t < trials) {
+        inliers[t] = cnt_s[0][lane] + cnt_s[1][lane] + cnt_s[2][lane] + cnt_s[3][lane];
+        if (FIT && A_out) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) A_out[(size_t)t * 16 + k] = A[k];
+        }
+    }
+}
+
+}  // namespace pm
+
+extern "C" {
+
+int pm_ransac_affine(const double *mov, int n_mov, const double *fix, int n_fix, const int32_t *rows, const int32_t *cols,
+                     int n, const int32_t *samples, int trials, double error, double *A_out, int32_t *inliers,
+                     void *stream) {
+    if (!mov || !fix || !samples || !inliers || n_mov <= 0 || n_fix <= 0 || n <= 0 || trials <= 0) return PM_ERR_INVALID_ARG;
+    pm::ransac_kernel<true><<<(trials + 63) / 64, pm::RS_THREADS, 0, (hipStream_t)stream>>>(
+        mov, n_mov, fix, n_fix, rows, cols, n, samples, nullptr, trials, error, A_out, inliers);
+    return pm::launch_status();
+}
+
+int pm_ransac_score(const double *mov, int n_mov, const double *fix, int n_fix, const int32_t *rows, const int32_t *cols,
+                    int n, const double *A_in, int trials, double error, int32_t *inliers, void *stream) {
+    if (!mov || !fix || !A_in || !inliers || n_mov <= 0 || n_fix <= 0 || n <= 0 || trials <= 0) return PM_ERR_INVALID_ARG;
+    pm::ransac_kernel<false><<<(trials + 63) / 64, pm::RS_THREADS, 0, (hipStream_t)stream>>>(
+        mov, n_mov, fix, n_fix, rows, cols, n, nullptr, A_in, trials, error, nullptr, inliers);
+    return pm::launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+"""Shape-context descriptors, chi-square distance and RANSAC with the reference's names
+(platymatch/estimate_transform/shape_context.py).  NumPy or torch in, same kind out.
+
+Like the reference module (`from apply_transform import *`, shape_context.py:4) this one also
+re-exports apply_affine_transform / apply_similar_transform.
+"""
+import numpy as np
+
+from .. import _kernels as K
+from .. import _native as nat
+from .apply_transform import apply_affine_transform, apply_similar_transform  # noqa: F401
+from .find_transform import get_affine_transform, get_similar_transform  # noqa: F401
+
+HYPOTHESES = ("11", "12", "13", "14", "21", "22", "23", "24")   # widget order, _dock_widget.py:547-611
+
+
+def get_Y(z, x):
+    """shape_context.py:6-8: unit(z x x).  Three-vector helper; the per-point frames of get_unary are
+    built inside the shape-context kernel, this is kept for API compatibility."""
+    y = np.cross(np.asarray(z, dtype=np.float64), np.asarray(x, dtype=np.float64))
+    return y / np.linalg.norm(y)
+
+
+def get_shape_context(neighbors, mean_dist, r_inner=1 / 8, r_outer=2, n_rbins=5, n_thetabins=6, n_phibins=12):
+    """shape_context.py:10-42: histogram of neighbours already expressed in the local frame
+    ((N-1) x 3 rows of x_, y_, z_), normalised by the number counted."""
+    if (r_inner, r_outer, n_rbins, n_thetabins, n_phibins) != (1 / 8, 2, 5, 6, 12):
+        raise ValueError("only the reference's default binning (r 1/8..2, 5 x 6 x 12) is implemented: "
+                         "the reference never passes anything else (SURVEY.md §5)")
+    nb = nat.to_dev(neighbors)
+    if nb.dim() != 2 or nb.shape[1] != 3:
+        raise ValueError("neighbors must be (N-1) x 3")
+    hist, _, _ = K.shape_context_neighbors(nb.contiguous(), float(mean_dist))
+    return nat.like_input(hist, neighbors)
+
+
+def get_bin_index(r, theta, phi, r_edges, n_rbins, n_thetabins, n_phibins):
+    """shape_context.py:46-58 on explicit (r, theta, phi) lists -> list of float bin indices.
+    Legacy helper on host lists, kept for API compatibility: the device path never materialises
+    angles (pm_binning.h bins by comparison), so nothing on the hot path calls this."""
+    r, theta, phi = (np.asarray(v, dtype=np.float64) for v in (r, theta, phi))
+    edges = np.asarray(r_edges, dtype=np.float64)
+    below = r[:, None] < edges[None, :]
+    r_index = np.where(below.any(1), below.argmax(1), n_rbins - 1).astype(np.float64)
+    theta_index = theta // (np.pi / n_thetabins)
+    phi_index = phi // (2 * np.pi / n_phibins)
+    return list(r_index * n_thetabins * n_phibins + theta_index * n_phibins + phi_index)
+
+
+def transform(detection, x_vector, y_vector, z_vector, neighbors):
+    """shape_context.py:61-84: express `neighbors` ((N-1) x 3) in the frame (x, y, z) at `detection`.
+    The 4 x 4 map T = B . inv(A) is formed on the host exactly as the reference does (one 4 x 4
+    inverse) and applied to the points on the device."""
+    det = np.asarray(nat.to_dev(detection).cpu().numpy(), dtype=np.float64).reshape(3)
+    vx, vy, vz = (np.asarray(nat.to_dev(v).cpu().numpy(), dtype=np.float64).reshape(3) for v in (x_vector, y_vector, z_vector))
+    A = np.ones((4, 4))
+    A[0, :3], A[1, :3], A[2, :3], A[3, :3] = det, det + vx, det + vy, det + vz
+    B = np.array([[0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1], [1, 1, 1, 1]], dtype=np.float64)
+    T = np.matmul(B, np.linalg.inv(A.T))
+    nb = nat.to_dev(neighbors)
+    if nb.dim() != 2 or nb.shape[1] != 3:
+        raise ValueError("neighbors must be (N-1) x 3")
+    T[3, :] = [0, 0, 0, 1]
+    out = K.apply_affine(nat.to_dev(T, dev=nb.device).reshape(16), nb.t().contiguous())
+    return nat.like_input(out.t().contiguous(), neighbors)
+
+
+def get_unary_distance(sc1, sc2):
+    """shape_context.py:88-99 for one pair of descriptors (kept for the widget's per-pair loops;
+    use unary_distance_matrix / unary_distance_matrices for whole clouds)."""
+    a, b = nat.to_dev(sc1).reshape(1, -1), nat.to_dev(sc2).reshape(1, -1)
+    d = K.chi2_cost(a.contiguous(), b.contiguous())
+    return d[0, 0] if nat.is_torch(sc1) else float(d.item())
+
+
+def unary_distance_matrix(scA, scB):
+    """U[i, j] = get_unary_distance(scA[i], scB[j]) for all pairs (_dock_widget.py:547-602), bit-identical
+    to the scalar loop."""
+    a, b = nat.to_dev(scA), nat.to_dev(scB)
+    return nat.like_input(K.chi2_cost(a.contiguous(), b.contiguous()), scA)
+
+
+def unary_distance_matrices(unary_moving, unary_fixed, out=None):
+    """The widget's eight cost matrices in one launch: unary_moving = (sc, sc2) from
+    get_unary(..., 'moving'), unary_fixed = (sc, sc2, sc3, sc4) from get_unary(..., 'fixed').
+    -> [8, N, M] in the order U11, U12, U13, U14, U21, U22, U23, U24."""
+    torch = nat.torch_mod()
+    m = torch.stack([nat.to_dev(unary_moving[k]) for k in range(2)]) if not _stacked(unary_moving, 2) else unary_moving
+    f = torch.stack([nat.to_dev(unary_fixed[k]) for k in range(4)]) if not _stacked(unary_fixed, 4) else unary_fixed
+    U = K.chi2_cost8(m.contiguous(), f.contiguous(), out=out)
+    return U if (nat.is_torch(unary_moving[0]) or out is not None) else U.cpu().numpy()
+
+
+def _stacked(x, k):
+    return nat.is_torch(x) and x.dim() == 3 and x.shape[0] == k and x.is_cuda
+
+
+def draw_ransac_samples(n, min_samples, trials):
+    """The index sets do_ransac draws: one np.random.choice(n, min_samples, replace=False) per trial
+    from NumPy's global RNG, in trial order (shape_context.py:122) — so np.random.seed(s) before a
+    call reproduces the reference's sets exactly."""
+    return np.stack([np.random.choice(n, min_samples, replace=False) for _ in range(trials)]).astype(np.int32)
+
+
+def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transform='Affine', rows=None, cols=None):
+    """shape_context.py:103-139 -> (A_best 4 x 4, inliers_best).
+
+    The host draws the index sets (same RNG calls as the reference); one kernel launch fits and
+    scores every trial.  The first trial with strictly more inliers than all before it wins;
+    with no inliers at all A_best stays np.ones((4, 4)), as in the reference (:119-120, 136-138).
+    `rows`/`cols` (optional) select matched pairs without gathering on the host:
+    pairs are (moving_all[:, rows[k]], fixed_all[:, cols[k]])."""
+    torch = nat.torch_mod()
+    m, f = nat.to_dev(moving_all), nat.to_dev(fixed_all)
+    if m.dim() != 2 or f.dim() != 2:
+        raise ValueError("clouds must be 3 x N or 4 x N")
+    if m.shape[0] == 4 or f.shape[0] == 4:
+        m, f = m[:3, :], f[:3, :]
+    m, f = m.contiguous(), f.contiguous()
+    if rows is not None:
+        rows = nat.to_dev(rows, dtype=torch.int32, dev=m.device)
+        cols = nat.to_dev(cols, dtype=torch.int32, dev=m.device)
+        n = rows.numel()
+    else:
+        n = f.shape[1]
+    trials = int(trials)
+    ones = np.ones((4, 4))
+    if trials <= 0:
+        return (torch.as_tensor(ones, device=m.device) if nat.is_torch(moving_all) else ones), 0
+    samples = draw_ransac_samples(n, int(min_samples), trials)
+    if transform == 'Affine':
+        if int(min_samples) != 4:
+            raise ValueError("the device path fits the affine through exactly 4 pairs (the widget's default, "
+                             "_dock_widget.py:327); got min_samples=%d" % min_samples)
+        A, inl = K.ransac_affine(m, f, rows, cols, nat.to_dev(samples, dtype=torch.int32, dev=m.device), float(error))
+    elif transform == 'Similar':
+        mh, fh = m.cpu().numpy(), f.cpu().numpy()
+        if rows is not None:
+            mh, fh = mh[:, rows.cpu().numpy()], fh[:, cols.cpu().numpy()]
+        from .find_transform import similar_from_sums
+        A_h = np.stack([similar_from_sums(_host_sums(mh[:, s], fh[:, s]), np.zeros(6)) for s in samples])
+        A = nat.to_dev(A_h, dev=m.device)
+        inl = K.ransac_score(m, f, rows, cols, A, float(error))
+    else:
+        raise ValueError("transform must be 'Affine' or 'Similar'")
+    inl_h = inl.cpu().numpy()
+    best = int(np.argmax(inl_h))          # first maximum == first strictly-better trial
+    if inl_h[best] <= 0:
+        return (torch.as_tensor(ones, device=m.device) if nat.is_torch(moving_all) else ones), 0
+    A_best = A[best]
+    return (A_best if nat.is_torch(moving_all) else A_best.cpu().numpy()), int(inl_h[best])
+
+
+def _host_sums(P, Y):
+    """24 moment sums (pm_icp_accumulate layout, origin 0) of a handful of sampled pairs — host side,
+    used only by the 'Similar' RANSAC fit whose eigen-problem is on the host anyway."""
+    s = np.zeros(24)
+    s[0] = P.shape[1]
+    s[1:4], s[4:7] = P.sum(1), Y.sum(1)
+    PP = P @ P.T
+    s[7:13] = [PP[0, 0], PP[0, 1], PP[0, 2], PP[1, 1], PP[1, 2], PP[2, 2]]
+    s[13:22] = (Y @ P.T).reshape(-1)
+    s[22] = (Y * Y).sum()
+    return s
+
+
+def get_unary(centroid, mean_distance, detections, type, transposed=False, x0=None):
+    """shape_context.py:144-188 -> (sc, sc2, sc3, sc4), each (N, 360) float64; sc3 and sc4 are empty
+    (shape (0,)) unless type == 'fixed', as in the reference.
+
+    centroid: 3 x 1 (or 1 x 3 with transposed=True); detections: 3 x N (or N x 3); a 4th
+    row/column is dropped (:156-157).  The first PCA axis the reference gets from sklearn
+    (:162-165) is computed on the device unless `x0` is given."""
+    torch = nat.torch_mod()
+    d = nat.to_dev(detections)
+    if d.dim() != 2:
+        raise ValueError("detections must be 2-D")
+    if transposed:
+        d = d.t()
+    if d.shape[0] not in (3, 4):
+        raise ValueError("detections must be 3 x N (N x 3 with transposed=True)")
+    xyz = d[:3, :].contiguous()
+    c = nat.to_dev(centroid, dev=xyz.device).reshape(-1)[:3].contiguous()
+    md = nat.to_dev(mean_distance, dev=xyz.device).reshape(1)
+    axis = K.pca_axis(xyz) if x0 is None else nat.to_dev(x0, dev=xyz.device).reshape(3).contiguous()
+    nf = 4 if type == 'fixed' else 2
+    hist = K.shape_context(xyz, c, axis, md, nf)["hist"]
+    outs = [nat.like_input(hist[k], detections) for k in range(nf)]
+    if nf == 2:
+        empty = torch.empty(0, dtype=torch.float64, device=xyz.device) if nat.is_torch(detections) else np.array([])
+        outs += [empty, empty]
+    return tuple(outs)

@@ -1,0 +1,261 @@
+"""Headless estimate_transform: the stage order of the napari widget's worker
+(EstimateTransform._click_run, platymatch/_dock_widget.py:526-718) as a function, on one GPU or
+row-sharded over the GPUs of a node (one process per GPU, torch.distributed / RCCL).
+
+Sharding: rank g owns a contiguous block of moving rows and of fixed rows.
+  descriptors   each rank builds its rows; the fixed descriptor sets are all-gathered (the one
+                exchange the cost build needs — every moving row is compared with every fixed row);
+  cost matrices each rank fills its [8, rows_g, M] block — no communication;
+  assembly      for the host Hungarian solves, hypothesis h's full matrix is collected on rank
+                h mod G (one collective per hypothesis), the ranks solve their hypotheses in
+                parallel and the index vectors are all-gathered;
+  ICP           moving rows sharded, fixed replicated; per iteration the 24 moment sums are
+                all-gathered and added in rank order so every rank solves the identical 4x4.
+Cloud statistics (centroid, mean distance, PCA axis) are O(N)…O(N^2) on 24·N bytes and are computed
+redundantly by every rank: identical inputs and a fixed reduction order give identical values
+without a collective.
+"""
+import numpy as np
+from scipy.optimize import linear_sum_assignment
+
+from . import _native as nat
+
+HYPOTHESES = ("11", "12", "13", "14", "21", "22", "23", "24")
+
+
+class GpuBackend:
+    """The product's only compute backend: the HIP kernels behind libplatymatch_hip.so."""
+
+    def __init__(self, dev=None):
+        from . import _kernels
+        self.K = _kernels
+        self.device = nat.device(dev)
+
+    def cloud(self, x):
+        t = nat.to_dev(x, dev=self.device)
+        if t.dim() != 2 or t.shape[0] not in (3, 4):
+            raise ValueError("clouds must be 3 x N (or 4 x N)")
+        return t[:3, :].contiguous()
+
+    def stats(self, xyz):
+        return self.K.centroid(xyz), self.K.mean_distance(xyz), self.K.pca_axis(xyz)
+
+    def shape_context(self, xyz, c, md, x0, nf, row0, nrows):
+        return self.K.shape_context(xyz, c, x0, md, nf, row0=row0, nrows=nrows)["hist"]
+
+    def chi2_cost8(self, sc_m, sc_f):
+        return self.K.chi2_cost8(sc_m, sc_f)
+
+    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples):
+        from .estimate_transform.shape_context import do_ransac
+        return do_ransac(mov, fix, min_samples=min_samples, trials=trials, error=error, transform=transform,
+                         rows=rows, cols=cols)
+
+    def fit(self, kp_m, kp_f, transform):
+        from .estimate_transform.find_transform import get_affine_transform, get_similar_transform
+        fn = get_affine_transform if transform == 'Affine' else get_similar_transform
+        return nat.to_dev(fn(kp_m, kp_f), dev=self.device)
+
+    def apply_affine(self, A, xyz):
+        return self.K.apply_affine(A.reshape(16).contiguous(), xyz)
+
+    def icp(self, mov, fix, iters, transform, log):
+        from .estimate_transform.perform_icp import perform_icp
+        return perform_icp(mov, fix, iters, transform, log=log)
+
+    def icp_nn(self, mov, fix):
+        return self.K.icp_nn(mov, fix, want_dist=False)[0]
+
+    def icp_accumulate(self, mov, fix, nn, origin):
+        return self.K.icp_accumulate(mov, fix, nn, origin)
+
+    def icp_update(self, sums, origin, mov, fix, nn, A_icp):
+        return self.K.icp_update(sums, origin, mov, fix, nn, A_icp)
+
+
+def shard_bounds(n, world):
+    """Contiguous row blocks, sizes differing by at most one: block g = [b[g], b[g+1])."""
+    base, extra = divmod(n, world)
+    b = [0]
+    for g in range(world):
+        b.append(b[-1] + base + (1 if g < extra else 0))
+    return b
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def _world(group):
+    if group is None:
+        return 0, 1
+    dist = _dist()
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def _global_rank(group, group_rank):
+    dist = _dist()
+    if group is None or group is dist.group.WORLD:
+        return group_rank
+    return dist.get_global_rank(group, group_rank)
+
+
+def all_gather_rows(local, bounds, dim, group):
+    """All-gather blocks of unequal row counts along `dim` (padded to the largest block: RCCL's
+    all-gather wants equal contributions)."""
+    import torch
+    dist = _dist()
+    world = len(bounds) - 1
+    if world == 1:
+        return local
+    biggest = max(bounds[g + 1] - bounds[g] for g in range(world))
+    shape = list(local.shape)
+    shape[dim] = biggest
+    padded = torch.zeros(shape, dtype=local.dtype, device=local.device)
+    padded.narrow(dim, 0, local.shape[dim]).copy_(local)
+    gathered = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded.contiguous(), group=group)
+    return torch.cat([gathered[g].narrow(dim, 0, bounds[g + 1] - bounds[g]) for g in range(world)], dim=dim)
+
+
+def build_descriptors(be, mov, fix, group=None):
+    """Stages 526-545 of the widget: statistics and get_unary for both clouds.
+    -> (sc_m [2, rows_g, 360], sc_f [4, M, 360] complete, moving row bounds)."""
+    rank, world = _world(group)
+    n, m = mov.shape[1], fix.shape[1]
+    cm, mdm, x0m = be.stats(mov)
+    cf, mdf, x0f = be.stats(fix)
+    bn, bm = shard_bounds(n, world), shard_bounds(m, world)
+    sc_m = be.shape_context(mov, cm, mdm, x0m, 2, bn[rank], bn[rank + 1] - bn[rank])
+    sc_f_loc = be.shape_context(fix, cf, mdf, x0f, 4, bm[rank], bm[rank + 1] - bm[rank])
+    sc_f = all_gather_rows(sc_f_loc, bm, 1, group)
+    return sc_m, sc_f, bn
+
+
+def build_costs(be, mov, fix, group=None):
+    """Descriptors + the eight chi-square matrices for this rank's moving rows -> (U [8, rows_g, M], bounds)."""
+    sc_m, sc_f, bn = build_descriptors(be, mov, fix, group)
+    return be.chi2_cost8(sc_m, sc_f), bn
+
+
+def assign(U_loc, bounds, group=None):
+    """linear_sum_assignment on each of the eight matrices (_dock_widget.py:604-611) -> list of
+    (row_ind, col_ind) int64 arrays, identical on every rank.  SciPy stays the solver: it defines
+    the reference's tie-breaking.  Sharded: hypothesis h is assembled on rank h mod G."""
+    import torch
+    rank, world = _world(group)
+    if world == 1:
+        return [linear_sum_assignment(U_loc[h].cpu().numpy()) for h in range(8)]
+    dist = _dist()
+    n = bounds[-1]
+    biggest = max(bounds[g + 1] - bounds[g] for g in range(world))
+    mine = {}
+    for h in range(8):
+        owner = h % world
+        padded = torch.zeros((biggest, U_loc.shape[2]), dtype=U_loc.dtype, device=U_loc.device)
+        padded[:U_loc.shape[1]].copy_(U_loc[h])
+        blocks = [torch.empty_like(padded) for _ in range(world)] if owner == rank else None
+        dist.gather(padded, blocks, dst=_global_rank(group, owner), group=group)   # row blocks -> the owner only
+        if owner == rank:    # keep the assembled matrix on the host; solve after all gathers so ranks solve concurrently
+            mine[h] = torch.cat([blocks[g][:bounds[g + 1] - bounds[g]] for g in range(world)], dim=0).cpu().numpy()
+            del blocks
+    for h in list(mine):
+        mine[h] = linear_sum_assignment(mine[h])
+    k = min(n, U_loc.shape[2])
+    out = []
+    for h in range(8):
+        buf = torch.zeros((2, k), dtype=torch.int64, device=U_loc.device)
+        if h in mine:
+            buf[0] = torch.as_tensor(mine[h][0], device=U_loc.device)
+            buf[1] = torch.as_tensor(mine[h][1], device=U_loc.device)
+        dist.broadcast(buf, src=_global_rank(group, h % world), group=group)
+        out.append((buf[0].cpu().numpy(), buf[1].cpu().numpy()))
+    return out
+
+
+def icp_sharded(be, moved, fix, iters, group=None):
+    """Affine ICP with the moving rows sharded (perform_icp.py:7-26).  -> (A_icp [4,4], residuals [iters])."""
+    import torch
+    rank, world = _world(group)
+    dist = _dist() if world > 1 else None
+    bn = shard_bounds(moved.shape[1], world)
+    loc = moved[:, bn[rank]:bn[rank + 1]].contiguous().clone()
+    A_icp = torch.eye(4, dtype=torch.float64, device=moved.device).reshape(16).contiguous()
+    origin = torch.cat([fix[:, 0], fix[:, 0]]).contiguous()
+    residuals = []
+    for _ in range(iters):
+        nn = be.icp_nn(loc, fix)
+        sums = be.icp_accumulate(loc, fix, nn, origin)
+        if world > 1:
+            parts = [torch.empty_like(sums) for _ in range(world)]
+            dist.all_gather(parts, sums, group=group)
+            sums = parts[0].clone()
+            for g in range(1, world):       # rank order: every rank forms the same float64 sums
+                sums += parts[g]
+        _, rp = be.icp_update(sums, origin, loc, fix, nn, A_icp)
+        if world > 1:
+            rps = [torch.empty_like(rp) for _ in range(world)]
+            dist.all_gather(rps, rp, group=group)
+            rp = rps[0].clone()
+            for g in range(1, world):
+                rp += rps[g]
+        residuals.append(rp[0] / rp[1])
+    res = torch.stack(residuals) if residuals else torch.empty(0, dtype=torch.float64, device=moved.device)
+    return A_icp.reshape(4, 4), res
+
+
+def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
+                       ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, group=None,
+                       backend=None):
+    """Reproduces _dock_widget.py:526-718 -> (A_sc, A_icp, inliers[8]); final transform = A_icp @ A_sc (:428).
+
+    moving, fixed   3 x N / 3 x M float64 (rows z, y, x), NumPy or torch
+    mode            'unsupervised' (shape context + Hungarian + RANSAC) or 'supervised'
+                    (keypoints=(kp_moving, kp_fixed), 3 x k each; _dock_widget.py:707-711)
+    ransac_error    16 for CSV detections (_dock_widget.py:613-614); with nucleus sizes the widget uses
+                    0.5 * (mean(size_m)**(1/3) + mean(size_f)**(1/3)) — pass that value
+    seed            if not None, np.random.seed(seed) right before the eight RANSAC runs
+    group           torch.distributed process group to shard over (None = this GPU only); every rank
+                    passes the same clouds and gets the same results
+    details         optional dict filled with intermediate results (lsa, ransac_A, residuals)
+    """
+    import torch
+    be = backend or GpuBackend()
+    mov, fix = be.cloud(moving), be.cloud(fixed)
+    inliers = np.zeros(8, dtype=np.int64)
+    rank, world = _world(group)
+    if mode == 'unsupervised':
+        U, bn = build_costs(be, mov, fix, group)
+        lsa = assign(U, bn, group)
+        del U
+        if seed is not None:
+            np.random.seed(seed)
+        A_h = []
+        for h, (r, c) in enumerate(lsa):            # every rank runs the same 8 x trials: same RNG stream everywhere
+            A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
+                                ransac_samples)
+            A_h.append(nat.to_dev(A, dev=mov.device))
+            inliers[h] = k
+        A_sc = A_h[int(np.argmax(inliers))]          # first maximum (_dock_widget.py:683-703)
+        if details is not None:
+            details.update(lsa=lsa, ransac_A=torch.stack(A_h).cpu().numpy())
+    elif mode == 'supervised':
+        if keypoints is None:
+            raise ValueError("supervised mode needs keypoints=(moving_keypoints, fixed_keypoints)")
+        A_sc = be.fit(keypoints[0], keypoints[1], transform)
+    else:
+        raise ValueError("mode must be 'unsupervised' or 'supervised'")
+    moved = be.apply_affine(A_sc, mov)                                              # :714
+    if world > 1 and transform == 'Affine':
+        A_icp, res = icp_sharded(be, moved, fix, int(icp_iterations), group)
+        if details is not None:
+            details['residuals'] = res.cpu().numpy()
+    else:
+        log = {} if details is not None else None
+        A_icp = be.icp(moved, fix, int(icp_iterations), transform, log)             # :715-717
+        if details is not None:
+            details.update(residuals=log['residuals'], nn=log['nn'])
+    if nat.is_torch(moving):
+        return A_sc, nat.to_dev(A_icp, dev=mov.device), inliers
+    return A_sc.cpu().numpy(), (A_icp.cpu().numpy() if nat.is_torch(A_icp) else np.asarray(A_icp)), inliers

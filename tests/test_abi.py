@@ -1,0 +1,74 @@
+"""The C-ABI library builds for gfx950, loads without a GPU and exports every symbol include/*.h declares.
+No compute is called here (there is no GPU in the CPU suite)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from platymatch_amd.build import build_native
+    return build_native()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "platymatch_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_python_binding_covers_the_header(lib_path):
+    from platymatch_amd import _native
+    assert sorted(_native.SIGNATURES) == declared_symbols()
+    lib = _native.load()
+    assert lib.pm_version() == 1
+    assert b"workspace" in lib.pm_error_string(-2)
+
+
+def test_workspace_queries_and_argument_errors(lib_path):
+    """Host-side behaviour that needs no device: sizes, and rejection before anything is enqueued."""
+    from platymatch_amd import _native
+    lib = _native.load()
+    assert lib.pm_mean_distance_workspace(1000) == 4 * 4 * 8
+    assert lib.pm_icp_workspace(50000, 50000) > 50000 * 4
+    assert lib.pm_icp_workspace(0, 10) == 0
+    assert lib.pm_centroid(None, 10, None, None, 0, None) == -1
+    assert lib.pm_chi2_cost(None, 1, None, 1, None, 1, None) == -1
+    assert lib.pm_shape_context(None, 0, 0, 0, None, None, None, 3, None, None, None, None) == -1
+    assert lib.pm_icp(None, 5, None, 5, 1, None, None, None, None, 0, None) == -1
+
+
+def test_product_refuses_to_run_without_a_gpu(lib_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from platymatch_amd import _native
+    from platymatch_amd.utils import utils
+    with pytest.raises(_native.NativeError):
+        utils.get_centroid(np.zeros((3, 5)), transposed=False)
+    import platymatch_amd
+    with pytest.raises(_native.NativeError):
+        platymatch_amd.estimate_transform(np.zeros((3, 8)), np.zeros((3, 8)))
+
+
+def test_no_oracle_import_in_product():
+    """The product never imports, links or executes anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "platymatch_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "pm_oracle" not in src and "libpm_oracle" not in src, f

@@ -1,0 +1,78 @@
+"""Host-side logic of the product that needs no GPU."""
+import numpy as np
+
+from conftest import load_golden
+
+
+def test_shard_bounds():
+    from platymatch_amd.pipeline import shard_bounds
+    assert shard_bounds(10, 1) == [0, 10]
+    assert shard_bounds(10, 3) == [0, 4, 7, 10]
+    assert shard_bounds(2, 4) == [0, 1, 2, 2, 2]
+    b = shard_bounds(50000, 8)
+    assert b[-1] == 50000 and all(b[i + 1] - b[i] == 6250 for i in range(8))
+
+
+def test_ransac_draws_follow_the_reference_rng_sequence(oracle):
+    """do_ransac draws np.random.choice(n, 4, replace=False) once per trial from the global RNG
+    (shape_context.py:122): the product's host-side draw must be that exact call sequence."""
+    from platymatch_amd.estimate_transform.shape_context import draw_ransac_samples
+    np.random.seed(0)
+    ours = draw_ransac_samples(331, 4, 50)
+    np.random.seed(0)
+    ref = np.stack([np.random.choice(331, 4, replace=False) for _ in range(50)])
+    assert np.array_equal(ours, ref) and ours.dtype == np.int32
+    np.random.seed(0)
+    assert np.array_equal(oracle.draw_ransac_samples(331, 4, 50), ref)
+
+
+def test_similar_from_sums_matches_reference_closed_form(oracle):
+    """Horn's closed form rebuilt from moment sums (incl. the row-0 eigenvector quirk, find_transform.py:60-66)
+    against the oracle (itself bit-exact with the reference on micro.npz)."""
+    from platymatch_amd.estimate_transform.find_transform import similar_from_sums
+    from platymatch_amd.estimate_transform.shape_context import _host_sums
+    d = load_golden("micro")
+    P, Q = d["fit_moving"], d["fit_fixed"]
+    for sl in (slice(None), slice(0, 4), slice(3, 12)):
+        A = similar_from_sums(_host_sums(P[:, sl], Q[:, sl]), np.zeros(6))
+        ref = oracle.get_similar_transform(P[:, sl], Q[:, sl])
+        assert np.abs(A - ref).max() < 1e-9 * np.abs(ref).max()
+    # with a non-zero origin (what the device accumulates about)
+    o = np.concatenate([P[:, 0], Q[:, 0]])
+    A = similar_from_sums(_host_sums(P - o[:3, None], Q - o[3:, None]), o)
+    assert np.abs(A - d["fit_similar"]).max() < 1e-9 * np.abs(d["fit_similar"]).max()
+
+
+def test_legacy_get_bin_index_helper(micro):
+    """get_bin_index on explicit (r, theta, phi) lists (shape_context.py:46-58)."""
+    from platymatch_amd.estimate_transform.shape_context import get_bin_index, get_Y
+    nb = micro["rand_neighbors"]
+    r = np.linalg.norm(nb, axis=1) / 55.0
+    th = np.arccos(nb[:, 2] / np.linalg.norm(nb, axis=1))
+    at = np.arctan2(nb[:, 1], nb[:, 0])
+    ph = np.where(at < 0, 2 * np.pi + at, at)
+    got = np.array(get_bin_index(list(r), list(th), list(ph), micro["r_edges"], 5, 6, 12))
+    assert np.array_equal(got, micro["rand_bin_index"])
+    y = get_Y(np.array([[0.0, 0.0, 1.0]]), np.array([[1.0, 0.0, 0.0]]))
+    assert np.allclose(y, [[0.0, 1.0, 0.0]])
+
+
+def test_install_as_platymatch_aliases():
+    import sys
+    import platymatch_amd
+    saved = {k: v for k, v in sys.modules.items() if k == "platymatch" or k.startswith("platymatch.")}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        platymatch_amd.install_as_platymatch()
+        from platymatch.estimate_transform.shape_context import get_unary, get_unary_distance, do_ransac  # noqa: F401
+        from platymatch.estimate_transform.perform_icp import perform_icp  # noqa: F401
+        from platymatch.estimate_transform.find_transform import get_affine_transform, get_similar_transform  # noqa: F401
+        from platymatch.estimate_transform.apply_transform import apply_affine_transform  # noqa: F401
+        from platymatch.utils.utils import get_centroid, get_mean_distance  # noqa: F401
+        import platymatch_amd.estimate_transform.shape_context as sc
+        assert get_unary is sc.get_unary
+    finally:
+        for k in [k for k in sys.modules if k == "platymatch" or k.startswith("platymatch.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
