@@ -5,9 +5,17 @@ functions (same names, arguments and array conventions), computed by hand-writte
 for gfx950 behind a C ABI (include/platymatch_hip.h).  There is no CPU fallback: without the
 built library and an AMD GPU every entry point raises.
 """
-from .pipeline import estimate_transform  # noqa: F401
 
 __version__ = "0.1.0"
+
+# The headless driver is platymatch_amd.estimate_transform.estimate_transform (the sub-package keeps the
+# reference's name, so the function lives inside it); `register` is a top-level alias.
+
+
+def register(moving, fixed, **kwargs):
+    """Alias of platymatch_amd.estimate_transform.estimate_transform."""
+    from .pipeline import estimate_transform as run
+    return run(moving, fixed, **kwargs)
 
 
 def install_as_platymatch():

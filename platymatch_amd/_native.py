@@ -71,6 +71,11 @@ def load():
     global _lib
     with _lock:
         if _lib is None:
+            # torch bundles its own HIP runtime (SONAME libamdhip64.so.7, the same as /opt/rocm's).  It must be
+            # in the process BEFORE this library is opened, so that both resolve to ONE runtime: loaded the
+            # other way round the process ends up with two runtimes and torch's streams/pointers mean nothing
+            # to ours (hipErrorNoDevice on the first launch).
+            import torch  # noqa: F401
             if not os.path.exists(LIB_PATH):
                 raise NativeError(
                     "%s not found. Build it with `python -m platymatch_amd.build` (needs hipcc); "

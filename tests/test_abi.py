@@ -61,7 +61,7 @@ def test_product_refuses_to_run_without_a_gpu(lib_path):
         utils.get_centroid(np.zeros((3, 5)), transposed=False)
     import platymatch_amd
     with pytest.raises(_native.NativeError):
-        platymatch_amd.estimate_transform(np.zeros((3, 8)), np.zeros((3, 8)))
+        platymatch_amd.register(np.zeros((3, 8)), np.zeros((3, 8)))
 
 
 def test_no_oracle_import_in_product():

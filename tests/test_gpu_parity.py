@@ -358,7 +358,7 @@ def test_estimate_transform_end_to_end(gpu, oracle, name):
     pi.VERBOSE = False
     d = load_golden(name)
     det = {}
-    A_sc, A_icp, inl = platymatch_amd.estimate_transform(d["moving"], d["fixed"], ransac_trials=int(d["ransac_trials"]),
+    A_sc, A_icp, inl = platymatch_amd.register(d["moving"], d["fixed"], ransac_trials=int(d["ransac_trials"]),
                                                          ransac_error=float(d["ransac_error"]), icp_iterations=int(d["icp_iters"]),
                                                          seed=int(d["ransac_seed"]), details=det)
     for h in range(8):
@@ -376,15 +376,15 @@ def test_estimate_transform_supervised_and_api_kinds(gpu, oracle, micro):
     pi.VERBOSE = False
     d = load_golden("synth128")
     P, Q = micro["fit_moving"], micro["fit_fixed"]
-    A_sc, A_icp, inl = platymatch_amd.estimate_transform(P, Q, mode="supervised", keypoints=(P[:, :10], Q[:, :10]), icp_iterations=5)
+    A_sc, A_icp, inl = platymatch_amd.register(P, Q, mode="supervised", keypoints=(P[:, :10], Q[:, :10]), icp_iterations=5)
     assert relerr(A_sc, micro["sup_A_sc"]) < 1e-10 and (inl == 0).all()
     ref_icp = oracle.perform_icp(oracle.apply_affine_transform(P, micro["sup_A_sc"]), Q, 5)
     assert relerr(A_icp, ref_icp) < 1e-9
-    t_sc, t_icp, _ = platymatch_amd.estimate_transform(gpu.d(d["moving"]), gpu.d(d["fixed"]), ransac_trials=200, seed=0,
+    t_sc, t_icp, _ = platymatch_amd.register(gpu.d(d["moving"]), gpu.d(d["fixed"]), ransac_trials=200, seed=0,
                                                        icp_iterations=3)
     assert gpu.nat.is_torch(t_sc) and gpu.nat.is_torch(t_icp)
     with pytest.raises(ValueError):
-        platymatch_amd.estimate_transform(P, Q, mode="nope")
+        platymatch_amd.register(P, Q, mode="nope")
 
 
 def test_get_unary_mirror_conventions(gpu, oracle):
