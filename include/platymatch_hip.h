@@ -105,6 +105,19 @@ int pm_chi2_cost8(const double *sc_m1, const double *sc_m2, int nM, const double
                   const double *sc_f2, const double *sc_f3, const double *sc_f4, int nF,
                   double *out, size_t ld, size_t matrix_stride, void *stream);
 
+/* Frames 2..4 of get_unary are, away from exact sector edges, phi-sector permutations of frame 1
+ * (sc2[q] = sc1[(q+6)%12], sc3[q] = sc1[11-q], sc4[q] = sc1[(5-q) mod 12] within each (r, theta) shell),
+ * which lets the eight matrices be built from the frame-1 descriptors with half the divisions.
+ * pm_chi2_symmetry_check verifies the relation bit for bit on the given arrays: flag1[0] = 0 if it
+ * holds for every row of both clouds, 1 otherwise (the flag is reset by the call itself).
+ * pm_chi2_cost8_sym then produces exactly what pm_chi2_cost8 would (same bits, same layout) and must
+ * only be called when the flag is 0; otherwise use pm_chi2_cost8. */
+int pm_chi2_symmetry_check(const double *sc_m1, const double *sc_m2, int nM, const double *sc_f1,
+                           const double *sc_f2, const double *sc_f3, const double *sc_f4, int nF,
+                           int32_t *flag1, void *stream);
+int pm_chi2_cost8_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
+                      size_t matrix_stride, void *stream);
+
 /* ---- RANSAC -------------------------------------------------------------------------------- */
 
 /* do_ransac's trial loop (shape_context.py:121-138) with the index sets drawn by the caller

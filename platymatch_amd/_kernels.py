@@ -126,8 +126,21 @@ def chi2_cost(scA, scB, out=None):
     return out
 
 
-def chi2_cost8(sc_m, sc_f, out=None):
-    """sc_m: [2, nM, 360], sc_f: [4, nF, 360] -> out [8, nM, nF] in the widget's order 11..14, 21..24."""
+def chi2_symmetric(sc_m, sc_f):
+    """True if frames 2..4 are, bit for bit, the phi-sector permutations of frame 1 (one tiny kernel + a 4-byte read)."""
+    torch = _t()
+    m = [_desc(sc_m[k], "sc_m[%d]" % k) for k in range(2)]
+    f = [_desc(sc_f[k], "sc_f[%d]" % k) for k in range(4)]
+    flag = torch.empty(1, dtype=torch.int32, device=sc_m.device)
+    check(nat.load().pm_chi2_symmetry_check(ptr(m[0]), ptr(m[1]), m[0].shape[0], ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]),
+                                            f[0].shape[0], ptr(flag), nat.stream_ptr()))
+    return int(flag.item()) == 0
+
+
+def chi2_cost8(sc_m, sc_f, out=None, path="auto"):
+    """sc_m: [2, nM, 360], sc_f: [4, nF, 360] -> out [8, nM, nF] in the widget's order 11..14, 21..24.
+    path: 'auto' (verify the frame-permutation relation on the device, then take the half-cost kernel if it
+    holds), 'general' (never assume it) or 'symmetric' (caller has verified it).  All paths give identical bits."""
     torch = _t()
     if not (nat.is_torch(sc_m) and sc_m.dim() == 3 and sc_m.shape[0] == 2 and nat.is_torch(sc_f) and sc_f.dim() == 3
             and sc_f.shape[0] == 4):
@@ -140,8 +153,14 @@ def chi2_cost8(sc_m, sc_f, out=None):
     elif not (out.is_cuda and out.dtype == torch.float64 and tuple(out.shape) == (8, nM, nF) and out.stride(2) == 1
               and out.stride(0) >= nM * out.stride(1) and out.stride(1) >= nF):
         raise ValueError("out must be float64 GPU [8, nM, nF] with unit column stride")
-    check(nat.load().pm_chi2_cost8(ptr(m[0]), ptr(m[1]), nM, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), nF, ptr(out),
-                                   out.stride(1), out.stride(0), nat.stream_ptr()))
+    if path not in ("auto", "general", "symmetric"):
+        raise ValueError("path must be 'auto', 'general' or 'symmetric'")
+    sym = path == "symmetric" or (path == "auto" and chi2_symmetric(sc_m, sc_f))
+    if sym:
+        check(nat.load().pm_chi2_cost8_sym(ptr(m[0]), nM, ptr(f[0]), nF, ptr(out), out.stride(1), out.stride(0), nat.stream_ptr()))
+    else:
+        check(nat.load().pm_chi2_cost8(ptr(m[0]), ptr(m[1]), nM, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), nF, ptr(out),
+                                       out.stride(1), out.stride(0), nat.stream_ptr()))
     return out
 
 

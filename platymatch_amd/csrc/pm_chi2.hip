@@ -128,7 +128,168 @@ int chi2_launch(const Chi2Args<NFA, NFB> &args, int nA, int nB, double *out, siz
     return launch_status();
 }
 
+// ---- the eight hypothesis matrices from the frame-1 descriptors alone ----------------------------
+// get_unary's frames 2..4 re-express every neighbour with (x, y) -> (-x, -y), (x, -y), (-x, y)
+// (shape_context.py:172-175, 180-181): phi -> phi + pi, -phi, pi - phi.  Away from exact sector edges
+// that permutes the 12 phi sectors of each (r, theta) shell:
+//     sc2[q] = sc1[(q + 6) % 12]     sc3[q] = sc1[11 - q]     sc4[q] = sc1[(5 - q) mod 12]
+// so U_ab = sum_q f(sc_a^m[q], sc_b^f[q]) only ever pairs A[p] (moving frame 1) with one of
+// B[p], B[p+6], B[11-p], B[5-p] (fixed frame 1): four sets of terms, each summed in two orders —
+// natural p = 0..11 (U11, U12, U13, U14) and rolled p = 6..11,0..5 (U22, U21, U24, U23).  Terms are
+// computed once and added into both running sums in the reference's order, so all eight matrices stay
+// bit-identical to the general kernel at half its divisions.  Whether the permutation relation holds
+// for the given descriptor arrays is CHECKED bit for bit by symmetry_check_kernel, never assumed.
+template <int SY_RI, int MINW>            // rows per wave; minimum waves per SIMD asked of the register allocator
+__global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double *__restrict__ scA, int nA,
+                                                                 const double *__restrict__ scB, int nB,
+                                                                 double *__restrict__ out, size_t ld, size_t mstride,
+                                                                 int nTi, unsigned int nblocks) {
+    constexpr int SY_TI = 4 * SY_RI;      // rows per tile
+    __shared__ __attribute__((aligned(16))) double A_s[SY_TI][CH_K];
+    __shared__ __attribute__((aligned(16))) double B_s[CH_TJ][CH_BPITCH];
+
+    unsigned int bid = blockIdx.x;
+    const unsigned int full = nblocks / 8u * 8u;
+    if (bid < full) bid = (bid % 8u) * (full / 8u) + bid / 8u;
+    const int ti = bid % (unsigned int)nTi, tj = bid / (unsigned int)nTi;
+    const int i0 = ti * SY_TI, j0 = tj * CH_TJ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    double acc[SY_RI][8];
+#pragma unroll
+    for (int r = 0; r < SY_RI; ++r)
+#pragma unroll
+        for (int h = 0; h < 8; ++h) acc[r][h] = 0.0;
+
+    for (int g = 0; g < CH_STAGES; ++g) {
+        __syncthreads();
+        for (int e = tid; e < SY_TI * CH_K; e += CH_THREADS) {
+            const int r = e / CH_K, k = e - r * CH_K;
+            A_s[r][k] = scA[(size_t)min(i0 + r, nA - 1) * PM_NBINS + g * CH_K + k];
+        }
+        for (int e = tid; e < CH_TJ * (CH_K / 2); e += CH_THREADS) {
+            const int j = e / (CH_K / 2), kk = e - j * (CH_K / 2);
+            double2 v = *reinterpret_cast<const double2 *>(scB + (size_t)min(j0 + j, nB - 1) * PM_NBINS + g * CH_K + 2 * kk);
+            v.x = (v.x == 0.0) ? CH_TINY : v.x;
+            v.y = (v.y == 0.0) ? CH_TINY : v.y;
+            *reinterpret_cast<double2 *>(&B_s[j][2 * kk]) = v;
+        }
+        __syncthreads();
+        double b[CH_K];
+#pragma unroll
+        for (int k = 0; k < CH_K; k += 2) {
+            double2 v = *reinterpret_cast<const double2 *>(&B_s[lane][k]);
+            b[k] = v.x; b[k + 1] = v.y;
+        }
+#pragma unroll
+        for (int r = 0; r < SY_RI; ++r) {
+            double a[CH_K];
+#pragma unroll
+            for (int k = 0; k < CH_K; k += 2) {
+                double2 v = *reinterpret_cast<const double2 *>(&A_s[wave * SY_RI + r][k]);
+                a[k] = v.x; a[k + 1] = v.y;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // pairing t: B index for A index p; natural-order matrix, rolled-order matrix (widget numbering 0..7)
+                const int hn = t, hr = (t == 0) ? 5 : (t == 1) ? 4 : (t == 2) ? 7 : 6;
+                double T[CH_K];
+#pragma unroll
+                for (int p = 0; p < CH_K; ++p) {
+                    const int q = (t == 0) ? p : (t == 1) ? (p + 6) % 12 : (t == 2) ? 11 - p : (17 - p) % 12;
+                    const double df = a[p] - b[q];
+                    T[p] = div_pos(df * df, a[p] + b[q]);
+                }
+                double sn = acc[r][hn], sr = acc[r][hr];
+#pragma unroll
+                for (int p = 0; p < CH_K; ++p) sn = sn + T[p];
+#pragma unroll
+                for (int p = 0; p < CH_K; ++p) sr = sr + T[(p + 6) % 12];
+                acc[r][hn] = sn;
+                acc[r][hr] = sr;
+            }
+        }
+    }
+    const int gj = j0 + lane;
+    if (gj < nB) {
+#pragma unroll
+        for (int r = 0; r < SY_RI; ++r) {
+            const int gi = i0 + wave * SY_RI + r;
+            if (gi < nA) {
+#pragma unroll
+                for (int h = 0; h < 8; ++h) out[(size_t)h * mstride + (size_t)gi * ld + gj] = 0.5 * acc[r][h];
+            }
+        }
+    }
+}
+
+// flag[0] |= 1 unless, bit for bit, sc2 = roll6(sc1), sc3 = reverse(sc1), sc4 = (5-q)(sc1) within every shell.
+// which: 0 = moving (frame 2 only), 1 = fixed (frames 2, 3, 4).  One thread per (row, bin).
+__global__ __launch_bounds__(256) void symmetry_check_kernel(const unsigned long long *__restrict__ s1,
+                                                             const unsigned long long *__restrict__ s2,
+                                                             const unsigned long long *__restrict__ s3,
+                                                             const unsigned long long *__restrict__ s4, int n,
+                                                             int *__restrict__ flag) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)n * PM_NBINS) return;
+    const int k = (int)(e % PM_NBINS), q = k % 12;
+    const size_t base = e - q;
+    bool bad = s2[e] != s1[base + (q + 6) % 12];
+    if (s3) bad = bad || s3[e] != s1[base + 11 - q] || s4[e] != s1[base + (17 - q) % 12];
+    if (bad) atomicOr(flag, 1);
+}
+
 }  // namespace pm
+
+extern "C" int pm_chi2_symmetry_check(const double *sc_m1, const double *sc_m2, int nM, const double *sc_f1,
+                                      const double *sc_f2, const double *sc_f3, const double *sc_f4, int nF, int32_t *flag1,
+                                      void *stream) {
+    if (!sc_m1 || !sc_m2 || !sc_f1 || !sc_f2 || !sc_f3 || !sc_f4 || !flag1 || nM <= 0 || nF <= 0) return PM_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(flag1, 0, sizeof(int32_t), s) != hipSuccess) return pm::launch_status();
+    typedef const unsigned long long *U;
+    const size_t em = (size_t)nM * PM_NBINS, ef = (size_t)nF * PM_NBINS;
+    pm::symmetry_check_kernel<<<(unsigned int)((em + 255) / 256), 256, 0, s>>>((U)sc_m1, (U)sc_m2, nullptr, nullptr, nM, flag1);
+    pm::symmetry_check_kernel<<<(unsigned int)((ef + 255) / 256), 256, 0, s>>>((U)sc_f1, (U)sc_f2, (U)sc_f3, (U)sc_f4, nF, flag1);
+    return pm::launch_status();
+}
+
+namespace pm {
+template <int RI, int MINW>
+int chi2_sym_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld, size_t mstride, hipStream_t s) {
+    const long nTi = ((long)nM + 4 * RI - 1) / (4 * RI), nTj = ((long)nF + CH_TJ - 1) / CH_TJ;
+    const long nblocks = nTi * nTj;
+    if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
+    chi2_sym_kernel<RI, MINW><<<(unsigned int)nblocks, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, mstride, (int)nTi,
+                                                                          (unsigned int)nblocks);
+    return launch_status();
+}
+}  // namespace pm
+
+// tuning hook (not part of the public ABI): same result from differently shaped launches
+extern "C" int pm_chi2_cost8_sym_variant(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
+                                         size_t matrix_stride, int variant, void *stream) {
+    if (!sc_m1 || !sc_f1 || !out || nM <= 0 || nF <= 0 || ld < (size_t)nF || matrix_stride < (size_t)nM * ld)
+        return PM_ERR_INVALID_ARG;
+    if (((uintptr_t)sc_f1 & 15) != 0 || ((uintptr_t)sc_m1 & 15) != 0) return PM_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (variant) {
+        case 0: return pm::chi2_sym_launch<4, 2>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s);
+        case 1: return pm::chi2_sym_launch<4, 3>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s);
+        case 2: return pm::chi2_sym_launch<2, 3>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s);
+        case 3: return pm::chi2_sym_launch<2, 4>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s);
+        case 4: return pm::chi2_sym_launch<1, 4>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s);
+        case 5: return pm::chi2_sym_launch<8, 2>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s);
+        case 6: return pm::chi2_sym_launch<4, 4>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s);
+        default: return PM_ERR_INVALID_ARG;
+    }
+}
+
+extern "C" int pm_chi2_cost8_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
+                                 size_t matrix_stride, void *stream) {
+    return pm_chi2_cost8_sym_variant(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, 0, stream);
+}
 
 extern "C" int pm_chi2_cost(const double *scA, int nA, const double *scB, int nB, double *out, size_t ld, void *stream) {
     if (!scA || !scB || !out || nA <= 0 || nB <= 0 || ld < (size_t)nB) return PM_ERR_INVALID_ARG;

@@ -2,13 +2,13 @@
 // Reference: perform_icp (perform_icp.py:7-26).  Per iteration the reference materialises
 // scipy.spatial.distance_matrix(moving.T, fixed.T) — sum(|x-y|**2, axis=-1)**0.5, N x M float64 — and
 // takes np.argmin(axis=1) (first index on ties).  Here the matrix is never formed: each lane keeps
-// one moving point in registers, the fixed cloud streams through LDS as wave-uniform broadcasts, and
-// a running (distance, index) pair lives in registers.
+// two moving points in registers, the fixed cloud streams through the scalar unit as wave-uniform loads,
+// and a running (squared distance, index) pair per point lives in registers.
 //
-// Exact argmin over the ROUNDED square roots without taking a square root per pair: candidate j
-// (later than every candidate this lane has seen) replaces the current best R only if
-// fl(sqrt(s_j)) < R, i.e. s_j < thr with thr = the smallest float64 whose rounded root is R.
-// sqrt and thr are recomputed only when a lane's best changes (O(log M) times per lane).
+// Exact argmin over the ROUNDED square roots without taking a square root per pair: candidate j (later
+// than every candidate this lane has seen) replaces the current best only if fl(sqrt(s_j)) < fl(sqrt(S_best));
+// that is certain when s_j is below S_best by more than a few ulps and is checked with two square roots in
+// the (rare) remaining sliver — see NnBest.
 // Squared distances use the reference's operation order ((d0*d0 + d1*d1) + d2*d2, d = fixed - moving),
 // one rounding each, so indices match np.argmin bit for bit.
 #include "pm_common.h"
@@ -20,75 +20,85 @@ int update(const double *, const double *, const double *, double *, int, const 
            double *, double *, double *, double *, hipStream_t);
 
 constexpr int NN_THREADS = 256;
-constexpr int NN_WAVES = 4;
-constexpr int NN_CHUNK = 1024;                 // fixed points staged per step
-constexpr int NN_SUB = NN_CHUNK / NN_WAVES;    // per wave
+constexpr int NN_TILE = 128;                   // moving points per wave (two per lane)
+constexpr int NN_UNROLL = 4;                   // fixed points per loop trip
 
 __device__ __forceinline__ double next_below(double t) {   // t > 0
     return __longlong_as_double(__double_as_longlong(t) - 1);
 }
 
-__global__ __launch_bounds__(NN_THREADS) void nn_kernel(const double *__restrict__ mov, int n,
-                                                        const double *__restrict__ fix, int m, int slice_len,
-                                                        int32_t *__restrict__ out_idx, double *__restrict__ out_dist) {
-    __shared__ double F[3][NN_CHUNK];
-    __shared__ double mR[NN_WAVES][64];
-    __shared__ int mI[NN_WAVES][64];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = blockIdx.x * 64 + lane;
-    const int ic = min(i, n - 1);
-    const double p0 = mov[ic], p1 = mov[(size_t)n + ic], p2 = mov[2 * (size_t)n + ic];
-    const int jb = blockIdx.y * slice_len, je = min(m, jb + slice_len);
+// fixed cloud 3 x m (SoA) -> packed {x, y, z, 0} records, padded with infinitely distant points up to m_pad,
+// so that one wave-uniform 32-byte (scalar) load fetches a whole point and slices need no tail handling
+__global__ __launch_bounds__(256) void nn_pack_kernel(const double *__restrict__ fix, int m, int m_pad, double4 *__restrict__ packed) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m_pad) return;
+    double4 v;
+    if (j < m) { v.x = fix[j]; v.y = fix[(size_t)m + j]; v.z = fix[2 * (size_t)m + j]; v.w = 0.0; }
+    else { v.x = INFINITY; v.y = 0.0; v.z = 0.0; v.w = 0.0; }
+    packed[j] = v;
+}
 
-    double bestR = INFINITY, thr = INFINITY;
-    int bestI = 0x7fffffff;
-    for (int c0 = jb; c0 < je; c0 += NN_CHUNK) {
-        __syncthreads();
-        for (int e = tid; e < NN_CHUNK; e += NN_THREADS) {
-            const int j = c0 + e;
-            const bool ok = j < je;
-            F[0][e] = ok ? fix[j] : INFINITY;      // padding: infinitely far, never wins
-            F[1][e] = ok ? fix[(size_t)m + j] : 0.0;
-            F[2][e] = ok ? fix[2 * (size_t)m + j] : 0.0;
+// Running best of one moving point.  S is the squared distance of the current best candidate, I its index,
+// lim = S * (1 - 2^-48): a later candidate with s < lim has a strictly smaller ROUNDED root (the real roots
+// differ by > 8 ulp), so it wins without any square root being taken; s in [lim, S) is the only case in which
+// two different squared distances may round to the same root — decided exactly there, and rare.
+struct NnBest {
+    double S, lim;
+    int I;
+};
+
+__device__ __forceinline__ void nn_offer(NnBest &b, double s, int j) {
+    if (s < b.S) {
+        if (s < b.lim || __builtin_sqrt(s) < __builtin_sqrt(b.S)) {   // np.argmin keeps the FIRST index of equal roots
+            b.S = s;
+            b.I = j;
+            b.lim = s * 0x1.ffffffffffffp-1;                           // 1 - 2^-48
         }
-        __syncthreads();
-        const int e0 = wave * NN_SUB;
-#pragma unroll 4
-        for (int e = e0; e < e0 + NN_SUB; ++e) {
-            const double d0 = F[0][e] - p0, d1 = F[1][e] - p1, d2 = F[2][e] - p2;
-            const double s = (d0 * d0 + d1 * d1) + d2 * d2;
-            if (s < thr) {
-                const double R = __builtin_sqrt(s);
-                bestR = R;
-                bestI = c0 + e;
-                double t = s;
-                for (int it = 0; it < 8 && t > 0.0; ++it) {
-                    const double tp = next_below(t);
-                    if (__builtin_sqrt(tp) == R) t = tp; else break;
-                }
-                thr = t;
-            }
-        }
-    }
-    // merge the four waves (disjoint index ranges): smaller distance, then smaller index
-    mR[wave][lane] = bestR;
-    mI[wave][lane] = bestI;
-    __syncthreads();
-    if (wave == 0 && i < n) {
-        double R = mR[0][lane];
-        int I = mI[0][lane];
-#pragma unroll
-        for (int w = 1; w < NN_WAVES; ++w) {
-            const double Rw = mR[w][lane];
-            const int Iw = mI[w][lane];
-            if (Rw < R || (Rw == R && Iw < I)) { R = Rw; I = Iw; }
-        }
-        out_idx[(size_t)blockIdx.y * n + i] = I;
-        out_dist[(size_t)blockIdx.y * n + i] = R;
     }
 }
 
+// One wave = 128 moving points (lane l owns l and l + 64) against one slice of the fixed cloud.
+// The fixed point is the same for every lane: it arrives by wave-uniform loads (scalar unit, SGPR operands),
+// so the vector unit only sees 3 sub + 3 mul + 2 add + 1 compare per pair and LDS is not used at all.
+__global__ __launch_bounds__(NN_THREADS) void nn_kernel(const double *__restrict__ mov, int n,
+                                                        const double4 *__restrict__ fixp, int slice_len,
+                                                        int32_t *__restrict__ out_idx, double *__restrict__ out_dist) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int base = (blockIdx.x * 4 + wave) * NN_TILE;
+    if (base >= n) return;
+    const int i0 = base + lane, i1 = base + 64 + lane;
+    const int c0 = min(i0, n - 1), c1 = min(i1, n - 1);
+    const double a0 = mov[c0], a1 = mov[(size_t)n + c0], a2 = mov[2 * (size_t)n + c0];
+    const double b0 = mov[c1], b1 = mov[(size_t)n + c1], b2 = mov[2 * (size_t)n + c1];
+    const int jb = blockIdx.y * slice_len, je = jb + slice_len;
+
+    NnBest A = {INFINITY, INFINITY, 0x7fffffff}, B = {INFINITY, INFINITY, 0x7fffffff};
+    for (int j = jb; j < je; j += NN_UNROLL) {
+        double sa[NN_UNROLL], sb[NN_UNROLL];
+        unsigned long long hit = 0;
+#pragma unroll
+        for (int u = 0; u < NN_UNROLL; ++u) {
+            const double4 f = fixp[j + u];
+            double d0 = f.x - a0, d1 = f.y - a1, d2 = f.z - a2;
+            sa[u] = (d0 * d0 + d1 * d1) + d2 * d2;
+            d0 = f.x - b0; d1 = f.y - b1; d2 = f.z - b2;
+            sb[u] = (d0 * d0 + d1 * d1) + d2 * d2;
+            hit |= __builtin_amdgcn_ballot_w64(sa[u] < A.S) | __builtin_amdgcn_ballot_w64(sb[u] < B.S);
+        }
+        if (hit) {                                  // wave-uniform branch; candidates are offered in index order
+#pragma unroll
+            for (int u = 0; u < NN_UNROLL; ++u) {
+                nn_offer(A, sa[u], j + u);
+                nn_offer(B, sb[u], j + u);
+            }
+        }
+    }
+    if (i0 < n) { out_idx[(size_t)blockIdx.y * n + i0] = A.I; out_dist[(size_t)blockIdx.y * n + i0] = __builtin_sqrt(A.S); }
+    if (i1 < n) { out_idx[(size_t)blockIdx.y * n + i1] = B.I; out_dist[(size_t)blockIdx.y * n + i1] = __builtin_sqrt(B.S); }
+}
+
+// slices cover disjoint, increasing index ranges: smaller distance wins, then smaller index
 __global__ __launch_bounds__(256) void nn_merge_kernel(const int32_t *__restrict__ pidx, const double *__restrict__ pdist,
                                                        int n, int slices, int32_t *__restrict__ nn, double *__restrict__ dist) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -104,29 +114,44 @@ __global__ __launch_bounds__(256) void nn_merge_kernel(const int32_t *__restrict
     if (dist) dist[i] = R;
 }
 
-inline int nn_slices(int n, int m) {
-    const int row_blocks = (n + 63) / 64;
-    int want = (1024 + row_blocks - 1) / row_blocks;            // aim for >= 1024 workgroups (4 per CU)
-    int max_slices = (m + NN_CHUNK - 1) / NN_CHUNK;
-    int s = want < 1 ? 1 : want;
+struct NnPlan {
+    int slices, slice_len, m_pad;
+    size_t off_idx, off_pack, total;
+};
+
+inline NnPlan nn_plan(int n, int m) {
+    NnPlan p;
+    const int tiles = (n + NN_TILE - 1) / NN_TILE;
+    int s = (6144 + tiles - 1) / tiles;                           // aim for ~6 waves per SIMD in flight
+    const int max_slices = (m + 63) / 64;                         // at least 64 fixed points per slice
     if (s > max_slices) s = max_slices;
-    if (s > 64) s = 64;
-    return s < 1 ? 1 : s;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    int len = (m + s - 1) / s;
+    len = (len + NN_UNROLL - 1) / NN_UNROLL * NN_UNROLL;
+    s = (m + len - 1) / len;                                      // drop slices made empty by the rounding
+    p.slices = s;
+    p.slice_len = len;
+    p.m_pad = s * len;
+    size_t o = align_up((size_t)s * n * sizeof(double), 256);
+    p.off_idx = o; o += align_up((size_t)s * n * sizeof(int32_t), 256);
+    p.off_pack = o; o += align_up((size_t)p.m_pad * sizeof(double4), 256);
+    p.total = o;
+    return p;
 }
 
-inline size_t nn_ws_bytes(int n, int m) {
-    const size_t s = (size_t)nn_slices(n, m);
-    return align_up(s * n * sizeof(double), 256) + align_up(s * n * sizeof(int32_t), 256);
-}
+inline size_t nn_ws_bytes(int n, int m) { return nn_plan(n, m).total; }
 
-int nn_search(const double *mov, int n, const double *fix, int m, int32_t *nn, double *dist, void *ws, hipStream_t s) {
-    const int slices = nn_slices(n, m);
-    int slice_len = (m + slices - 1) / slices;
-    slice_len = (slice_len + NN_CHUNK - 1) / NN_CHUNK * NN_CHUNK;
+// `packed_ready`: the packed copy of `fix` in the workspace is still valid (same fix, same n, m) — the ICP loop packs once
+int nn_search(const double *mov, int n, const double *fix, int m, int32_t *nn, double *dist, void *ws, hipStream_t s,
+              bool packed_ready = false) {
+    const NnPlan p = nn_plan(n, m);
     double *pdist = (double *)ws;
-    int32_t *pidx = (int32_t *)((char *)ws + align_up((size_t)slices * n * sizeof(double), 256));
-    nn_kernel<<<dim3((n + 63) / 64, slices), NN_THREADS, 0, s>>>(mov, n, fix, m, slice_len, pidx, pdist);
-    nn_merge_kernel<<<(n + 255) / 256, 256, 0, s>>>(pidx, pdist, n, slices, nn, dist);
+    int32_t *pidx = (int32_t *)((char *)ws + p.off_idx);
+    double4 *packed = (double4 *)((char *)ws + p.off_pack);
+    if (!packed_ready) nn_pack_kernel<<<(p.m_pad + 255) / 256, 256, 0, s>>>(fix, m, p.m_pad, packed);
+    nn_kernel<<<dim3((n + 4 * NN_TILE - 1) / (4 * NN_TILE), p.slices), NN_THREADS, 0, s>>>(mov, n, packed, p.slice_len, pidx, pdist);
+    nn_merge_kernel<<<(n + 255) / 256, 256, 0, s>>>(pidx, pdist, n, p.slices, nn, dist);
     return launch_status();
 }
 
@@ -182,7 +207,7 @@ int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_ic
     pm::icp_init_kernel<<<1, 64, 0, s>>>(fix, m, origin, A_icp16);
     for (int it = 0; it < iters; ++it) {
         int32_t *nn = nn_all ? nn_all + (size_t)it * n : nn_buf;
-        int rc = pm::nn_search(mov, n, fix, m, nn, nullptr, base + L.nn_ws, s);
+        int rc = pm::nn_search(mov, n, fix, m, nn, nullptr, base + L.nn_ws, s, it > 0);
         if (rc != PM_OK) return rc;
         rc = pm::accumulate(mov, n, fix, m, nn, origin, sums, acc_ws, s);
         if (rc != PM_OK) return rc;

@@ -186,6 +186,45 @@ def test_cost8_equals_eight_single_matrices(gpu, oracle):
         assert np.array_equal(U8[h], oracle.unary_distance_matrix(m[int(nm[0]) - 1], f[int(nm[1]) - 1]))
 
 
+@pytest.mark.parametrize("n,m,seed", [(331, 331, 0), (1000, 777, 1), (3000, 3000, 2)])
+def test_half_cost_path_identical_bits(gpu, oracle, n, m, seed):
+    """The frame-permutation kernel (4 term sets, 2 summation orders) gives the general kernel's bits, and the
+    device-side check recognises when it may be used."""
+    mv, fx, _ = synth_pair(max(n, m), seed)
+    mv, fx = np.ascontiguousarray(mv[:, :n]), np.ascontiguousarray(fx[:, :m])
+    x, y = gpu.d(mv), gpu.d(fx)
+    hm = gpu.K.shape_context(x, gpu.K.centroid(x), gpu.K.pca_axis(x), gpu.K.mean_distance(x), 2)["hist"]
+    hf = gpu.K.shape_context(y, gpu.K.centroid(y), gpu.K.pca_axis(y), gpu.K.mean_distance(y), 4)["hist"]
+    assert gpu.K.chi2_symmetric(hm, hf)
+    Ug = gpu.K.chi2_cost8(hm, hf, path="general")
+    Us = gpu.K.chi2_cost8(hm, hf, path="symmetric")
+    Ua = gpu.K.chi2_cost8(hm, hf)
+    assert gpu.t.equal(Ug, Us) and gpu.t.equal(Ug, Ua)
+    ref = oracle.unary_distance_matrix(hm[1][:64].cpu().numpy(), hf[2].cpu().numpy())     # U23 rows vs the oracle
+    assert np.array_equal(Us[6][:64].cpu().numpy(), ref)
+    # one bin off in one frame: the check must refuse, and 'auto' must fall back to the general kernel
+    bad = hf.clone()
+    bad[3, m // 2, 100] += 1e-9
+    assert not gpu.K.chi2_symmetric(hm, bad)
+    assert gpu.t.equal(gpu.K.chi2_cost8(hm, bad), gpu.K.chi2_cost8(hm, bad, path="general"))
+    bad2 = hm.clone()
+    bad2[1, 0, 0], bad2[1, 0, 6] = bad2[1, 0, 6].clone(), bad2[1, 0, 0].clone()
+    assert gpu.K.chi2_symmetric(bad2, hf) == bool(hm[1, 0, 0] == hm[1, 0, 6])
+
+
+def test_half_cost_path_nan_rows(gpu, micro, oracle):
+    cloud, c, md = micro["degenerate_cloud"], micro["degenerate_centroid"], float(micro["degenerate_mean_dist"])
+    x = gpu.d(cloud)
+    args = (gpu.d(np.ravel(c)), gpu.K.pca_axis(x), gpu.d(np.array([md])))
+    hm = gpu.K.shape_context(x, *args, 2)["hist"]
+    hf = gpu.K.shape_context(x, *args, 4)["hist"]
+    Ug = gpu.K.chi2_cost8(hm, hf, path="general").cpu().numpy()
+    if gpu.K.chi2_symmetric(hm, hf):       # exact (anti)parallel neighbours may break the relation; then auto == general
+        assert np.array_equal(Ug, gpu.K.chi2_cost8(hm, hf, path="symmetric").cpu().numpy(), equal_nan=True)
+    assert np.array_equal(Ug, gpu.K.chi2_cost8(hm, hf).cpu().numpy(), equal_nan=True)
+    assert np.isnan(Ug[:, 40, :]).all() and np.isnan(Ug[:, :, 40]).all()
+
+
 def test_cost_symmetry_property_large(gpu):
     """Size-independent property at a size the CPU cannot check: chi2(A, B) == chi2(B, A)^T bit for bit
     ((a-b)^2 and a+b are symmetric in IEEE arithmetic), and chi2(A, A) has an exactly zero diagonal."""
