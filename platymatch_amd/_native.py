@@ -113,6 +113,8 @@ def torch_mod():
 
 def device(dev=None):
     torch = torch_mod()
+    if dev is not None and torch.device(dev).type != "cuda":
+        return torch.device(dev)   # plumbing only (host-side tensors of a caller-supplied backend); kernels insist on .is_cuda
     if not torch.cuda.is_available():
         raise NativeError("no ROCm device visible: platymatch_amd runs on an AMD GPU only (no CPU fallback)")
     if dev is None:

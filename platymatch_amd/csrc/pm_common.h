@@ -44,17 +44,21 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
     return r;
 }
 
-// 1/d refined to full float64 accuracy, then n/d correctly rounded, for finite positive d and
-// finite n >= 0 well inside the exponent range (no scaling/fix-up needed): the LLVM AMDGPU f64
-// division sequence (v_rcp_f64 + 2 Newton steps + residual correction) without div_scale/div_fixup.
+// n / d, correctly rounded, for finite positive d and finite n >= 0 well inside the exponent range (no
+// scaling / fix-up needed).  v_rcp_f64 is good to 2^-24.4 on gfx950 (tools/microbench/rcp_accuracy.hip); one
+// cubic step r <- r + r*(e + e*e), e = 1 - d*r, leaves a truncation error of e^3 < 2^-73, i.e. the reciprocal
+// rounded to nearest in all but ~2^-20 of cases and within 0.5000005 ulp otherwise; the quotient then gets the
+// usual exact-residual correction (Markstein).  This is LLVM's AMDGPU f64 division with its two Newton steps
+// fused into one (one fma fewer) and without div_scale/div_fixup; it is checked bit for bit against IEEE
+// division on 1.3e11 operands, a third of them built to sit within 2^-53 ulp of a rounding midpoint
+// (tools/microbench/div_check.hip, also run by the gpu test-suite), and by every chi-square parity test.
 __device__ __forceinline__ double div_pos(double n, double d) {
     double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(e, r, r);
-    e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(e, r, r);
-    double q = n * r;
-    double res = __builtin_fma(-d, q, n);
+    const double e = __builtin_fma(-d, r, 1.0);
+    const double t = __builtin_fma(e, e, e);
+    r = __builtin_fma(r, t, r);
+    const double q = n * r;
+    const double res = __builtin_fma(-d, q, n);
     return __builtin_fma(res, r, q);
 }
 

@@ -225,6 +225,31 @@ def test_half_cost_path_nan_rows(gpu, micro, oracle):
     assert np.isnan(Ug[:, 40, :]).all() and np.isnan(Ug[:, :, 40]).all()
 
 
+def test_division_sequence_is_correctly_rounded(gpu):
+    """The shortened float64 division inside the chi-square kernels (pm::div_pos) against IEEE division, incl. 1e9
+    quotients constructed to lie next to a rounding midpoint; a deliberately sloppy control sequence must fail there
+    (proves the hard cases are hard).  Source: tools/microbench/div_check.hip (seqB is the shipped sequence)."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    src = os.path.join(ROOT, "tools", "microbench", "div_check.hip")
+    exe = os.path.join(ROOT, "tools", "microbench", "div_check")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-ffp-contract=off", src, "-o", exe])
+    out = subprocess.run([exe, "1000"], capture_output=True, text=True, timeout=300, check=True).stdout
+    rows = re.findall(r"seqA\(2 Newton\) (\d+)\s+seqB\(1 cubic\) (\d+)\s+control\(1 Newton\) (\d+)", out)
+    assert len(rows) == 3, out
+    for a, b, _ in rows:
+        assert int(a) == 0 and int(b) == 0, out
+    assert int(rows[2][2]) > 0, out          # the control is wrong on near-midpoint quotients
+    # and the shipped header really contains that sequence
+    hdr = open(os.path.join(ROOT, "platymatch_amd", "csrc", "pm_common.h")).read()
+    assert "__builtin_fma(e, e, e)" in hdr and "__builtin_fma(r, t, r)" in hdr
+
+
 def test_cost_symmetry_property_large(gpu):
     """Size-independent property at a size the CPU cannot check: chi2(A, B) == chi2(B, A)^T bit for bit
     ((a-b)^2 and a+b are symmetric in IEEE arithmetic), and chi2(A, A) has an exactly zero diagonal."""
