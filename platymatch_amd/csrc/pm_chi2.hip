@@ -32,6 +32,20 @@ constexpr int CH_STAGES = PM_NBINS / CH_K;
 constexpr int CH_BPITCH = CH_K + 2;       // doubles; 112 B row pitch
 constexpr double CH_TINY = 1e-300;
 
+// Tile order within an XCD's run of tiles: column tiles are taken in groups of CH_GJ; inside a group the row
+// tile advances slowest.  The ~100 workgroups an XCD has in flight then cover ~12 row tiles x 8 column tiles:
+// the 8 B tiles of the group stay hot in that XCD's L2 for the whole group and every A tile is fetched once per
+// group instead of once per column tile (measured before this ordering: ~120 GB of A re-reads per 50k build).
+constexpr int CH_GJ = 8;
+__device__ __forceinline__ void tile_of(unsigned int lid, int nTi, unsigned int nblocks, int &ti, int &tj) {
+    const unsigned int nTj = nblocks / (unsigned int)nTi;
+    const unsigned int per_group = CH_GJ * (unsigned int)nTi;
+    const unsigned int g = lid / per_group, rem = lid - g * per_group;
+    const unsigned int gcols = min((unsigned int)CH_GJ, nTj - g * CH_GJ);
+    ti = (int)(rem / gcols);
+    tj = (int)(g * CH_GJ + rem % gcols);
+}
+
 template <int NFA, int NFB>
 struct Chi2Args {
     const double *a[NFA];
@@ -49,7 +63,8 @@ __global__ __launch_bounds__(CH_THREADS) void chi2_kernel(Chi2Args<NFA, NFB> arg
     unsigned int bid = blockIdx.x;
     const unsigned int full = nblocks / 8u * 8u;
     if (bid < full) bid = (bid % 8u) * (full / 8u) + bid / 8u;
-    const int ti = bid % (unsigned int)nTi, tj = bid / (unsigned int)nTi;
+    int ti, tj;
+    tile_of(bid, nTi, nblocks, ti, tj);
     const int i0 = ti * CH_TI, j0 = tj * CH_TJ;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -151,7 +166,8 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
     unsigned int bid = blockIdx.x;
     const unsigned int full = nblocks / 8u * 8u;
     if (bid < full) bid = (bid % 8u) * (full / 8u) + bid / 8u;
-    const int ti = bid % (unsigned int)nTi, tj = bid / (unsigned int)nTi;
+    int ti, tj;
+    tile_of(bid, nTi, nblocks, ti, tj);
     const int i0 = ti * SY_TI, j0 = tj * CH_TJ;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -183,24 +183,28 @@ def icp_sharded(be, moved, fix, iters, group=None):
     loc = moved[:, bn[rank]:bn[rank + 1]].contiguous().clone()
     A_icp = torch.eye(4, dtype=torch.float64, device=moved.device).reshape(16).contiguous()
     origin = torch.cat([fix[:, 0], fix[:, 0]]).contiguous()
+    # One collective per iteration: the 24 moment sums of this iteration travel together with the residual
+    # parts of the previous one.  Every rank reduces the same gathered [G, 26] block with the same kernel, so all
+    # ranks hold bit-identical sums and solve the identical 4x4 — they stay in lockstep without a broadcast.
     residuals = []
-    for _ in range(iters):
-        nn = be.icp_nn(loc, fix)
-        sums = be.icp_accumulate(loc, fix, nn, origin)
+    rp = torch.zeros(2, dtype=torch.float64, device=moved.device)
+    for it in range(iters + (1 if world > 1 and iters else 0)):
+        last = it == iters
+        if not last:
+            nn = be.icp_nn(loc, fix)
+            sums = be.icp_accumulate(loc, fix, nn, origin)
         if world > 1:
-            parts = [torch.empty_like(sums) for _ in range(world)]
-            dist.all_gather(parts, sums, group=group)
-            sums = parts[0].clone()
-            for g in range(1, world):       # rank order: every rank forms the same float64 sums
-                sums += parts[g]
-        _, rp = be.icp_update(sums, origin, loc, fix, nn, A_icp)
-        if world > 1:
-            rps = [torch.empty_like(rp) for _ in range(world)]
-            dist.all_gather(rps, rp, group=group)
-            rp = rps[0].clone()
-            for g in range(1, world):
-                rp += rps[g]
-        residuals.append(rp[0] / rp[1])
+            mine = torch.cat([sums, rp])
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=group)
+            total = torch.stack(parts).sum(0)
+            sums = total[:24].contiguous()
+            if it > 0:
+                residuals.append(total[24] / total[25])
+        if not last:
+            _, rp = be.icp_update(sums, origin, loc, fix, nn, A_icp)
+            if world == 1:
+                residuals.append(rp[0] / rp[1])
     res = torch.stack(residuals) if residuals else torch.empty(0, dtype=torch.float64, device=moved.device)
     return A_icp.reshape(4, 4), res
 
