@@ -73,6 +73,82 @@ PM_HD int pm_phi_index(double x, double y) {
     return idx;
 }
 
+// ---- all frames of get_unary at once (the shape-context kernel's inner step) ------------------------------
+// Frames 2..4 see the same neighbour as (-x,-y), (x,-y), (-x,y) (shape_context.py:172-175, 180-181): same ring,
+// same theta, and — whenever (x, y) is clear of every sector edge — phi sectors that are fixed permutations of
+// frame 1's.  pm_phi_index4 classifies frame 1 with two multiplications (|y| against tan30*|x|, tan60*|x|), accepts
+// the result only if the point is at least 2^-40 (relative) away from all twelve rays — far more than the
+// ~1e-15 by which the exact thresholds and this arithmetic can differ — and otherwise falls back to the exact
+// sign tests per frame.  Ring thresholds on r_ replace the division r_/mean_dist (pm_ring_thresholds).
+
+PM_HD double pm_next_up(double t) {       // t > 0 finite
+    long long b; __builtin_memcpy(&b, &t, 8); b += 1; __builtin_memcpy(&t, &b, 8); return t;
+}
+PM_HD double pm_next_down(double t) {     // t > 0
+    long long b; __builtin_memcpy(&b, &t, 8); b -= 1; __builtin_memcpy(&t, &b, 8); return t;
+}
+
+// rho[k] = smallest float64 r_ with fl(r_ / md) >= edge k, so that  #{k : r_ >= rho[k]}  is the reference's
+// r_index (first edge with r < edge, else 4; shape_context.py:49-56) for every r_, bit for bit.
+PM_HD void pm_ring_thresholds(double md, double rho[4]) {
+    const double e[4] = {PM_REDGE0, PM_REDGE1, PM_REDGE2, PM_REDGE3};
+    for (int k = 0; k < 4; ++k) {
+        const double t0 = e[k] * md;
+        // mean distance 0 or NaN (r = inf / NaN: `r < edge` never holds -> ring 4), or e*md underflowed: every r_ passes
+        if (!(md > 0.0) || !(t0 > 0.0)) { rho[k] = -1.0; continue; }
+        // e*md overflowed or md = inf (r = 0 for every finite r_ -> ring 0): nothing passes
+        if (!(t0 < 0x1p+1020)) { rho[k] = t0; continue; }
+        double t = t0;
+        for (int it = 0; it < 8; ++it) { const double p = pm_next_down(t); if (p / md >= e[k]) t = p; else break; }
+        for (int it = 0; it < 8; ++it) { if (t / md >= e[k]) break; t = pm_next_up(t); }
+        rho[k] = t;
+    }
+}
+
+#define PM_TAN30 0x1.279a74590331cp-1
+#define PM_TAN60 0x1.bb67ae8584caap+0
+
+// phi sectors of (x,y), (-x,-y), (x,-y), (-x,y).  Exact in all cases; fast when clear of the edges.
+PM_HD void pm_phi_index4(double x, double y, int nframes, int p[4]) {
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const double sum = ax + ay;
+    const double m = sum * 0x1p-40;
+    const double d1 = ay - PM_TAN30 * ax, d2 = ay - PM_TAN60 * ax;
+    const int safe = (__builtin_fabs(d1) > m) & (__builtin_fabs(d2) > m) & (ax > m) & (ay > m) & (sum > 0x1p-900) & (sum < 0x1p+900);
+    if (safe) {
+        const int k = (d1 > 0.0) + (d2 > 0.0);
+        const int p0 = (y > 0.0) ? ((x > 0.0) ? k : 5 - k) : ((x > 0.0) ? 11 - k : 6 + k);
+        p[0] = p0;
+        p[1] = (p0 < 6) ? p0 + 6 : p0 - 6;
+        p[2] = 11 - p0;
+        p[3] = (p0 < 6) ? 5 - p0 : 17 - p0;
+    } else {
+        p[0] = pm_phi_index(x, y);
+        p[1] = pm_phi_index(-x, -y);
+        p[2] = (nframes > 2) ? pm_phi_index(x, -y) : 0;
+        p[3] = (nframes > 2) ? pm_phi_index(-x, y) : 0;
+    }
+}
+
+// Bins of one neighbour (frame coordinates x_, y_, z_) in frames 1..nframes: out[f] = bin or PM_DROP.
+PM_HD void pm_bin_index4(double x_, double y_, double z_, const double rho[4], int nframes, int out[4]) {
+    const double r_ = __builtin_sqrt((x_ * x_ + y_ * y_) + z_ * z_);   // :29
+    const double c = z_ / r_;                                          // :31 argument of arccos
+    if (!(__builtin_fabs(c) <= 1.0) || x_ != x_ || y_ != y_) {         // arccos / atan2 -> NaN: not counted
+        out[0] = out[1] = out[2] = out[3] = PM_DROP;
+        return;
+    }
+    const int th = (c <= PM_CTH[0]) + (c <= PM_CTH[1]) + (c <= PM_CTH[2]) + (c <= PM_CTH[3]) + (c <= PM_CTH[4]) + (c <= PM_CTH[5]);
+    const int ring = (r_ >= rho[0]) + (r_ >= rho[1]) + (r_ >= rho[2]) + (r_ >= rho[3]);
+    const int base = ring * 72 + th * 12;
+    int p[4];
+    pm_phi_index4(x_, y_, nframes, p);
+    for (int f = 0; f < 4; ++f) {
+        const int idx = base + p[f];
+        out[f] = (f < nframes && idx < PM_NBINS) ? idx : PM_DROP;
+    }
+}
+
 // Bin of a neighbour given its frame coordinates (x_, y_, z_), r_ = ||.|| and r = r_/mean_dist,
 // both already computed by the caller in float64 (shape_context.py:29-30).
 PM_HD int pm_bin_index(double x_, double y_, double z_, double r_, double r) {

@@ -74,12 +74,20 @@ __global__ __launch_bounds__(NN_THREADS) void nn_kernel(const double *__restrict
     const int jb = blockIdx.y * slice_len, je = jb + slice_len;
 
     NnBest A = {INFINITY, INFINITY, 0x7fffffff}, B = {INFINITY, INFINITY, 0x7fffffff};
+    double4 cur[NN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < NN_UNROLL; ++u) cur[u] = fixp[jb + u];
     for (int j = jb; j < je; j += NN_UNROLL) {
+        // software prefetch: the next trip's scalar loads are in flight while this trip's arithmetic runs
+        double4 nxt[NN_UNROLL];
+        const int jn = (j + NN_UNROLL < je) ? j + NN_UNROLL : jb;
+#pragma unroll
+        for (int u = 0; u < NN_UNROLL; ++u) nxt[u] = fixp[jn + u];
         double sa[NN_UNROLL], sb[NN_UNROLL];
         unsigned long long hit = 0;
 #pragma unroll
         for (int u = 0; u < NN_UNROLL; ++u) {
-            const double4 f = fixp[j + u];
+            const double4 f = cur[u];
             double d0 = f.x - a0, d1 = f.y - a1, d2 = f.z - a2;
             sa[u] = (d0 * d0 + d1 * d1) + d2 * d2;
             d0 = f.x - b0; d1 = f.y - b1; d2 = f.z - b2;
@@ -93,6 +101,8 @@ __global__ __launch_bounds__(NN_THREADS) void nn_kernel(const double *__restrict
                 nn_offer(B, sb[u], j + u);
             }
         }
+#pragma unroll
+        for (int u = 0; u < NN_UNROLL; ++u) cur[u] = nxt[u];
     }
     if (i0 < n) { out_idx[(size_t)blockIdx.y * n + i0] = A.I; out_dist[(size_t)blockIdx.y * n + i0] = __builtin_sqrt(A.S); }
     if (i1 < n) { out_idx[(size_t)blockIdx.y * n + i1] = B.I; out_dist[(size_t)blockIdx.y * n + i1] = __builtin_sqrt(B.S); }

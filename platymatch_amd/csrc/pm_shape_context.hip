@@ -7,8 +7,9 @@
 // neighbour per step for all frames, and counts go to per-wave LDS histograms with ds_add_u32.
 // `transform` builds T = B.inv(A) mapping p_i -> 0, p_i + x,y,z -> e1,e2,e3; for the orthonormal
 // frame that is [x y z]^T (p_j - p_i), evaluated here directly.
-// Frames 2..4 differ from frame 1 only in the signs of (x, y) (:172-175, :180-181), so r and theta
-// are shared and only the phi sector is re-derived per frame.
+// Frames 2..4 differ from frame 1 only in the signs of (x, y) (:172-175, :180-181), so ring and theta are
+// shared; the phi sectors of all frames come from one classification when the neighbour is clear of every
+// sector edge and from exact per-frame sign tests otherwise (pm_bin_index4, pm_binning.h).
 #include "pm_common.h"
 #include "pm_binning.h"
 
@@ -47,25 +48,20 @@ __global__ __launch_bounds__(SC_THREADS) void shape_context_kernel(
     y0 /= ny; y1 /= ny; y2 /= ny;
     __syncthreads();
 
+    double rho[4];
+    pm_ring_thresholds(md, rho);       // r_/md < edge  <=>  r_ < rho (exact), computed once per workgroup
+
     for (int j = tid; j < n; j += SC_THREADS) {
         if (j == i) continue;                                  // np.delete (:168)
-        double v0 = P0[j] - p0, v1 = P1[j] - p1, v2 = P2[j] - p2;
-        double vx = (x0 * v0 + x1 * v1) + x2 * v2;
-        double vy = (y0 * v0 + y1 * v1) + y2 * v2;
-        double vz = (z0 * v0 + z1 * v1) + z2 * v2;
-        double r_ = __builtin_sqrt((vx * vx + vy * vy) + vz * vz);   // :29
-        double r = r_ / md;                                          // :30
-        // frame f: (sx*vx, sy*vy, vz); r_, r, theta unchanged
-        int b = pm_bin_index(vx, vy, vz, r_, r);
-        if (b != PM_DROP) atomicAdd(&h[wave][0][b], 1u);
-        b = pm_bin_index(-vx, -vy, vz, r_, r);
-        if (b != PM_DROP) atomicAdd(&h[wave][1][b], 1u);
-        if (NF == 4) {
-            b = pm_bin_index(vx, -vy, vz, r_, r);
-            if (b != PM_DROP) atomicAdd(&h[wave][2][b], 1u);
-            b = pm_bin_index(-vx, vy, vz, r_, r);
-            if (b != PM_DROP) atomicAdd(&h[wave][3][b], 1u);
-        }
+        const double v0 = P0[j] - p0, v1 = P1[j] - p1, v2 = P2[j] - p2;
+        const double vx = (x0 * v0 + x1 * v1) + x2 * v2;
+        const double vy = (y0 * v0 + y1 * v1) + y2 * v2;
+        const double vz = (z0 * v0 + z1 * v1) + z2 * v2;
+        int b[4];
+        pm_bin_index4(vx, vy, vz, rho, NF, b);
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            if (b[f] != PM_DROP) atomicAdd(&h[wave][f][b[f]], 1u);
     }
     __syncthreads();
     // fold the per-wave histograms, total per frame

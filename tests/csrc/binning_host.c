@@ -17,3 +17,16 @@ int pmt_phi_index(const double *xy, int n, int32_t *out) {
     for (int i = 0; i < n; ++i) out[i] = pm_phi_index(xy[2 * i], xy[2 * i + 1]);
     return 0;
 }
+
+/* the kernel's per-neighbour step: all four frames at once; out: n x 4 int32 */
+int pmt_bin_index4(const double *nb, int n, double mean_dist, int nframes, int32_t *out) {
+    double rho[4];
+    pm_ring_thresholds(mean_dist, rho);
+    for (int i = 0; i < n; ++i) {
+        int b[4];
+        pm_bin_index4(nb[3 * i], nb[3 * i + 1], nb[3 * i + 2], rho, nframes, b);
+        for (int f = 0; f < 4; ++f) out[4 * i + f] = b[f];
+    }
+    return 0;
+}
+int pmt_ring_thresholds(double md, double *rho) { pm_ring_thresholds(md, rho); return 0; }

@@ -85,3 +85,89 @@ def test_tables_regenerate(oracle):
     out = subprocess.run(["python", gen], capture_output=True, text=True, timeout=120, check=True).stdout
     with open(os.path.join(ROOT, "platymatch_amd", "csrc", "pm_bin_tables.h")) as fh:
         assert fh.read() == out
+
+
+# ---- the kernel's fused four-frame step (pm_bin_index4: ring thresholds, one-shot phi classification + exact fallback)
+SIGNS = [(1.0, 1.0), (-1.0, -1.0), (1.0, -1.0), (-1.0, 1.0)]     # frames 1..4: (x, y) sign flips (shape_context.py:172-181)
+
+
+def prod_bin4(lib, nb, md, nframes=4):
+    nb = np.ascontiguousarray(nb, dtype=np.float64)
+    out = np.empty((len(nb), 4), np.int32)
+    lib.pmt_bin_index4(nb.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(len(nb)), ctypes.c_double(md), ctypes.c_int(nframes),
+                       out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def oracle_bin4(oracle, nb, md):
+    return np.stack([oracle_bin(oracle, nb * np.array([sx, sy, 1.0]), md) for sx, sy in SIGNS], axis=1)
+
+
+def test_four_frame_step_random_and_edges(host_lib, oracle, micro):
+    rng = np.random.default_rng(2)
+    nb = rng.normal(size=(1_000_000, 3)) * rng.uniform(0.1, 100, size=(1_000_000, 1))
+    for md in (37.0, 114.13353403330422, 1.0):
+        assert np.array_equal(prod_bin4(host_lib, nb, md), oracle_bin4(oracle, nb, md))
+    assert np.array_equal(prod_bin4(host_lib, nb[:1000], 37.0, nframes=2)[:, :2], oracle_bin4(oracle, nb[:1000], 37.0)[:, :2])
+    assert (prod_bin4(host_lib, nb[:1000], 37.0, nframes=2)[:, 2:] == -1).all()
+    for md in (1.0, 3.0, 0.7):
+        assert np.array_equal(prod_bin4(host_lib, micro["grid_neighbors"], md), oracle_bin4(oracle, micro["grid_neighbors"], md))
+    tests = []
+    for m in range(13):
+        for k in list(range(-40, 41)) + [-10 ** 3, 10 ** 3, -10 ** 5, 10 ** 5]:      # ulps around each edge, then just outside the margin
+            ang = m * np.pi / 6 + (k * 2.0 ** -52 if abs(k) > 40 else 0.0)
+            if abs(k) <= 40:
+                for _ in range(abs(k)):
+                    ang = math.nextafter(ang, math.inf if k > 0 else -math.inf)
+            for rad in (1.0, 3.7, 1e-3, 123.456):
+                for zz in (0.0, 0.5, -2.0):
+                    tests.append((rad * math.cos(ang), rad * math.sin(ang), zz))
+                    tests.append((rad * math.sin(ang), zz, rad * math.cos(ang)))
+    # points at relative distance ~2^-40 from the 30/60 degree rays and the axes: both sides of the safety margin
+    for t in (math.tan(math.pi / 6), math.tan(math.pi / 3)):
+        for eps in (0.0, 2.0 ** -41, 2.0 ** -40, 2.0 ** -39, -2.0 ** -41, -2.0 ** -39, 1e-9, -1e-9):
+            for sx in (1, -1):
+                for sy in (1, -1):
+                    tests.append((sx * 10.0, sy * 10.0 * t * (1 + eps), 1.0))
+    for eps in (2.0 ** -41, 2.0 ** -39, 1e-300, 1e-20):
+        tests += [(10.0, eps * 10, 1.0), (10.0, -eps * 10, 1.0), (-10.0, eps * 10, 1.0), (eps * 10, 10.0, 1.0), (-eps * 10, -10.0, 1.0)]
+    tests = np.array(tests)
+    assert np.array_equal(prod_bin4(host_lib, tests, 1.0), oracle_bin4(oracle, tests, 1.0))
+    z = [0.0, -0.0, 1.0, -1.0, 1e-300, -1e-300, 1e-310, 1e150, -1e153, np.nan]
+    sp = np.array([(x, y, w) for x in z for y in z for w in z])
+    a, b = prod_bin4(host_lib, sp, 1.0), oracle_bin4(oracle, sp, 1.0)
+    ratio_underflow = (np.abs(sp[:, 1]) > 0) & (np.abs(sp[:, 1]) < np.abs(sp[:, 0]) * 1e-300)
+    assert np.array_equal(a[~ratio_underflow], b[~ratio_underflow])
+
+
+def test_ring_thresholds_equal_the_division(host_lib):
+    """#{k : r_ >= rho[k]} must be the reference's r_index for every r_ (rho from pm_ring_thresholds)."""
+    edges = np.array([0.125, 0.25000000000000006, 0.5000000000000001, 1.0])
+    rng = np.random.default_rng(3)
+    for md in [1.0, 3.0, 0.7, 37.0, 114.13353403330422, 1e-3, 12345.678, 1 / 3, float(rng.uniform(1, 200)), 2.0 ** -30, 1e300, 1e-300]:
+        rho = np.zeros(4)
+        host_lib.pmt_ring_thresholds(ctypes.c_double(md), rho.ctypes.data_as(ctypes.c_void_p))
+        cand = [rng.uniform(0, 3 * md, size=20000)]
+        for k in range(4):                       # and a dense neighbourhood of every edge
+            c = edges[k] * md
+            pts = [c]
+            for _ in range(50):
+                pts.append(math.nextafter(pts[-1], math.inf))
+            lo = c
+            for _ in range(50):
+                lo = math.nextafter(lo, -math.inf)
+                pts.append(lo)
+            cand.append(np.array(pts))
+        r_ = np.concatenate(cand)
+        with np.errstate(over="ignore"):
+            want = np.where((r_ / md)[:, None] < edges[None, :], 1, 0)
+        want_idx = np.where(want.any(1), want.argmax(1), 4)
+        got_idx = (r_[:, None] >= rho[None, :]).sum(1)
+        assert np.array_equal(got_idx, want_idx), md
+    for md in (0.0, float("nan")):               # degenerate mean distance: `r < edge` never holds -> ring 4
+        rho = np.zeros(4)
+        host_lib.pmt_ring_thresholds(ctypes.c_double(md), rho.ctypes.data_as(ctypes.c_void_p))
+        assert (np.array([0.0, 1.0, 1e300])[:, None] >= rho[None, :]).all()
+    rho = np.zeros(4)
+    host_lib.pmt_ring_thresholds(ctypes.c_double(float("inf")), rho.ctypes.data_as(ctypes.c_void_p))
+    assert not (np.array([0.0, 1.0, 1e300])[:, None] >= rho[None, :]).any()      # r = 0 for every finite r_: ring 0
