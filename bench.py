@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=50000, help="points per cloud (default: the BASELINE 50k configuration)")
+    ap.add_argument("--points", type=int, default=50000, help="points per cloud (default: the BASELINE 50k configuration)")
     ap.add_argument("--icp-iters", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -106,15 +106,23 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     nat.load()                                   # fails loudly if the HIP library is missing
+    # rehearsal switches (not used by the driver): PM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # PM_BENCH_BACKEND=gloo replaces RCCL, so the sharded code path can be exercised on a one-GPU box
+    if os.environ.get("PM_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("PM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
 
-    n = m = args.n
+    n = m = args.points
     mv_h, fx_h, start_h = synth(n)
     mov, fix, start = (nat.to_dev(x, dev=dev) for x in (mv_h, fx_h, start_h))
     be = P.GpuBackend(dev)
@@ -184,6 +192,11 @@ def main():
     tflops = flops / (chi2_ms * 1e-3) / 1e12
     ns_per_instr = chi2_ms * 1e6 / (instr / 1024.0)                          # per SIMD (256 CUs x 4)
 
+    # HBM traffic of that launch from rocprofv3 PMC passes (profiles/r01_pmc_*_counter_collection.csv; separate --pmc runs,
+    # FETCH_SIZE and WRITE_SIZE in KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): 2 x 19.73 + 160.0 GB.
+    # Measured for the 1-GPU 50k half-cost launch only; null for any other configuration.
+    traffic = 199.5 if (world == 1 and n == 50000 and sym) else None
+
     if rank == 0:
         final = (A.reshape(4, 4).cpu().numpy())
         out = {
@@ -198,7 +211,7 @@ def main():
                        "sharding": "rows/%d" % world},
             "stage_ms": {"statistics": float(stage[0]), "shape_context": float(stage[1]), "chi2_cost8": chi2_ms, "icp": float(stage[3])},
             "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch",
                          "note": "compulsory bytes / measured launch time; the kernel is float64-VALU bound (360 correctly rounded "
                                  "divisions per pair and matrix), see fp64_valu"},
             "fp64_valu": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
