@@ -132,7 +132,7 @@ struct NnPlan {
 inline NnPlan nn_plan(int n, int m) {
     NnPlan p;
     const int tiles = (n + NN_TILE - 1) / NN_TILE;
-    int s = (6144 + tiles - 1) / tiles;                           // aim for ~6 waves per SIMD in flight
+    int s = 8192 / tiles;                                         // fill 8 waves per SIMD (1024 SIMDs) without spilling into a ninth
     const int max_slices = (m + 63) / 64;                         // at least 64 fixed points per slice
     if (s > max_slices) s = max_slices;
     if (s > 256) s = 256;
