@@ -184,13 +184,16 @@ def main():
     rows = r1 - r0
     algo_bytes = 8.0 * 8 * rows * m + 2880.0 * (2 * rows + 4 * m)          # 8 matrices written + descriptors read once
     achieved = algo_bytes / (chi2_ms * 1e-3) / 1e9
-    # float64 VALU view of the same launch.  Half-cost kernel: per (pair, bin) 4 terms x (sub, 2 mul, add, rcp, 6 fma) + 8
-    # running-sum adds = 52 instructions, 76 flop (fma = 2); general kernel: 8 terms x 12 instructions, 144 flop.
+    # float64 VALU view of the same launch.  Half-cost kernel: per (pair, bin) 4 terms x (sub, 2 mul, add, rcp, 5 fma) + 8
+    # running-sum adds = 48 instructions, 68 flop (fma = 2); general kernel: 8 terms x 11 instructions, 128 flop.
+    # Issue model (measured, tools/microbench/fp64_issue.hip + SQ counters): 4 cycles per instruction, 16 for v_rcp_f64.
     kernel_name = "pm::chi2_sym_kernel<4,2>" if sym else "pm::chi2_kernel<2,4>"
-    flops = (76.0 if sym else 144.0) * 360 * rows * m
-    instr = (52.0 if sym else 96.0) * 360 * rows * m / 64.0                  # wave64 VALU instructions
+    flops = (68.0 if sym else 128.0) * 360 * rows * m
+    instr = (48.0 if sym else 88.0) * 360 * rows * m / 64.0                  # wave64 VALU instructions
+    issue_cycles = ((44 * 4 + 4 * 16) if sym else (80 * 4 + 8 * 16)) * 360.0 * rows * m / 64.0 / 1024.0   # per SIMD
     tflops = flops / (chi2_ms * 1e-3) / 1e12
     ns_per_instr = chi2_ms * 1e6 / (instr / 1024.0)                          # per SIMD (256 CUs x 4)
+    issue_bound_ms = issue_cycles / 2.4e9 * 1e3                              # at the 2.4 GHz maximum clock
 
     # HBM traffic of that launch from rocprofv3 PMC passes (profiles/r01_pmc_*_counter_collection.csv; separate --pmc runs,
     # FETCH_SIZE and WRITE_SIZE in KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): 2 x 19.73 + 160.0 GB.
@@ -216,6 +219,7 @@ def main():
                                  "divisions per pair and matrix), see fp64_valu"},
             "fp64_valu": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
                           "ns_per_wave_instruction_per_simd": ns_per_instr,
+                          "issue_bound_ms": issue_bound_ms, "frac_of_issue_bound": issue_bound_ms / chi2_ms,
                           "note": "measured issue cost of one wave64 float64 instruction on this chip: ~2.0 ns (fma/mul/add), ~6.9 ns (rcp); "
                                   "tools/microbench/fp64_issue.hip"},
             "icp_residual_first_last": [float(res[0]), float(res[-1])] if args.icp_iters else None,
