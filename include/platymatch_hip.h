@@ -66,6 +66,25 @@ int pm_mean_distance(const double *xyz, int n, double *out1, void *ws, size_t ws
 size_t pm_pca_axis_workspace(int n);
 int pm_pca_axis(const double *xyz, int n, double *out3, void *ws, size_t ws_bytes, void *stream);
 
+/* All three principal axes as sklearn PCA(3).fit(X).components_ (the widget's PCA-only alignment,
+ * _dock_widget.py:722-731): out[9] row-major, rows ordered by decreasing variance, each row's
+ * largest-magnitude entry positive. */
+int pm_pca_components(const double *xyz, int n, double *out9, void *stream);
+
+/* ---- rows "next" of SURVEY.md §8f: evaluation and label images --------------------------------- */
+
+/* scipy.spatial.distance.cdist(a.T, b.T) (EvaluateMetrics._calculate_metrics, _dock_widget.py:1030-1051):
+ * out[i*ld + j] = sqrt(((a0-b0)^2 + (a1-b1)^2) + (a2-b2)^2), a is 3 x n, b is 3 x m.  An HBM-write-bound
+ * kernel (8 bytes per pair): lanes own adjacent column pairs, 16-byte stores. */
+int pm_cdist(const double *a, int n, const double *b, int m, double *out, size_t ld, void *stream);
+
+/* Label image -> per-label voxel count and coordinate sums (the widget's centroid loop over np.where,
+ * _dock_widget.py:497-521, as one pass): labels is a Z x Y x X int32 volume (0 = background, labels in
+ * [1, n_labels)); counts[n_labels] and sums[3][n_labels] (z, y, x index sums) are uint64 accumulators that
+ * the call zeroes itself.  Integer sums are exact, so centroid = sum / count reproduces np.mean bit for bit. */
+int pm_label_moments(const int32_t *labels, int nz, int ny, int nx, int n_labels, unsigned long long *counts,
+                     unsigned long long *sums3, void *stream);
+
 /* ---- shape context ------------------------------------------------------------------------- */
 
 /* get_unary (shape_context.py:144-188) for rows [row0, row0+nrows) of one cloud of n points:

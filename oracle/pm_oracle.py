@@ -325,3 +325,69 @@ def estimate_transform(moving, fixed, *, transform="Affine", mode="unsupervised"
     moved = apply_affine_transform(moving, A_sc)                                                     # 714
     A_icp = perform_icp(moved, fixed, icp_iterations, transform, log=details)                        # 715-717
     return A_sc, A_icp, inliers
+
+
+# --------------------------------------------------------------------------- rows "next" 
+def pca_components(detections_nx3):
+    """sklearn.decomposition.PCA(3).fit(X).components_ (the widget's PCA-only alignment, _dock_widget.py:722-731):
+    eigenvectors of the sample covariance by decreasing eigenvalue, each row's largest-|.| entry positive."""
+    X = np.asarray(detections_nx3, dtype=np.float64)
+    Xc = X - X.mean(0)
+    w, V = np.linalg.eigh((Xc.T @ Xc) / (X.shape[0] - 1))
+    comps = V[:, np.argsort(w)[::-1]].T.copy()
+    for r in comps:
+        if r[np.argmax(np.abs(r))] < 0:
+            r *= -1
+    return comps
+
+
+def cdist(a, b):
+    """scipy.spatial.distance.cdist(a.T, b.T) — the call EvaluateMetrics makes (_dock_widget.py:1032,1038,1050)."""
+    from scipy.spatial.distance import cdist as _cdist
+    return _cdist(np.asarray(a).transpose(), np.asarray(b).transpose())
+
+
+def calculate_metrics(moving_keypoints, moving_keypoint_ids, moving_detections, moving_ids, fixed_keypoints,
+                      fixed_keypoint_ids, fixed_detections, fixed_ids, transform_matrix_1, transform_matrix_2):
+    """EvaluateMetrics._calculate_metrics (_dock_widget.py:1030-1080) -> (matching accuracy, average registration error)."""
+    r, c = linear_sum_assignment(cdist(moving_keypoints, moving_detections))
+    moving_dictionary = {moving_keypoint_ids[i]: moving_ids[c[i]] for i in r}
+    r, c = linear_sum_assignment(cdist(fixed_keypoints, fixed_detections))
+    fixed_dictionary = {fixed_keypoint_ids[i]: fixed_ids[c[i]] for i in r}
+    moved = apply_affine_transform(apply_affine_transform(moving_detections, transform_matrix_1), transform_matrix_2)
+    row_indices, col_indices = linear_sum_assignment(cdist(moved, fixed_detections))
+    row_ids, col_ids = np.asarray(moving_ids)[row_indices], np.asarray(fixed_ids)[col_indices]
+    hits = 0
+    for key in moving_dictionary.keys():
+        if key in fixed_dictionary.keys():
+            got = col_ids[np.where(row_ids == moving_dictionary[key])]
+            if got.size == 1 and got[0] == fixed_dictionary[key]:
+                hits += 1
+    accuracy = hits / len(fixed_dictionary.keys())
+    combined = np.matmul(transform_matrix_2, transform_matrix_1)
+    tmk = apply_affine_transform(moving_keypoints, combined)
+    distance = 0
+    for i in range(tmk.shape[1]):
+        distance += np.linalg.norm([np.asarray(fixed_keypoints).transpose()[np.where(np.asarray(fixed_keypoint_ids) == moving_keypoint_ids[i]), :]
+                                    - tmk.transpose()[i, :]])
+    return accuracy, distance / len(moving_dictionary.keys())
+
+
+def label_centroids(label_image, anisotropy=1.0):
+    """The widget's label-image branch (_dock_widget.py:497-521), literally: per label np.where + np.mean."""
+    data = np.asarray(label_image)
+    ids = np.unique(data)
+    ids = ids[ids != 0]
+    cents, sizes = [], []
+    for i in ids:
+        z, y, x = np.where(data == i)
+        cents.append([np.mean(z), np.mean(y), np.mean(x)])
+        sizes.append(float(anisotropy) * len(z))
+    return np.asarray(cents).transpose(), np.asarray(sizes), ids
+
+
+def ransac_error_from_sizes(moving_nucleus_size, fixed_nucleus_size):
+    """_dock_widget.py:613-618."""
+    if len(moving_nucleus_size) == 0 or len(fixed_nucleus_size) == 0:
+        return 16
+    return 0.5 * (np.average(moving_nucleus_size) ** (1 / 3) + np.average(fixed_nucleus_size) ** (1 / 3))

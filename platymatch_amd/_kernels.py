@@ -71,6 +71,51 @@ def pca_axis(xyz):
     return out
 
 
+def pca_components(xyz):
+    """-> [3, 3]: sklearn PCA(3).fit(X).components_ (rows by decreasing variance, sign convention of svd_flip)."""
+    xyz = _cloud(xyz)
+    if xyz.shape[1] < 2:
+        raise ValueError("PCA needs at least two points")
+    out = _t().empty((3, 3), dtype=_t().float64, device=xyz.device)
+    check(nat.load().pm_pca_components(ptr(xyz), xyz.shape[1], ptr(out), nat.stream_ptr()))
+    return out
+
+
+def cdist(a, b, out=None):
+    """Euclidean distance matrix of two [3, n], [3, m] clouds -> [n, m] (scipy cdist semantics)."""
+    torch = _t()
+    a, b = _cloud(a, "a"), _cloud(b, "b")
+    n, m = a.shape[1], b.shape[1]
+    if out is None:
+        out = torch.empty((n, m), dtype=torch.float64, device=a.device)
+    elif not (out.is_cuda and out.dtype == torch.float64 and tuple(out.shape) == (n, m) and out.stride(1) == 1):
+        raise ValueError("out must be float64 GPU [n, m] with unit column stride")
+    check(nat.load().pm_cdist(ptr(a), n, ptr(b), m, ptr(out), out.stride(0), nat.stream_ptr()))
+    return out
+
+
+def label_moments(labels, n_labels=None):
+    """labels: int32 GPU [Z, Y, X] -> (counts [L] int64, sums [3, L] int64 of z, y, x indices), L = max label + 1."""
+    torch = _t()
+    if not (nat.is_torch(labels) and labels.is_cuda and labels.dtype == torch.int32 and labels.dim() == 3
+            and labels.is_contiguous() and labels.numel() > 0):
+        raise ValueError("labels must be a contiguous int32 GPU tensor [Z, Y, X]")
+    if n_labels is None:
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0:
+            raise ValueError("labels must be non-negative")
+        n_labels = max(hi + 1, 2)
+    if n_labels > 2 ** 27:
+        raise ValueError("label values above 2^27 are not supported")
+    nz, ny, nx = labels.shape
+    counts = torch.empty(n_labels, dtype=torch.int64, device=labels.device)
+    sums = torch.empty((3, n_labels), dtype=torch.int64, device=labels.device)
+    check(nat.load().pm_label_moments(ptr(labels), nz, ny, nx, n_labels, ptr(counts), ptr(sums), nat.stream_ptr()))
+    if int(counts[0]) != 0:
+        raise IndexError("label image has values outside [0, %d)" % n_labels)
+    return counts, sums
+
+
 def shape_context(xyz, centroid3, x0_3, mean_dist1, n_frames, row0=0, nrows=None, want_counts=False, want_hist=True):
     """-> dict(hist=[F, nrows, 360] float64, counts=[F, nrows, 360] int32, totals=[F, nrows] int32)."""
     torch = _t()

@@ -30,6 +30,9 @@ SIGNATURES = {
     "pm_mean_distance": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_pca_axis_workspace": (_c_size_t, [_c_int]),
     "pm_pca_axis": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_pca_components": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
+    "pm_cdist": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_label_moments": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "pm_shape_context": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int,
                                   _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "pm_shape_context_neighbors": (_c_int, [_c_void_p, _c_int, _c_double, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),

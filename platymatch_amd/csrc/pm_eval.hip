@@ -1,0 +1,112 @@
+// pm_eval.hip — rows "next" of SURVEY.md §8f: pairwise Euclidean distances for the evaluation metrics and
+// per-label moments of a label image.
+// Reference: EvaluateMetrics._calculate_metrics (_dock_widget.py:1030-1080: scipy cdist + linear_sum_assignment)
+// and the label-image branch of EstimateTransform._click_run (_dock_widget.py:497-521: per label np.where + np.mean).
+#include "pm_common.h"
+
+namespace pm {
+
+// ---- cdist: 8 bytes written per pair, nothing else to do -> HBM-write bound ----------------------------------
+// Workgroup tile: 32 rows x 512 columns.  A lane owns two adjacent columns (one 16-byte store per row: the
+// store width that reaches the write roofline on gfx950) and keeps their b-points in registers; the 32 a-points of
+// the tile are wave-uniform (scalar loads).  scipy's euclidean kernel sums (u_i - v_i)^2 in coordinate order and
+// takes one sqrt: ((d0*d0 + d1*d1) + d2*d2), reproduced operation for operation.
+constexpr int CD_ROWS = 32;
+constexpr int CD_COLS = 512;
+
+__global__ __launch_bounds__(256) void cdist_kernel(const double *__restrict__ a, int n, const double *__restrict__ b, int m,
+                                                    double *__restrict__ out, size_t ld) {
+    const int j = blockIdx.x * CD_COLS + 2 * threadIdx.x;
+    const int i0 = blockIdx.y * CD_ROWS;
+    if (j >= m) return;
+    const bool two = (j + 1 < m) && ((ld & 1) == 0) && ((((uintptr_t)out) & 15) == 0);   // 16-byte store allowed
+    const int j1 = min(j + 1, m - 1);
+    const double b0 = b[j], b1 = b[(size_t)m + j], b2 = b[2 * (size_t)m + j];
+    const double c0 = b[j1], c1 = b[(size_t)m + j1], c2 = b[2 * (size_t)m + j1];
+    const int rows = min(CD_ROWS, n - i0);
+    for (int r = 0; r < rows; ++r) {
+        const int i = i0 + r;                                  // wave-uniform
+        const double p0 = a[i], p1 = a[(size_t)n + i], p2 = a[2 * (size_t)n + i];
+        double d0 = p0 - b0, d1 = p1 - b1, d2 = p2 - b2;
+        const double u = __builtin_sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+        d0 = p0 - c0; d1 = p1 - c1; d2 = p2 - c2;
+        const double v = __builtin_sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+        double *dst = out + (size_t)i * ld + j;
+        if (two) {
+            *reinterpret_cast<double2 *>(dst) = make_double2(u, v);
+        } else {
+            dst[0] = u;
+            if (j + 1 < m) dst[1] = v;
+        }
+    }
+}
+
+// ---- label moments -----------------------------------------------------------------------------------------------
+// One thread walks LM_RUN consecutive voxels of one image row and flushes a (count, sum x) pair per run of equal
+// labels: labels are spatially coherent, so a thread issues one or two sets of atomics instead of LM_RUN.
+// All accumulators are 64-bit integers: the sums are exact, the result does not depend on the order of the atomics.
+constexpr int LM_RUN = 16;
+
+__global__ __launch_bounds__(256) void label_moments_kernel(const int32_t *__restrict__ labels, int nz, int ny, int nx,
+                                                            int n_labels, unsigned long long *__restrict__ counts,
+                                                            unsigned long long *__restrict__ sums, int *__restrict__ bad) {
+    const int chunks = (nx + LM_RUN - 1) / LM_RUN;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)nz * ny * chunks;
+    if (t >= total) return;
+    const int chunk = (int)(t % chunks);
+    const long long row = t / chunks;                          // z * ny + y
+    const int y = (int)(row % ny), z = (int)(row / ny);
+    const int x0 = chunk * LM_RUN, x1 = min(nx, x0 + LM_RUN);
+    const int32_t *p = labels + row * (long long)nx;
+    int cur = 0;
+    unsigned long long cnt = 0, sx = 0;
+    for (int x = x0; x < x1; ++x) {
+        const int l = p[x];
+        if (l != cur) {
+            if (cur > 0 && cnt) {
+                atomicAdd(&counts[cur], cnt);
+                atomicAdd(&sums[cur], cnt * (unsigned long long)z);
+                atomicAdd(&sums[(size_t)n_labels + cur], cnt * (unsigned long long)y);
+                atomicAdd(&sums[2 * (size_t)n_labels + cur], sx);
+            }
+            cur = l; cnt = 0; sx = 0;
+            if (l < 0 || l >= n_labels) { atomicOr(bad, 1); cur = 0; }
+        }
+        if (cur > 0) { ++cnt; sx += (unsigned long long)x; }
+    }
+    if (cur > 0 && cnt) {
+        atomicAdd(&counts[cur], cnt);
+        atomicAdd(&sums[cur], cnt * (unsigned long long)z);
+        atomicAdd(&sums[(size_t)n_labels + cur], cnt * (unsigned long long)y);
+        atomicAdd(&sums[2 * (size_t)n_labels + cur], sx);
+    }
+}
+
+}  // namespace pm
+
+extern "C" {
+
+int pm_cdist(const double *a, int n, const double *b, int m, double *out, size_t ld, void *stream) {
+    if (!a || !b || !out || n <= 0 || m <= 0 || ld < (size_t)m) return PM_ERR_INVALID_ARG;
+    dim3 grid((m + pm::CD_COLS - 1) / pm::CD_COLS, (n + pm::CD_ROWS - 1) / pm::CD_ROWS);
+    if (grid.y > 65535u * 1024u) return PM_ERR_INVALID_ARG;
+    pm::cdist_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, n, b, m, out, ld);
+    return pm::launch_status();
+}
+
+int pm_label_moments(const int32_t *labels, int nz, int ny, int nx, int n_labels, unsigned long long *counts,
+                     unsigned long long *sums3, void *stream) {
+    if (!labels || !counts || !sums3 || nz <= 0 || ny <= 0 || nx <= 0 || n_labels < 2) return PM_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    // counts[0] doubles as the out-of-range flag word (label 0 is background and never accumulated)
+    if (hipMemsetAsync(counts, 0, sizeof(unsigned long long) * (size_t)n_labels, s) != hipSuccess) return pm::launch_status();
+    if (hipMemsetAsync(sums3, 0, sizeof(unsigned long long) * 3 * (size_t)n_labels, s) != hipSuccess) return pm::launch_status();
+    const long long total = (long long)nz * ny * ((nx + pm::LM_RUN - 1) / pm::LM_RUN);
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return PM_ERR_INVALID_ARG;
+    pm::label_moments_kernel<<<(unsigned int)blocks, 256, 0, s>>>(labels, nz, ny, nx, n_labels, counts, sums3, (int *)counts);
+    return pm::launch_status();
+}
+
+}  // extern "C"

@@ -95,8 +95,9 @@ __device__ void jacobi3(double a[3][3], double v[3][3]) {
     }
 }
 
+// ncomp = 1: first axis (out[3]); ncomp = 3: all axes by decreasing variance (out[9], row-major)
 __global__ __launch_bounds__(STAT_THREADS) void pca_axis_kernel(const double *__restrict__ xyz, int n,
-                                                                double *__restrict__ out3) {
+                                                                double *__restrict__ out3, int ncomp) {
     __shared__ double scratch[STAT_THREADS / 64];
     __shared__ double mean[3];
     for (int c = 0; c < 3; ++c) {
@@ -120,18 +121,23 @@ __global__ __launch_bounds__(STAT_THREADS) void pca_axis_kernel(const double *__
         double a[3][3] = {{c00 * inv, c01 * inv, c02 * inv}, {c01 * inv, c11 * inv, c12 * inv}, {c02 * inv, c12 * inv, c22 * inv}};
         double v[3][3];
         jacobi3(a, v);
-        int best = 0;
-        if (a[1][1] > a[best][best]) best = 1;
-        if (a[2][2] > a[best][best]) best = 2;
-        double e0 = v[0][best], e1 = v[1][best], e2 = v[2][best];
-        double nrm = __builtin_sqrt((e0 * e0 + e1 * e1) + e2 * e2);
-        e0 /= nrm; e1 /= nrm; e2 /= nrm;
-        // svd_flip(u_based_decision=False): the entry of largest magnitude is made positive
-        double big = e0;
-        if (__builtin_fabs(e1) > __builtin_fabs(big)) big = e1;
-        if (__builtin_fabs(e2) > __builtin_fabs(big)) big = e2;
-        if (big < 0.0) { e0 = -e0; e1 = -e1; e2 = -e2; }
-        out3[0] = e0; out3[1] = e1; out3[2] = e2;
+        // eigenvalues on the diagonal of a, eigenvectors in the columns of v; order by decreasing eigenvalue
+        int order[3] = {0, 1, 2};
+        for (int i = 0; i < 2; ++i)
+            for (int j = i + 1; j < 3; ++j)
+                if (a[order[j]][order[j]] > a[order[i]][order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+        for (int c = 0; c < ncomp; ++c) {
+            const int col = order[c];
+            double e0 = v[0][col], e1 = v[1][col], e2 = v[2][col];
+            double nrm = __builtin_sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+            e0 /= nrm; e1 /= nrm; e2 /= nrm;
+            // svd_flip(u_based_decision=False): the entry of largest magnitude is made positive
+            double big = e0;
+            if (__builtin_fabs(e1) > __builtin_fabs(big)) big = e1;
+            if (__builtin_fabs(e2) > __builtin_fabs(big)) big = e2;
+            if (big < 0.0) { e0 = -e0; e1 = -e1; e2 = -e2; }
+            out3[3 * c] = e0; out3[3 * c + 1] = e1; out3[3 * c + 2] = e2;
+        }
     }
 }
 
@@ -167,7 +173,13 @@ size_t pm_pca_axis_workspace(int) { return 0; }
 
 int pm_pca_axis(const double *xyz, int n, double *out3, void *, size_t, void *stream) {
     if (!xyz || !out3 || n < 2) return PM_ERR_INVALID_ARG;
-    pm::pca_axis_kernel<<<1, pm::STAT_THREADS, 0, (hipStream_t)stream>>>(xyz, n, out3);
+    pm::pca_axis_kernel<<<1, pm::STAT_THREADS, 0, (hipStream_t)stream>>>(xyz, n, out3, 1);
+    return pm::launch_status();
+}
+
+int pm_pca_components(const double *xyz, int n, double *out9, void *stream) {
+    if (!xyz || !out9 || n < 2) return PM_ERR_INVALID_ARG;
+    pm::pca_axis_kernel<<<1, pm::STAT_THREADS, 0, (hipStream_t)stream>>>(xyz, n, out9, 3);
     return pm::launch_status();
 }
 

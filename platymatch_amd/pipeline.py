@@ -209,6 +209,17 @@ def icp_sharded(be, moved, fix, iters, group=None):
     return A_icp.reshape(4, 4), res
 
 
+def pca_alignment(moving, fixed):
+    """The widget's PCA-only branch (_dock_widget.py:722-731): sklearn PCA(3).components_ of each (centred) cloud
+    -> (moving_transform 3 x 3, fixed_transform 3 x 3), exported by io.save_pca_transforms."""
+    be = GpuBackend()
+    mt = be.K.pca_components(be.cloud(moving))
+    ft = be.K.pca_components(be.cloud(fixed))
+    if nat.is_torch(moving):
+        return mt, ft
+    return mt.cpu().numpy(), ft.cpu().numpy()
+
+
 def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
                        ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, group=None,
                        backend=None):

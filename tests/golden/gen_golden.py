@@ -286,7 +286,86 @@ def micro(ref):
     return out
 
 
-ALL = ["micro", "synth128", "synth96x128", "insitu02_identity", "insitu02_affine", "insitu04_affine"]
+def next_rows(ref):
+    """Known answers for the SURVEY.md §8f rows: sklearn PCA components, the evaluation metrics (scipy cdist +
+    linear_sum_assignment in the call order of _dock_widget.py:1030-1080 — the method itself lives in a Qt class and cannot
+    be imported) and the label-image centroid loop (_dock_widget.py:497-521)."""
+    sc_mod, ft, at, icp_mod, utils = ref
+    from scipy.optimize import linear_sum_assignment
+    from scipy.spatial.distance import cdist
+    from sklearn.decomposition import PCA
+    out = {}
+    for tag, asset in (("02", "02-insitu.csv"), ("04", "04-insitu.csv")):
+        X = load_asset(asset)
+        out["pca_cloud_" + tag] = X
+        out["pca_components_" + tag] = PCA(n_components=3).fit((X - utils.get_centroid(X, transposed=False)).transpose()).components_
+    # evaluation metrics on a noisy synthetic pair with ids
+    rng, mv = synth_cloud(220, 3)
+    T1 = A_GT.copy()
+    T1[3] = [0, 0, 0, 1]
+    th = 0.01
+    T2 = np.array([[np.cos(th), -np.sin(th), 0, 0.4], [np.sin(th), np.cos(th), 0, -0.3], [0, 0, 1, 0.2], [0, 0, 0, 1.0]])
+    fx_all = at.apply_affine_transform(at.apply_affine_transform(mv, T1), T2) + rng.normal(scale=2.5, size=mv.shape)
+    perm = rng.permutation(220)[:200]
+    fx = np.ascontiguousarray(fx_all[:, perm])
+    m_ids = np.arange(1000, 1220)
+    f_ids = (np.arange(5000, 5220))[perm]
+    kp_sel = rng.choice(200, 14, replace=False)
+    kp_ids = np.arange(1, 15)
+    m_kp = mv[:, perm[kp_sel]] + rng.normal(scale=1.0, size=(3, 14))
+    f_kp = fx[:, kp_sel] + rng.normal(scale=1.0, size=(3, 14))
+    f_kp_ids = kp_ids.copy()
+    f_kp_ids[-2:] = [99, 98]                                   # two keypoints without a partner
+    out.update(ev_moving=mv, ev_fixed=fx, ev_moving_ids=m_ids, ev_fixed_ids=f_ids, ev_moving_kp=m_kp, ev_fixed_kp=f_kp,
+               ev_moving_kp_ids=kp_ids, ev_fixed_kp_ids=f_kp_ids, ev_T1=T1, ev_T2=T2)
+    r, c = linear_sum_assignment(cdist(m_kp.transpose(), mv.transpose()))
+    md = {kp_ids[i]: m_ids[c[i]] for i in r}
+    r, c = linear_sum_assignment(cdist(f_kp.transpose(), fx.transpose()))
+    fd = {f_kp_ids[i]: f_ids[c[i]] for i in r}
+    moved = at.apply_affine_transform(at.apply_affine_transform(mv, T1), T2)
+    cost = cdist(moved.transpose(), fx.transpose())
+    ri, ci = linear_sum_assignment(cost)
+    row_ids, col_ids = m_ids[ri], f_ids[ci]
+    hits = 0
+    for key in md.keys():
+        if key in fd.keys():
+            got = col_ids[np.where(row_ids == md[key])]
+            if got.size == 1 and got[0] == fd[key]:
+                hits += 1
+    out["ev_accuracy"] = np.float64(hits / len(fd.keys()))
+    tmk = at.apply_affine_transform(m_kp, np.matmul(T2, T1))
+    dist = 0
+    for i in range(tmk.shape[1]):
+        dist += np.linalg.norm([f_kp.transpose()[np.where(f_kp_ids == kp_ids[i]), :] - tmk.transpose()[i, :]])
+    out["ev_registration_error"] = np.float64(dist / len(md.keys()))
+    out["ev_cdist_rows"] = cost[::20]
+    out["ev_lsa_cols"] = ci.astype(np.int32)
+    # label image: ellipsoids with non-contiguous ids, touching the borders, one voxel-sized label
+    lab = np.zeros((40, 48, 56), dtype=np.uint16)
+    zz, yy, xx = np.meshgrid(np.arange(40), np.arange(48), np.arange(56), indexing="ij")
+    lid = 3
+    for _ in range(30):
+        c = rng.uniform([0, 0, 0], [40, 48, 56])
+        rad = rng.uniform(2, 6, size=3)
+        mask = ((zz - c[0]) / rad[0]) ** 2 + ((yy - c[1]) / rad[1]) ** 2 + ((xx - c[2]) / rad[2]) ** 2 <= 1
+        lab[mask] = lid
+        lid += int(rng.integers(1, 40))
+    lab[39, 47, 55] = 60000
+    out["lab_image"] = lab
+    ids = np.unique(lab)
+    ids = ids[ids != 0]
+    cents, sizes = [], []
+    for i in ids:
+        z, y, x = np.where(lab == i)
+        cents.append([np.mean(z), np.mean(y), np.mean(x)])
+        sizes.append(float(2.0) * len(z))
+    out["lab_ids"] = ids
+    out["lab_centroids"] = np.asarray(cents).transpose()
+    out["lab_sizes_aniso2"] = np.asarray(sizes)
+    return out
+
+
+ALL = ["next_rows", "micro", "synth128", "synth96x128", "insitu02_identity", "insitu02_affine", "insitu04_affine"]
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or ALL
@@ -298,6 +377,8 @@ if __name__ == "__main__":
         t0 = time.time()
         if name == "micro":
             res = micro(ref)
+        elif name == "next_rows":
+            res = next_rows(ref)
         else:
             res, a_gt = scenario(ref, name)
             res["A_gt"] = a_gt

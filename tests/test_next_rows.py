@@ -1,0 +1,96 @@
+"""SURVEY.md §8f rows widened into so far: PCA-only alignment, evaluation metrics, label-image centroids.
+CPU part: the oracle against reference-generated known answers (tests/golden/next_rows.npz).
+GPU part (-m gpu): the HIP path against the oracle and the same known answers."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+@pytest.fixture(scope="module")
+def nx():
+    return load_golden("next_rows")
+
+
+def metrics_args(d):
+    return (d["ev_moving_kp"], d["ev_moving_kp_ids"], d["ev_moving"], d["ev_moving_ids"], d["ev_fixed_kp"], d["ev_fixed_kp_ids"],
+            d["ev_fixed"], d["ev_fixed_ids"], d["ev_T1"], d["ev_T2"])
+
+
+# ------------------------------------------------------------------------------------------------ oracle (CPU)
+def test_oracle_pca_components(oracle, nx):
+    for t in ("02", "04"):
+        assert np.abs(oracle.pca_components(nx["pca_cloud_" + t].T) - nx["pca_components_" + t]).max() < 1e-12   # sklearn PCA
+
+
+def test_oracle_metrics_and_cdist(oracle, nx):
+    acc, err = oracle.calculate_metrics(*metrics_args(nx))
+    assert acc == nx["ev_accuracy"] and err == nx["ev_registration_error"]
+    moved = oracle.apply_affine_transform(oracle.apply_affine_transform(nx["ev_moving"], nx["ev_T1"]), nx["ev_T2"])
+    assert np.array_equal(oracle.cdist(moved, nx["ev_fixed"])[::20], nx["ev_cdist_rows"])
+
+
+def test_oracle_label_centroids(oracle, nx):
+    c, s, ids = oracle.label_centroids(nx["lab_image"], 2.0)
+    assert np.array_equal(c, nx["lab_centroids"]) and np.array_equal(s, nx["lab_sizes_aniso2"]) and np.array_equal(ids, nx["lab_ids"])
+    assert oracle.ransac_error_from_sizes([], [1.0]) == 16
+    assert oracle.ransac_error_from_sizes([8.0, 8.0], [27.0]) == 0.5 * (8.0 ** (1 / 3) + 27.0 ** (1 / 3))
+
+
+# ------------------------------------------------------------------------------------------------ HIP path (GPU)
+@pytest.mark.gpu
+def test_gpu_pca_alignment(oracle, nx):
+    from platymatch_amd.pipeline import pca_alignment
+    mt, ft = pca_alignment(nx["pca_cloud_02"], nx["pca_cloud_04"])
+    assert np.abs(mt - nx["pca_components_02"]).max() < 1e-11 and np.abs(ft - nx["pca_components_04"]).max() < 1e-11
+    assert mt.shape == (3, 3) and np.allclose(mt @ mt.T, np.eye(3), atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_gpu_cdist_bit_exact_and_ragged(oracle, nx):
+    from platymatch_amd import _kernels as K, _native as nat
+    from platymatch_amd.evaluate_metrics import cdist
+    rng = np.random.default_rng(4)
+    for n, m in ((1, 1), (14, 200), (33, 513), (200, 200), (1000, 1025), (31, 7)):
+        a, b = rng.normal(size=(3, n)) * 80, rng.normal(size=(3, m)) * 80
+        assert np.array_equal(cdist(a, b), oracle.cdist(a, b))                   # scipy's operation order, correctly rounded sqrt
+    moved = oracle.apply_affine_transform(oracle.apply_affine_transform(nx["ev_moving"], nx["ev_T1"]), nx["ev_T2"])
+    assert np.array_equal(cdist(moved, nx["ev_fixed"])[::20], nx["ev_cdist_rows"])
+    # odd leading dimension / unaligned views take the 8-byte store path and give the same numbers
+    import torch
+    a, b = nat.to_dev(rng.normal(size=(3, 50))), nat.to_dev(rng.normal(size=(3, 77)))
+    big = torch.full((50, 101), -1.0, dtype=torch.float64, device=a.device)
+    K.cdist(a, b, out=big[:, 3:80])
+    assert torch.equal(big[:, 3:80], K.cdist(a, b)) and (big[:, :3] == -1).all() and (big[:, 80:] == -1).all()
+
+
+@pytest.mark.gpu
+def test_gpu_metrics(oracle, nx):
+    from platymatch_amd.evaluate_metrics import calculate_metrics
+    acc, err = calculate_metrics(*metrics_args(nx))
+    assert acc == nx["ev_accuracy"]
+    assert abs(err - nx["ev_registration_error"]) < 1e-12 * nx["ev_registration_error"]
+    acc1, _ = calculate_metrics(*metrics_args(nx)[:8], np.matmul(nx["ev_T2"], nx["ev_T1"]))    # T2 defaults to identity
+    assert 0.0 <= acc1 <= 1.0
+
+
+@pytest.mark.gpu
+def test_gpu_label_centroids(oracle, nx):
+    from platymatch_amd.label_image import label_centroids, ransac_error_from_sizes
+    c, s, ids = label_centroids(nx["lab_image"], 2.0)
+    assert np.array_equal(c, nx["lab_centroids"]) and np.array_equal(s, nx["lab_sizes_aniso2"]) and np.array_equal(ids, nx["lab_ids"])
+    rng = np.random.default_rng(9)
+    vol = np.zeros((33, 65, 130), dtype=np.int32)                              # ragged row length, labels filling whole rows
+    vol[5:20, 10:40, :] = 7
+    vol[0, 0, :] = 2
+    vol[32, 64, 129] = 900
+    vol[10:12, 50:60, 100:130] = rng.integers(0, 5, size=(2, 10, 30)) * 11      # salt-and-pepper labels 11..44
+    oc, osz, oid = oracle.label_centroids(vol, 1.0)
+    gc, gsz, gid = label_centroids(vol, 1.0)
+    assert np.array_equal(gc, oc) and np.array_equal(gsz, osz) and np.array_equal(gid, oid)
+    assert ransac_error_from_sizes([], []) == 16
+    assert ransac_error_from_sizes(gsz, osz) == oracle.ransac_error_from_sizes(gsz, osz)
+    with pytest.raises(ValueError):
+        label_centroids(np.zeros((4, 4)), 1.0)
+    with pytest.raises(ValueError):
+        label_centroids(np.full((2, 2, 2), -1, dtype=np.int32), 1.0)
