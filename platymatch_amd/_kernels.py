@@ -33,12 +33,13 @@ def _vec(x, n, name):
     return x
 
 
-def _idx(x, n, hi, name):
-    """int32 GPU index vector of length n with values in [0, hi) — range-checked here, not in the kernel."""
+def _idx(x, n, hi, name, trusted=False):
+    """int32 GPU index vector of length n with values in [0, hi) — range-checked here, not in the kernel.
+    `trusted`: the vector was produced by one of our own kernels (e.g. icp_nn); skip the two read-backs."""
     torch = _t()
     if not (nat.is_torch(x) and x.is_cuda and x.dtype == torch.int32 and x.is_contiguous() and x.numel() == n):
         raise ValueError("%s must be a contiguous int32 GPU tensor with %d elements" % (name, n))
-    if n and (int(x.min()) < 0 or int(x.max()) >= hi):
+    if n and not trusted and (int(x.min()) < 0 or int(x.max()) >= hi):
         raise IndexError("%s has entries outside [0, %d)" % (name, hi))
     return x
 
@@ -289,32 +290,33 @@ def icp_nn(mov, fix, want_dist=True):
     return nn, dist
 
 
-def icp_accumulate(mov, fix, nn, origin6):
+def icp_accumulate(mov, fix, nn, origin6, out=None, nn_trusted=False):
+    """-> sums [24] (written into `out` if given).  nn_trusted: nn comes straight from icp_nn (no range read-back)."""
     torch = _t()
     mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
     n = mov.shape[1]
-    nn = None if nn is None else _idx(nn, n, fix.shape[1], "nn")
+    nn = None if nn is None else _idx(nn, n, fix.shape[1], "nn", trusted=nn_trusted)
     origin6 = _vec(origin6, 6, "origin")
     lib = nat.load()
     ws = nat.workspace(lib.pm_icp_accumulate_workspace(n), mov.device)
-    sums = torch.empty(ICP_NSUMS, dtype=torch.float64, device=mov.device)
+    sums = torch.empty(ICP_NSUMS, dtype=torch.float64, device=mov.device) if out is None else _vec(out, ICP_NSUMS, "out")
     check(lib.pm_icp_accumulate(ptr(mov), n, ptr(fix), fix.shape[1], ptr(nn), ptr(origin6), ptr(sums), ptr(ws), ws.numel(),
                                 nat.stream_ptr()))
     return sums
 
 
-def icp_update(sums, origin6, mov, fix, nn, A_icp):
+def icp_update(sums, origin6, mov, fix, nn, A_icp, parts_out=None, nn_trusted=False):
     """In place: mov <- A_est mov, A_icp <- A_est A_icp.  -> (A_est [4,4], residual_parts [2] = (sum, n))."""
     torch = _t()
     mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
     n = mov.shape[1]
-    nn = None if nn is None else _idx(nn, n, fix.shape[1], "nn")
+    nn = None if nn is None else _idx(nn, n, fix.shape[1], "nn", trusted=nn_trusted)
     sums, origin6 = _vec(sums, ICP_NSUMS, "sums"), _vec(origin6, 6, "origin")
     A_icp = _vec(A_icp, 16, "A_icp")
     lib = nat.load()
     ws = nat.workspace(lib.pm_icp_update_workspace(n), mov.device)
     A_est = torch.empty((4, 4), dtype=torch.float64, device=mov.device)
-    parts = torch.empty(2, dtype=torch.float64, device=mov.device)
+    parts = torch.empty(2, dtype=torch.float64, device=mov.device) if parts_out is None else _vec(parts_out, 2, "parts_out")
     check(lib.pm_icp_update(ptr(sums), ptr(origin6), ptr(mov), n, ptr(fix), fix.shape[1], ptr(nn), ptr(A_icp), ptr(A_est),
                             ptr(parts), ptr(ws), ws.numel(), nat.stream_ptr()))
     return A_est, parts

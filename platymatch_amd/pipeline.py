@@ -66,11 +66,11 @@ class GpuBackend:
     def icp_nn(self, mov, fix):
         return self.K.icp_nn(mov, fix, want_dist=False)[0]
 
-    def icp_accumulate(self, mov, fix, nn, origin):
-        return self.K.icp_accumulate(mov, fix, nn, origin)
+    def icp_accumulate(self, mov, fix, nn, origin, out=None):
+        return self.K.icp_accumulate(mov, fix, nn, origin, out=out, nn_trusted=True)     # nn is icp_nn's own output
 
-    def icp_update(self, sums, origin, mov, fix, nn, A_icp):
-        return self.K.icp_update(sums, origin, mov, fix, nn, A_icp)
+    def icp_update(self, sums, origin, mov, fix, nn, A_icp, parts_out=None):
+        return self.K.icp_update(sums, origin, mov, fix, nn, A_icp, parts_out=parts_out, nn_trusted=True)
 
 
 def shard_bounds(n, world):
@@ -186,25 +186,28 @@ def icp_sharded(be, moved, fix, iters, group=None):
     # One collective per iteration: the 24 moment sums of this iteration travel together with the residual
     # parts of the previous one.  Every rank reduces the same gathered [G, 26] block with the same kernel, so all
     # ranks hold bit-identical sums and solve the identical 4x4 — they stay in lockstep without a broadcast.
-    residuals = []
-    rp = torch.zeros(2, dtype=torch.float64, device=moved.device)
+    mine = torch.zeros(26, dtype=torch.float64, device=moved.device)       # [0:24] moment sums, [24:26] residual parts
+    sums_view, rp_view = mine[:24], mine[24:]
+    gathered = [torch.empty_like(mine) for _ in range(world)] if world > 1 else None
+    res_buf = torch.zeros((max(iters, 1), 2), dtype=torch.float64, device=moved.device)
     for it in range(iters + (1 if world > 1 and iters else 0)):
         last = it == iters
         if not last:
             nn = be.icp_nn(loc, fix)
-            sums = be.icp_accumulate(loc, fix, nn, origin)
+            be.icp_accumulate(loc, fix, nn, origin, out=sums_view)
         if world > 1:
-            mine = torch.cat([sums, rp])
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine, group=group)
-            total = torch.stack(parts).sum(0)
-            sums = total[:24].contiguous()
+            dist.all_gather(gathered, mine, group=group)
+            total = torch.stack(gathered).sum(0)
             if it > 0:
-                residuals.append(total[24] / total[25])
+                res_buf[it - 1].copy_(total[24:])
+            sums = total[:24]
+        else:
+            sums = sums_view
         if not last:
-            _, rp = be.icp_update(sums, origin, loc, fix, nn, A_icp)
+            be.icp_update(sums, origin, loc, fix, nn, A_icp, parts_out=rp_view)
             if world == 1:
-                residuals.append(rp[0] / rp[1])
+                res_buf[it].copy_(rp_view)
+    residuals = list((res_buf[:iters, 0] / res_buf[:iters, 1]).unbind(0)) if iters else []
     res = torch.stack(residuals) if residuals else torch.empty(0, dtype=torch.float64, device=moved.device)
     return A_icp.reshape(4, 4), res
 

@@ -19,6 +19,8 @@ def gpu():
     """Fails (never skips) if the native library or the GPU is missing: the HIP path is the only path."""
     import torch
     from platymatch_amd import _kernels, _native
+    from platymatch_amd.build import build_native
+    build_native()          # no-op when the in-tree library is current; compiles it with hipcc otherwise
     _native.load()
     assert torch.cuda.is_available(), "gpu-marked tests need a ROCm device"
 

@@ -57,7 +57,7 @@ class OracleBackend:
     def icp_nn(self, mov, fix):
         return torch.as_tensor(self.o.nn_argmin(mov.numpy(), fix.numpy())[0])
 
-    def icp_accumulate(self, mov, fix, nn, origin):
+    def icp_accumulate(self, mov, fix, nn, origin, out=None):
         o = origin.numpy()
         a = mov.numpy() - o[:3, None]
         f = fix.numpy()[:, nn.numpy()] - o[3:, None]
@@ -68,9 +68,12 @@ class OracleBackend:
         s[7:13] = [aa[0, 0], aa[0, 1], aa[0, 2], aa[1, 1], aa[1, 2], aa[2, 2]]
         s[13:22] = (f @ a.T).ravel()
         s[22] = (f * f).sum()
+        if out is not None:
+            out.copy_(torch.as_tensor(s))
+            return out
         return torch.as_tensor(s)
 
-    def icp_update(self, sums, origin, mov, fix, nn, A_icp):
+    def icp_update(self, sums, origin, mov, fix, nn, A_icp, parts_out=None):
         s, o = sums.numpy(), origin.numpy()
         n = s[0]
         mb, fb = s[1:4] / n, s[4:7] / n
@@ -84,7 +87,11 @@ class OracleBackend:
         mov.copy_(torch.as_tensor(new))
         A_icp.copy_(torch.as_tensor((A @ A_icp.reshape(4, 4).numpy()).ravel()))
         res = np.linalg.norm(new - fix.numpy()[:, nn.numpy()], axis=0).sum()
-        return torch.as_tensor(A), torch.as_tensor(np.array([res, float(new.shape[1])]))
+        parts = torch.as_tensor(np.array([res, float(new.shape[1])]))
+        if parts_out is not None:
+            parts_out.copy_(parts)
+            parts = parts_out
+        return torch.as_tensor(A), parts
 
 
 def _free_port():
