@@ -178,10 +178,21 @@ int pm_fit_affine(const double *mov, int n, const double *fix, int n_fix, const 
 
 /* perform_icp's correspondence step (perform_icp.py:15-16): nn[i] = argmin_j
  * sqrt(sum((fix[:,j]-mov[:,i])**2)), first index on ties (scipy distance_matrix + np.argmin);
- * dist[i] (may be NULL) = that distance.  The N x M matrix is never materialised. */
+ * dist[i] (may be NULL) = that distance.  The N x M matrix is never materialised.
+ * pm_icp_nn bins the fixed cloud into a uniform grid and searches only the cells around each moving point
+ * (exactly the brute-force answer, O(N) per call instead of O(N*M)); pm_icp_grid_build / pm_icp_grid_nn expose
+ * the two halves so that a loop over a constant fixed cloud (ICP) bins it once; pm_icp_nn_brute evaluates every
+ * pair (one wave-uniform fixed point against 128 moving points per wave) and is kept as the O(N*M) yardstick. */
 size_t pm_icp_nn_workspace(int n, int m);
 int pm_icp_nn(const double *mov, int n, const double *fix, int m, int32_t *nn, double *dist,
               void *ws, size_t ws_bytes, void *stream);
+size_t pm_icp_grid_workspace(int m);
+int pm_icp_grid_build(const double *fix, int m, void *grid, size_t grid_bytes, void *stream);
+int pm_icp_grid_nn(const double *mov, int n, int m, const void *grid, size_t grid_bytes, int32_t *nn,
+                   double *dist, void *stream);
+size_t pm_icp_nn_brute_workspace(int n, int m);
+int pm_icp_nn_brute(const double *mov, int n, const double *fix, int m, int32_t *nn, double *dist,
+                    void *ws, size_t ws_bytes, void *stream);
 
 /* Partial sums of one rank's block for the affine refit: sums[PM_ICP_NSUMS] =
  * { n, sum m(3), sum f(3), sum m m^T (6: 00 01 02 11 12 22), sum f m^T (9 row-major), sum |f|^2, 0 } with

@@ -278,15 +278,34 @@ def fit_affine(mov, fix, nn=None):
     return A
 
 
-def icp_nn(mov, fix, want_dist=True):
+def icp_grid(fix):
+    """Bin a fixed cloud for repeated nearest-neighbour queries -> opaque workspace tensor (valid while `fix` is unchanged)."""
+    fix = _cloud(fix, "fixed")
+    lib = nat.load()
+    ws = nat.workspace(lib.pm_icp_grid_workspace(fix.shape[1]), fix.device)
+    check(lib.pm_icp_grid_build(ptr(fix), fix.shape[1], ptr(ws), ws.numel(), nat.stream_ptr()))
+    return ws
+
+
+def icp_nn(mov, fix, want_dist=True, grid=None, brute=False):
+    """Nearest fixed point of every moving point -> (nn [n] int32, dist [n] float64 or None).
+    grid: workspace from icp_grid(fix) to skip re-binning; brute=True evaluates all N*M pairs (same answer)."""
     torch = _t()
     mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
     n, m = mov.shape[1], fix.shape[1]
     lib = nat.load()
-    ws = nat.workspace(lib.pm_icp_nn_workspace(n, m), mov.device)
     nn = torch.empty(n, dtype=torch.int32, device=mov.device)
     dist = torch.empty(n, dtype=torch.float64, device=mov.device) if want_dist else None
-    check(lib.pm_icp_nn(ptr(mov), n, ptr(fix), m, ptr(nn), ptr(dist), ptr(ws), ws.numel(), nat.stream_ptr()))
+    if brute:
+        ws = nat.workspace(lib.pm_icp_nn_brute_workspace(n, m), mov.device)
+        check(lib.pm_icp_nn_brute(ptr(mov), n, ptr(fix), m, ptr(nn), ptr(dist), ptr(ws), ws.numel(), nat.stream_ptr()))
+    elif grid is not None:
+        if not (nat.is_torch(grid) and grid.is_cuda and grid.numel() >= lib.pm_icp_grid_workspace(m)):
+            raise ValueError("grid must be the tensor icp_grid(fix) returned for this fixed cloud")
+        check(lib.pm_icp_grid_nn(ptr(mov), n, m, ptr(grid), grid.numel(), ptr(nn), ptr(dist), nat.stream_ptr()))
+    else:
+        ws = nat.workspace(lib.pm_icp_nn_workspace(n, m), mov.device)
+        check(lib.pm_icp_nn(ptr(mov), n, ptr(fix), m, ptr(nn), ptr(dist), ptr(ws), ws.numel(), nat.stream_ptr()))
     return nn, dist
 
 

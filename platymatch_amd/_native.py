@@ -51,6 +51,11 @@ SIGNATURES = {
     "pm_fit_affine": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_icp_nn_workspace": (_c_size_t, [_c_int, _c_int]),
     "pm_icp_nn": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_icp_grid_workspace": (_c_size_t, [_c_int]),
+    "pm_icp_grid_build": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_icp_grid_nn": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_icp_nn_brute_workspace": (_c_size_t, [_c_int, _c_int]),
+    "pm_icp_nn_brute": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_icp_accumulate_workspace": (_c_size_t, [_c_int]),
     "pm_icp_accumulate": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                    _c_size_t, _c_void_p]),

@@ -16,6 +16,10 @@
 namespace pm {
 
 int accumulate(const double *, int, const double *, int, const int32_t *, const double *, double *, double *, hipStream_t);
+// uniform-grid search (pm_icp_grid.hip): same results as the brute-force kernels below, O(N) instead of O(N*M) per iteration
+size_t grid_ws_bytes(int m);
+int grid_build(const double *fix, int m, void *ws, hipStream_t s);
+int grid_query(const double *mov, int n, int m, const void *ws, int32_t *nn, double *dist, hipStream_t s);
 int update(const double *, const double *, const double *, double *, int, const double *, int, const int32_t *, double *,
            double *, double *, double *, double *, hipStream_t);
 
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(NN_THREADS) void nn_kernel(const double *__restrict
     const double b0 = mov[c1], b1 = mov[(size_t)n + c1], b2 = mov[2 * (size_t)n + c1];
     const int jb = blockIdx.y * slice_len, je = jb + slice_len;
 
-    NnBest A = {INFINITY, INFINITY, 0x7fffffff}, B = {INFINITY, INFINITY, 0x7fffffff};
+    NnBest A = {INFINITY, INFINITY, 0}, B = {INFINITY, INFINITY, 0};   // index 0 if nothing ever wins (all-NaN row: np.argmin gives 0)
     double4 cur[NN_UNROLL];
 #pragma unroll
     for (int u = 0; u < NN_UNROLL; ++u) cur[u] = fixp[jb + u];
@@ -179,7 +183,7 @@ struct IcpWs {
 inline IcpWs icp_layout(int n, int m) {
     IcpWs w;
     size_t o = 0;
-    w.nn_ws = o; o += align_up(nn_ws_bytes(n, m), 256);
+    w.nn_ws = o; o += align_up(grid_ws_bytes(m), 256);
     w.nn = o; o += align_up((size_t)n * sizeof(int32_t), 256);
     w.acc_ws = o; o += align_up(pm_icp_accumulate_workspace(n), 256);
     w.sums = o; o += 256;
@@ -192,13 +196,39 @@ inline IcpWs icp_layout(int n, int m) {
 
 extern "C" {
 
-size_t pm_icp_nn_workspace(int n, int m) { return (n > 0 && m > 0) ? pm::nn_ws_bytes(n, m) : 0; }
+size_t pm_icp_nn_brute_workspace(int n, int m) { return (n > 0 && m > 0) ? pm::nn_ws_bytes(n, m) : 0; }
+
+int pm_icp_nn_brute(const double *mov, int n, const double *fix, int m, int32_t *nn, double *dist, void *ws, size_t ws_bytes,
+                    void *stream) {
+    if (!mov || !fix || !nn || n <= 0 || m <= 0) return PM_ERR_INVALID_ARG;
+    if (!ws || ws_bytes < pm_icp_nn_brute_workspace(n, m)) return PM_ERR_WORKSPACE;
+    return pm::nn_search(mov, n, fix, m, nn, dist, ws, (hipStream_t)stream);
+}
+
+size_t pm_icp_grid_workspace(int m) { return m > 0 ? pm::grid_ws_bytes(m) : 0; }
+
+int pm_icp_grid_build(const double *fix, int m, void *grid, size_t grid_bytes, void *stream) {
+    if (!fix || m <= 0) return PM_ERR_INVALID_ARG;
+    if (!grid || grid_bytes < pm_icp_grid_workspace(m)) return PM_ERR_WORKSPACE;
+    return pm::grid_build(fix, m, grid, (hipStream_t)stream);
+}
+
+int pm_icp_grid_nn(const double *mov, int n, int m, const void *grid, size_t grid_bytes, int32_t *nn, double *dist,
+                   void *stream) {
+    if (!mov || !nn || n <= 0 || m <= 0) return PM_ERR_INVALID_ARG;
+    if (!grid || grid_bytes < pm_icp_grid_workspace(m)) return PM_ERR_WORKSPACE;
+    return pm::grid_query(mov, n, m, grid, nn, dist, (hipStream_t)stream);
+}
+
+size_t pm_icp_nn_workspace(int n, int m) { return (n > 0 && m > 0) ? pm::grid_ws_bytes(m) : 0; }
 
 int pm_icp_nn(const double *mov, int n, const double *fix, int m, int32_t *nn, double *dist, void *ws, size_t ws_bytes,
               void *stream) {
     if (!mov || !fix || !nn || n <= 0 || m <= 0) return PM_ERR_INVALID_ARG;
     if (!ws || ws_bytes < pm_icp_nn_workspace(n, m)) return PM_ERR_WORKSPACE;
-    return pm::nn_search(mov, n, fix, m, nn, dist, ws, (hipStream_t)stream);
+    int rc = pm::grid_build(fix, m, ws, (hipStream_t)stream);
+    if (rc != PM_OK) return rc;
+    return pm::grid_query(mov, n, m, ws, nn, dist, (hipStream_t)stream);
 }
 
 size_t pm_icp_workspace(int n, int m) { return (n > 0 && m > 0) ? pm::icp_layout(n, m).total : 0; }
@@ -215,9 +245,13 @@ int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_ic
     double *sums = (double *)(base + L.sums);
     double *origin = (double *)(base + L.origin);
     pm::icp_init_kernel<<<1, 64, 0, s>>>(fix, m, origin, A_icp16);
+    if (iters > 0) {                                   // the fixed cloud never changes: bin it once
+        int rc = pm::grid_build(fix, m, base + L.nn_ws, s);
+        if (rc != PM_OK) return rc;
+    }
     for (int it = 0; it < iters; ++it) {
         int32_t *nn = nn_all ? nn_all + (size_t)it * n : nn_buf;
-        int rc = pm::nn_search(mov, n, fix, m, nn, nullptr, base + L.nn_ws, s, it > 0);
+        int rc = pm::grid_query(mov, n, m, base + L.nn_ws, nn, nullptr, s);
         if (rc != PM_OK) return rc;
         rc = pm::accumulate(mov, n, fix, m, nn, origin, sums, acc_ws, s);
         if (rc != PM_OK) return rc;

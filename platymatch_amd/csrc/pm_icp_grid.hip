@@ -1,0 +1,274 @@
+// pm_icp_grid.hip — exact nearest-neighbour search of perform_icp's correspondence step on a uniform grid.
+// Reference: perform_icp.py:15-16 — scipy distance_matrix (N x M) + np.argmin(axis=1).
+//
+// The reference (and pm_icp_nn_brute) look at all N*M pairs.  The fixed cloud does not change during ICP, so it is
+// binned ONCE per call into a uniform grid (counting sort: cell index, per-cell counts, exclusive scan, scatter) and
+// every iteration then inspects only the cells around each moving point: rings of growing Chebyshev radius r around
+// its home cell until the best distance found is smaller than r*h, the least distance any point in a farther ring can
+// have (h = cell edge; home cells of points outside the grid are clamped, which only makes unexplored points farther).
+// The result is IDENTICAL to the brute-force arg-min — same squared-distance arithmetic ((d0*d0 + d1*d1) + d2*d2,
+// d = fixed - moving), same comparison of ROUNDED square roots, ties to the lowest original index — because every
+// point that could tie or win lies within the explored radius; candidate order does not matter since ties are broken
+// on the stored original index explicitly.  Work per iteration drops from N*M to ~N * (points in ~27 cells).
+#include "pm_common.h"
+
+namespace pm {
+
+constexpr int GR_MAX_DIM = 512;
+// Cells per point.  Nucleus clouds are blobs, not uniform boxes: the bounding box is mostly empty and the core is
+// ~30x denser than the box average, so the grid is sized for ~0.5 points per cell on average (~16 in the core).
+constexpr int GR_CELLS_PER_POINT = 2;
+constexpr int GR_RING_CAP = 3;            // beyond this ring radius a group scans the whole cloud instead (sparse outliers)
+
+struct GridHeader {          // lives at the start of the workspace, written by grid_plan_kernel
+    double lo[3];            // bounding box minimum
+    double h;                // cell edge
+    double inv_h;
+    int g[3];                // cells per axis
+    int ncells;
+};
+
+inline int grid_max_cells(int m) {
+    long c = (long)m * GR_CELLS_PER_POINT + 1;
+    if (c > (1L << 23)) c = 1L << 23;
+    return (int)c;
+}
+
+struct GridWs {
+    size_t header, start, cursor, pts, total;
+};
+
+inline GridWs grid_layout(int m) {
+    GridWs w;
+    size_t o = 0;
+    w.header = o; o += 256;
+    w.start = o; o += align_up(((size_t)grid_max_cells(m) + 1) * sizeof(int), 256);
+    w.cursor = o; o += align_up(((size_t)grid_max_cells(m) + 1) * sizeof(int), 256);
+    w.pts = o; o += align_up((size_t)m * sizeof(double4), 256);
+    w.total = o;
+    return w;
+}
+
+__device__ __forceinline__ int cell_coord(double x, double lo, double inv_h, int g) {
+    const double t = (x - lo) * inv_h;
+    int c = (t >= 0.0) ? ((t < (double)g) ? (int)t : g - 1) : 0;     // clamps points outside the box; NaN -> 0
+    return c;
+}
+
+// one workgroup: bounding box of the fixed cloud, cell edge and grid dimensions (at most max_cells cells)
+__global__ __launch_bounds__(1024) void grid_plan_kernel(const double *__restrict__ fix, int m, int max_cells, GridHeader *hd) {
+    __shared__ double smin[3][16], smax[3][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = 0; c < 3; ++c) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int j = threadIdx.x; j < m; j += 1024) {
+            const double v = fix[(size_t)c * m + j];
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const double a = __shfl_down(lo, off, 64), b = __shfl_down(hi, off, 64);
+            lo = a < lo ? a : lo;
+            hi = b > hi ? b : hi;
+        }
+        if (lane == 0) { smin[c][wave] = lo; smax[c][wave] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double lo[3], len[3];
+        for (int c = 0; c < 3; ++c) {
+            double a = smin[c][0], b = smax[c][0];
+            for (int w = 1; w < 16; ++w) { a = smin[c][w] < a ? smin[c][w] : a; b = smax[c][w] > b ? smax[c][w] : b; }
+            if (!(a <= b)) { a = 0.0; b = 0.0; }                 // NaN-only input: degenerate box
+            lo[c] = a;
+            len[c] = b - a;
+        }
+        // cell edge from the volume (area / length for flat clouds) and the target occupancy
+        double vol = 1.0;
+        int dims = 0;
+        for (int c = 0; c < 3; ++c)
+            if (len[c] > 0.0) { vol *= len[c]; ++dims; }
+        const double target = (double)m * GR_CELLS_PER_POINT;
+        double h = 1.0;
+        if (dims > 0 && target >= 1.0) h = pow(vol / target, 1.0 / dims);
+        if (dims > 0 && !(h > 0.0)) h = fmax(fmax(len[0], len[1]), len[2]);
+        int g[3];
+        for (int it = 0; it < 64; ++it) {
+            long prod = 1;
+            for (int c = 0; c < 3; ++c) {
+                double q = len[c] / h;
+                g[c] = (q < (double)(GR_MAX_DIM - 1)) ? (int)q + 1 : GR_MAX_DIM;
+                if (g[c] < 1) g[c] = 1;
+                prod *= g[c];
+            }
+            if (prod <= max_cells) break;
+            h *= 1.2599210498948732;                             // 2^(1/3): halves the cell count
+        }
+        if ((long)g[0] * g[1] * g[2] > max_cells) { g[0] = g[1] = g[2] = 1; }
+        for (int c = 0; c < 3; ++c) { hd->lo[c] = lo[c]; hd->g[c] = g[c]; }
+        hd->h = h;
+        hd->inv_h = 1.0 / h;
+        hd->ncells = g[0] * g[1] * g[2];
+    }
+}
+
+__device__ __forceinline__ int cell_of(const GridHeader &hd, double x, double y, double z) {
+    const int cx = cell_coord(x, hd.lo[0], hd.inv_h, hd.g[0]);
+    const int cy = cell_coord(y, hd.lo[1], hd.inv_h, hd.g[1]);
+    const int cz = cell_coord(z, hd.lo[2], hd.inv_h, hd.g[2]);
+    return (cz * hd.g[1] + cy) * hd.g[0] + cx;                    // x fastest: a run of x-cells is contiguous in memory
+}
+
+__global__ __launch_bounds__(256) void grid_count_kernel(const double *__restrict__ fix, int m, const GridHeader *__restrict__ hd,
+                                                         int *__restrict__ count) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    atomicAdd(&count[cell_of(*hd, fix[j], fix[(size_t)m + j], fix[2 * (size_t)m + j])], 1);
+}
+
+// exclusive scan of count[0..ncells) into start[0..ncells], one workgroup; cursor <- start
+__global__ __launch_bounds__(1024) void grid_scan_kernel(const GridHeader *__restrict__ hd, int *__restrict__ start, int *__restrict__ cursor) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int n = hd->ncells;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < n) ? start[i] : 0;                    // counts were accumulated in `start`
+        int incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int prefix = carry;
+        for (int w = 0; w < wave; ++w) prefix += wsum[w];
+        const int excl = prefix + incl - v;
+        if (i < n) { start[i] = excl; cursor[i] = excl; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = prefix + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) start[n] = carry;
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const double *__restrict__ fix, int m, const GridHeader *__restrict__ hd,
+                                                           int *__restrict__ cursor, double4 *__restrict__ pts) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const double x = fix[j], y = fix[(size_t)m + j], z = fix[2 * (size_t)m + j];
+    const int pos = atomicAdd(&cursor[cell_of(*hd, x, y, z)], 1);
+    double4 v;
+    v.x = x; v.y = y; v.z = z;
+    v.w = __longlong_as_double((long long)j);                    // original index rides along (exact bit pattern)
+    pts[pos] = v;
+}
+
+// exact "a is a better match than b": smaller rounded root, then smaller original index
+__device__ __forceinline__ bool grid_better(double aS, int aI, double bS, int bI) {
+    if (aS < bS * 0x1.ffffffffffffp-1) return true;               // clearly smaller (roots >= 2 ulp apart)
+    if (!(aS <= bS * 0x1.000000000001p+0)) return false;          // clearly larger, or NaN
+    if (aS == bS) return aI < bI;
+    const double ra = __builtin_sqrt(aS), rb = __builtin_sqrt(bS);
+    return (ra < rb) || (ra == rb && aI < bI);
+}
+
+// GR_LANES lanes cooperate on one moving point: lane l visits the cells l, l + GR_LANES, ... of the current ring's cube
+// (27 cells for rings 0 and 1 together), then the group's candidates are merged with the exact comparator.
+constexpr int GR_LANES = 32;
+
+__global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__ mov, int n, const GridHeader *__restrict__ hdp,
+                                                      const int *__restrict__ start, const double4 *__restrict__ pts,
+                                                      int32_t *__restrict__ nn, double *__restrict__ dist) {
+    const int sub = threadIdx.x & (GR_LANES - 1);
+    const int i = (blockIdx.x * 256 + threadIdx.x) / GR_LANES;
+    const int ic = min(i, n - 1);                                 // surplus groups shadow the last point (no divergent exit before shuffles)
+    const GridHeader hd = *hdp;
+    const double p0 = mov[ic], p1 = mov[(size_t)n + ic], p2 = mov[2 * (size_t)n + ic];
+    const int cx = cell_coord(p0, hd.lo[0], hd.inv_h, hd.g[0]);
+    const int cy = cell_coord(p1, hd.lo[1], hd.inv_h, hd.g[1]);
+    const int cz = cell_coord(p2, hd.lo[2], hd.inv_h, hd.g[2]);
+    const int rmax = max(max(max(cx, hd.g[0] - 1 - cx), max(cy, hd.g[1] - 1 - cy)), max(cz, hd.g[2] - 1 - cz));
+    double bS = INFINITY;
+    int bI = 0x7fffffff;           // "nothing yet": loses every index tie; replaced by 0 at the end if nothing ever matched
+    auto visit = [&](int x, int y, int z) {
+        if (x < 0 || y < 0 || z < 0 || x >= hd.g[0] || y >= hd.g[1] || z >= hd.g[2]) return;
+        const int c = (z * hd.g[1] + y) * hd.g[0] + x;
+        const int q0 = start[c], q1 = start[c + 1];
+        for (int q = q0; q < q1; ++q) {
+            const double4 f = pts[q];
+            const double d0 = f.x - p0, d1 = f.y - p1, d2 = f.z - p2;
+            const double s = (d0 * d0 + d1 * d1) + d2 * d2;
+            const int j = (int)__double_as_longlong(f.w);
+            if (grid_better(s, j, bS, bI)) { bS = s; bI = j; }
+        }
+    };
+    auto merge = [&]() {          // butterfly over the group: afterwards every lane holds the winner
+#pragma unroll
+        for (int off = GR_LANES / 2; off > 0; off >>= 1) {
+            const double oS = __shfl_xor(bS, off, 64);
+            const int oI = __shfl_xor(bI, off, 64);
+            if (grid_better(oS, oI, bS, bI)) { bS = oS; bI = oI; }
+        }
+    };
+    // pass 1: rings 0 and 1 = the 3 x 3 x 3 cube around the home cell, one cell per lane (constant divisors)
+    if (sub < 27) visit(cx + sub % 3 - 1, cy + (sub / 3) % 3 - 1, cz + sub / 9 - 1);
+    merge();
+    int r = 1;
+    // everything not yet visited is farther than r*h (minus the rounding slack of the cell map)
+    while (!(bS < (r * hd.h * (1.0 - 1e-6)) * (r * hd.h * (1.0 - 1e-6))) && r < rmax) {
+        ++r;
+        if (r > GR_RING_CAP) {                                  // sparse neighbourhood: scan every point (always exact)
+            const int m_all = start[hd.ncells];
+            for (int q = sub; q < m_all; q += GR_LANES) {
+                const double4 f = pts[q];
+                const double d0 = f.x - p0, d1 = f.y - p1, d2 = f.z - p2;
+                const double s = (d0 * d0 + d1 * d1) + d2 * d2;
+                const int j = (int)__double_as_longlong(f.w);
+                if (grid_better(s, j, bS, bI)) { bS = s; bI = j; }
+            }
+            merge();
+            break;
+        }
+        const int w = 2 * r + 1, cube = w * w * w;
+        for (int k = sub; k < cube; k += GR_LANES) {
+            const int dz = k / (w * w) - r, rem = k % (w * w), dy = rem / w - r, dx = rem % w - r;
+            if (max(max(abs(dx), abs(dy)), abs(dz)) < r) continue;               // interior: visited in earlier passes
+            visit(cx + dx, cy + dy, cz + dz);
+        }
+        merge();
+    }
+    if (sub == 0 && i < n) {
+        nn[i] = (bI == 0x7fffffff) ? 0 : bI;                     // all-NaN row: np.argmin answers 0
+        if (dist) dist[i] = __builtin_sqrt(bS);
+    }
+}
+
+size_t grid_ws_bytes(int m) { return grid_layout(m).total; }
+
+int grid_build(const double *fix, int m, void *ws, hipStream_t s) {
+    const GridWs L = grid_layout(m);
+    char *base = (char *)ws;
+    GridHeader *hd = (GridHeader *)(base + L.header);
+    int *start = (int *)(base + L.start), *cursor = (int *)(base + L.cursor);
+    const int max_cells = grid_max_cells(m);
+    if (hipMemsetAsync(start, 0, ((size_t)max_cells + 1) * sizeof(int), s) != hipSuccess) return launch_status();
+    grid_plan_kernel<<<1, 1024, 0, s>>>(fix, m, max_cells, hd);
+    grid_count_kernel<<<(m + 255) / 256, 256, 0, s>>>(fix, m, hd, start);
+    grid_scan_kernel<<<1, 1024, 0, s>>>(hd, start, cursor);
+    grid_scatter_kernel<<<(m + 255) / 256, 256, 0, s>>>(fix, m, hd, cursor, (double4 *)(base + L.pts));
+    return launch_status();
+}
+
+int grid_query(const double *mov, int n, int m, const void *ws, int32_t *nn, double *dist, hipStream_t s) {
+    const GridWs L = grid_layout(m);
+    const char *base = (const char *)ws;
+    grid_nn_kernel<<<(unsigned int)(((long)n * GR_LANES + 255) / 256), 256, 0, s>>>(mov, n, (const GridHeader *)(base + L.header), (const int *)(base + L.start),
+                                                   (const double4 *)(base + L.pts), nn, dist);
+    return launch_status();
+}
+
+}  // namespace pm

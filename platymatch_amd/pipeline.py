@@ -64,7 +64,11 @@ class GpuBackend:
         return perform_icp(mov, fix, iters, transform, log=log)
 
     def icp_nn(self, mov, fix):
-        return self.K.icp_nn(mov, fix, want_dist=False)[0]
+        # the fixed cloud is constant across the iterations of one ICP run: bin it once per (tensor, stream of calls)
+        key = (fix.data_ptr(), fix.shape[1])
+        if getattr(self, "_grid_key", None) != key:
+            self._grid, self._grid_key = self.K.icp_grid(fix), key
+        return self.K.icp_nn(mov, fix, want_dist=False, grid=self._grid)[0]
 
     def icp_accumulate(self, mov, fix, nn, origin, out=None):
         return self.K.icp_accumulate(mov, fix, nn, origin, out=out, nn_trusted=True)     # nn is icp_nn's own output
@@ -181,6 +185,8 @@ def icp_sharded(be, moved, fix, iters, group=None):
     dist = _dist() if world > 1 else None
     bn = shard_bounds(moved.shape[1], world)
     loc = moved[:, bn[rank]:bn[rank + 1]].contiguous().clone()
+    if hasattr(be, "_grid_key"):
+        be._grid_key = None            # a new run may reuse the address of an old fixed cloud: never trust a stale grid
     A_icp = torch.eye(4, dtype=torch.float64, device=moved.device).reshape(16).contiguous()
     origin = torch.cat([fix[:, 0], fix[:, 0]]).contiguous()
     # One collective per iteration: the 24 moment sums of this iteration travel together with the residual

@@ -302,6 +302,44 @@ def test_nn_sqrt_rounding_ties(gpu, oracle):
     assert np.array_equal(nn.cpu().numpy(), oi) and np.array_equal(dist.cpu().numpy(), od) and s > 0
 
 
+def test_nn_grid_equals_brute_force_on_awkward_geometry(gpu, oracle):
+    """pm_icp_nn searches a uniform grid; pm_icp_nn_brute looks at every pair; the oracle is np.argmin on the distance matrix.
+    All three must agree exactly — also when the moving cloud lies outside the fixed cloud's bounding box, for flat /
+    collinear / single-point / heavily clustered fixed clouds, and for a reused grid."""
+    rng = np.random.default_rng(12)
+    cases = {}
+    fx = rng.normal(size=(3, 3000)) * np.array([[60.0], [40.0], [25.0]]) + 200
+    cases["outside_box"] = (np.concatenate([fx[:, :500] + 1000.0, fx[:, 500:900] - np.array([[0.0], [500.0], [0.0]]), fx[:, 900:1200] * 3 - 400], 1), fx)
+    flat = fx.copy(); flat[2] = 7.0
+    cases["flat_fixed"] = (rng.normal(size=(3, 700)) * 50 + 200, flat)
+    line = np.stack([np.linspace(0, 500, 2000), np.full(2000, 3.0), np.full(2000, -1.0)])
+    cases["collinear_fixed"] = (rng.normal(size=(3, 300)) * 100 + 100, line)
+    cases["single_fixed"] = (rng.normal(size=(3, 130)), np.array([[1.0], [2.0], [3.0]]))
+    blob = np.concatenate([rng.normal(size=(3, 5000)) * 0.01, rng.normal(size=(3, 20)) * 1e4], 1)     # one crowded cell + far outliers
+    cases["clustered"] = (rng.normal(size=(3, 400)) * np.array([[1e4], [1.0], [0.01]]), blob)
+    cases["moving_equals_fixed"] = (fx[:, ::3].copy(), fx)
+    cases["tiny"] = (rng.normal(size=(3, 3)), rng.normal(size=(3, 5)))
+    for name, (mv, fxc) in cases.items():
+        g_nn, g_d = gpu.K.icp_nn(gpu.d(mv), gpu.d(fxc))
+        b_nn, b_d = gpu.K.icp_nn(gpu.d(mv), gpu.d(fxc), brute=True)
+        oi, od = oracle.nn_argmin(mv, fxc)
+        assert np.array_equal(g_nn.cpu().numpy(), oi) and np.array_equal(g_d.cpu().numpy(), od), name
+        assert gpu.t.equal(g_nn, b_nn) and gpu.t.equal(g_d, b_d), name
+    # one grid, several query clouds (what the ICP loop does)
+    fxd = gpu.d(fx)
+    grid = gpu.K.icp_grid(fxd)
+    for k in range(3):
+        mv = fx[:, rng.permutation(3000)[:777]] + rng.normal(scale=3.0 * k, size=(3, 777))
+        nn, d = gpu.K.icp_nn(gpu.d(mv), fxd, grid=grid)
+        oi, od = oracle.nn_argmin(mv, fx)
+        assert np.array_equal(nn.cpu().numpy(), oi) and np.array_equal(d.cpu().numpy(), od)
+    # a NaN moving point matches index 0, like np.argmin of an all-NaN row; its neighbours are unaffected
+    mv = fx[:, :70].copy()
+    mv[1, 5] = np.nan
+    nn, _ = gpu.K.icp_nn(gpu.d(mv), fxd)
+    assert int(nn[5]) == 0 and np.array_equal(np.delete(nn.cpu().numpy(), 5), np.delete(np.arange(70), 5))
+
+
 # ------------------------------------------------------------------------------------------------ transforms, RANSAC
 def test_fit_and_apply(gpu, oracle, micro):
     from platymatch_amd.estimate_transform.apply_transform import apply_affine_transform, apply_similar_transform
