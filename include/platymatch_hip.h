@@ -137,6 +137,20 @@ int pm_chi2_symmetry_check(const double *sc_m1, const double *sc_m2, int nM, con
 int pm_chi2_cost8_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
                       size_t matrix_stride, void *stream);
 
+/* ---- assignment (HOST function: host pointers, no stream) ---------------------------------------- */
+
+/* scipy.optimize.linear_sum_assignment(cost) as the widget calls it (_dock_widget.py:604-611): cost is an
+ * nr x nc row-major float64 HOST array; rows/cols receive min(nr, nc) int64 indices (rows ascending), exactly the
+ * indices SciPy 1.15.3 returns (its shortest-augmenting-path solver restated, ties included).  Unlike SciPy it can
+ * be called from several host threads at once, so the eight hypotheses are solved concurrently.
+ * PM_ERR_INVALID_ARG: NaN or -inf entry; PM_ERR_UNSUPPORTED: infeasible matrix. */
+int pm_lsap_solve(const double *cost, long nr, long nc, int64_t *rows, int64_t *cols);
+
+/* The index sets do_ransac draws (HOST function): `trials` successive np.random.choice(n, k, replace=False) calls on
+ * NumPy's legacy global generator (shape_context.py:122), reproduced from its MT19937 state — key[624] and *pos of
+ * np.random.get_state(), advanced in place exactly as NumPy would advance them.  out: trials x k int32. */
+int pm_legacy_choice(uint32_t *key, int *pos, long n, int k, long trials, int32_t *out);
+
 /* ---- RANSAC -------------------------------------------------------------------------------- */
 
 /* do_ransac's trial loop (shape_context.py:121-138) with the index sets drawn by the caller

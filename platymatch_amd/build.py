@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libplatymatch_hip.so")
 SOURCES = ["pm_api.hip", "pm_stats.hip", "pm_shape_context.hip", "pm_chi2.hip", "pm_transform.hip",
-           "pm_icp.hip", "pm_icp_grid.hip", "pm_ransac.hip", "pm_eval.hip"]
+           "pm_icp.hip", "pm_icp_grid.hip", "pm_ransac.hip", "pm_eval.hip", "pm_lsap.cpp", "pm_host_rng.cpp"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=off", "-fno-fast-math",
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
@@ -46,7 +46,7 @@ def build_native(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, src.replace(".hip", ".o").replace(".cpp", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
             jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])

@@ -99,7 +99,20 @@ def draw_ransac_samples(n, min_samples, trials):
     """The index sets do_ransac draws: one np.random.choice(n, min_samples, replace=False) per trial
     from NumPy's global RNG, in trial order (shape_context.py:122) — so np.random.seed(s) before a
     call reproduces the reference's sets exactly."""
-    return np.stack([np.random.choice(n, min_samples, replace=False) for _ in range(trials)]).astype(np.int32)
+    state = np.random.get_state()
+    if state[0] != 'MT19937' or trials == 0 or n > 2 ** 31 - 1 or min_samples > n:
+        # (min_samples > n raises inside np.random.choice exactly as in the reference)
+        return np.stack([np.random.choice(n, min_samples, replace=False) for _ in range(trials)]).astype(np.int32)
+    # Same generator outputs, consumed in C (pm_legacy_choice restates RandomState.choice -> permutation -> shuffle ->
+    # random_interval on MT19937); the advanced state is handed back so the global stream continues as NumPy's would.
+    import ctypes
+    key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+    pos = ctypes.c_int(int(state[2]))
+    out = np.empty((trials, int(min_samples)), dtype=np.int32)
+    nat.check(nat.load().pm_legacy_choice(key.ctypes.data, ctypes.byref(pos), int(n), int(min_samples), int(trials),
+                                          out.ctypes.data))
+    np.random.set_state(('MT19937', key, pos.value, state[3], state[4]))
+    return out
 
 
 def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transform='Affine', rows=None, cols=None):

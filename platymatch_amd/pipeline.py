@@ -16,9 +16,9 @@ redundantly by every rank: identical inputs and a fixed reduction order give ide
 without a collective.
 """
 import numpy as np
-from scipy.optimize import linear_sum_assignment
 
 from . import _native as nat
+from .lsap import linear_sum_assignment, solve_many
 
 HYPOTHESES = ("11", "12", "13", "14", "21", "22", "23", "24")
 
@@ -145,12 +145,13 @@ def build_costs(be, mov, fix, group=None):
 
 def assign(U_loc, bounds, group=None):
     """linear_sum_assignment on each of the eight matrices (_dock_widget.py:604-611) -> list of
-    (row_ind, col_ind) int64 arrays, identical on every rank.  SciPy stays the solver: it defines
-    the reference's tie-breaking.  Sharded: hypothesis h is assembled on rank h mod G."""
+    (row_ind, col_ind) int64 arrays, identical on every rank.  The solver is SciPy's algorithm restated in
+    C++ (lsap.py: identical indices, callable from threads): one GPU solves the eight hypotheses on eight host
+    threads; sharded, hypothesis h is assembled and solved on rank h mod G."""
     import torch
     rank, world = _world(group)
     if world == 1:
-        return [linear_sum_assignment(U_loc[h].cpu().numpy()) for h in range(8)]
+        return solve_many([U_loc[h].cpu().numpy() for h in range(8)])       # eight host threads, GIL released
     dist = _dist()
     n = bounds[-1]
     biggest = max(bounds[g + 1] - bounds[g] for g in range(world))

@@ -24,6 +24,22 @@ def test_ransac_draws_follow_the_reference_rng_sequence(oracle):
     assert np.array_equal(ours, ref) and ours.dtype == np.int32
     np.random.seed(0)
     assert np.array_equal(oracle.draw_ransac_samples(331, 4, 50), ref)
+    # the C reproduction of the draws: same sets for many sizes, and the global stream continues where NumPy's would
+    for n in (4, 5, 7, 128, 343, 4096, 5000, 65536, 70001):
+        np.random.seed(n)
+        want = np.stack([np.random.choice(n, 4, replace=False) for _ in range(40)])
+        after_want = np.random.random(3)
+        np.random.seed(n)
+        got = draw_ransac_samples(n, 4, 40)
+        assert np.array_equal(got, want) and np.array_equal(np.random.random(3), after_want), n
+    np.random.seed(5)
+    a = draw_ransac_samples(100, 4, 10)
+    b = draw_ransac_samples(100, 4, 10)          # second call continues the stream: eight hypotheses draw one after another
+    np.random.seed(5)
+    assert np.array_equal(np.concatenate([a, b]), np.stack([np.random.choice(100, 4, replace=False) for _ in range(20)]))
+    import pytest
+    with pytest.raises(ValueError):
+        draw_ransac_samples(3, 4, 2)            # fewer pairs than samples: NumPy's own error, as in the reference
 
 
 def test_similar_from_sums_matches_reference_closed_form(oracle):

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Wall-clock breakdown of one complete registration (BASELINE config 2 scale) — where the time goes once the O(N*M)
+stages run on the GPU.  Usage: python tools/e2e_timing.py [N] [ransac_trials]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from conftest import synth_pair  # noqa: E402
+from platymatch_amd import pipeline as P  # noqa: E402
+from platymatch_amd.estimate_transform import perform_icp as pi  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+trials = int(sys.argv[2]) if len(sys.argv) > 2 else 8000
+pi.VERBOSE = False
+mv, fx, A_gt = synth_pair(n, 42)
+be = P.GpuBackend()
+mov, fix = be.cloud(mv), be.cloud(fx)
+torch.cuda.synchronize()
+
+
+def timed(label, fn):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    print("%-34s %9.1f ms" % (label, (time.perf_counter() - t) * 1e3), flush=True)
+    return out
+
+
+timed("warm-up (library load, first launches)", lambda: P.build_costs(be, mov[:, :256].contiguous(), fix[:, :256].contiguous()))
+U, bn = timed("descriptors + 8 cost matrices (GPU)", lambda: P.build_costs(be, mov, fix))
+lsa = timed("8 x linear_sum_assignment (host)", lambda: P.assign(U, bn))
+np.random.seed(0)
+res = timed("8 x RANSAC, %d trials (host RNG + GPU)" % trials,
+            lambda: [be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), trials, 16, "Affine", 4) for r, c in lsa])
+inl = [k for _, k in res]
+A_sc = res[int(np.argmax(inl))][0]
+moved = be.apply_affine(P.nat.to_dev(A_sc, dev=mov.device), mov)
+A_icp = timed("ICP, 50 iterations (GPU)", lambda: be.icp(moved, fix, 50, "Affine", None))
+final = A_icp.cpu().numpy() @ (A_sc.cpu().numpy() if hasattr(A_sc, "cpu") else A_sc)
+print("inliers", inl, " rel. error vs ground truth %.2e" % (np.linalg.norm(final - A_gt) / np.linalg.norm(A_gt)))
