@@ -2,13 +2,13 @@
 EvaluateMetrics._calculate_metrics (platymatch/_dock_widget.py:1030-1080) as a function.
 
 The three scipy `cdist` matrices are built on the device (pm_cdist, an HBM-write-bound kernel), the three
-`linear_sum_assignment` solves stay on the host with SciPy (it defines the reference's tie-breaking), the transforms are
+`linear_sum_assignment` solves stay on the host (lsap.py: SciPy's solver restated, identical indices), the transforms are
 applied on the device.  Arrays are 3 x N float64 (z, y, x); ids are 1-D arrays as `_browse_detections` returns them."""
 import numpy as np
-from scipy.optimize import linear_sum_assignment
 
 from . import _kernels as K
 from . import _native as nat
+from .lsap import linear_sum_assignment
 
 
 def cdist(a, b):
