@@ -163,11 +163,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    fence()
+    # (reporting only) which chi-square kernel these descriptors select; probed on a row sample before the timed region
     cm, mdm, x0m = be.stats(mov)
     cf, mdf, x0f = be.stats(fix)
     sym = K.chi2_symmetric(be.shape_context(mov, cm, mdm, x0m, 2, 0, min(n, 2048)), be.shape_context(fix, cf, mdf, x0f, 4, 0, min(m, 2048)))
     del cm, mdm, x0m, cf, mdf, x0f
+    fence()                                      # barrier + synchronize on both sides of exactly `steps` steps
     t0 = time.perf_counter()
     for k in range(args.steps):
         A, res = step(ev[k])

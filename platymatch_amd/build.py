@@ -49,7 +49,11 @@ def build_native(force=False, verbose=False):
         o = os.path.join(OBJ, src.replace(".hip", ".o").replace(".cpp", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            if src.endswith(".cpp"):   # host-only translation units: plain C++ compiler, same floating-point discipline
+                jobs.append([shutil.which("g++") or "g++", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                             "-Wall", "-c", s, "-o", o])
+            else:
+                jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
