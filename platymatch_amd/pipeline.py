@@ -9,8 +9,9 @@ Sharding: rank g owns a contiguous block of moving rows and of 
   assembly      for the host Hungarian solves, hypothesis h's full matrix is collected on rank
                 h mod G (one collective per hypothesis), the ranks solve their hypotheses in
                 parallel and the index vectors are all-gathered;
-  ICP           moving rows sharded, fixed replicated; per iteration the 24 moment sums are
-                all-gathered and added in rank order so every rank solves the identical 4x4.
+  ICP           moving rows sharded, fixed replicated; per iteration ONE all-gather of 26 doubles (24
+                moment sums + the previous iteration's residual parts), reduced identically on every
+                rank, so every rank solves the identical 4x4.
 Cloud statistics (centroid, mean distance, PCA axis) are O(N)…O(N^2) on 24·N bytes and are computed
 redundantly by every rank: identical inputs and a fixed reduction order give identical values
 without a collective.
@@ -43,8 +44,8 @@ class GpuBackend:
     def shape_context(self, xyz, c, md, x0, nf, row0, nrows):
         return self.K.shape_context(xyz, c, x0, md, nf, row0=row0, nrows=nrows)["hist"]
 
-    def chi2_cost8(self, sc_m, sc_f):
-        return self.K.chi2_cost8(sc_m, sc_f)
+    def chi2_cost8(self, sc_m, sc_f, out=None):
+        return self.K.chi2_cost8(sc_m, sc_f, out=out)
 
     def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples):
         from .estimate_transform.shape_context import do_ransac
@@ -141,6 +142,23 @@ def build_costs(be, mov, fix, group=None):
     """Descriptors + the eight chi-square matrices for this rank's moving rows -> (U [8, rows_g, M], bounds)."""
     sc_m, sc_f, bn = build_descriptors(be, mov, fix, group)
     return be.chi2_cost8(sc_m, sc_f), bn
+
+
+def iter_cost_blocks(be, mov, fix, rows_per_block, group=None):
+    """The same cost rows in slabs, for sizes at which a rank's eight row blocks do not fit in HBM at once
+    (BASELINE config 4: 200k x 200k on 8 GPUs is 8 x 40 GB per rank).  Yields (first_row, U [8, r, M]) with r <=
+    rows_per_block; first_row is a global moving-row index.  The slab buffer is reused: consume (reduce, copy out)
+    each slab before advancing.  Every slab is bit-identical to the corresponding rows of build_costs."""
+    import torch
+    sc_m, sc_f, bn = build_descriptors(be, mov, fix, group)
+    rank, _ = _world(group)
+    rows = sc_m.shape[1]
+    rows_per_block = max(1, min(int(rows_per_block), max(rows, 1)))
+    buf = torch.empty((8, rows_per_block, sc_f.shape[1]), dtype=torch.float64, device=sc_m.device)
+    for r0 in range(0, rows, rows_per_block):
+        r1 = min(rows, r0 + rows_per_block)
+        out = buf[:, :r1 - r0]
+        yield bn[rank] + r0, be.chi2_cost8(sc_m[:, r0:r1].contiguous(), sc_f, out=out)
 
 
 def assign(U_loc, bounds, group=None):

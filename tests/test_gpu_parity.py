@@ -539,6 +539,18 @@ def test_c2_scale_costs_and_assignment(gpu, oracle):
     assert np.array_equal(linear_sum_assignment(sub)[1], linear_sum_assignment(ref)[1])
 
 
+def test_cost_rows_in_slabs(gpu):
+    """iter_cost_blocks (for sizes whose eight row blocks exceed HBM, BASELINE config 4) reproduces build_costs slab by slab."""
+    from platymatch_amd import pipeline as P
+    mv, fx, _ = synth_pair(700, 17)
+    be = P.GpuBackend()
+    mov, fix = be.cloud(mv), be.cloud(fx[:, :650])
+    U, bn = P.build_costs(be, mov, fix)
+    got = [(r0, blk.clone()) for r0, blk in P.iter_cost_blocks(be, mov, fix, 128)]
+    assert [r0 for r0, _ in got] == list(range(0, 700, 128))
+    assert gpu.t.equal(gpu.t.cat([b for _, b in got], dim=1), U) and U.shape == (8, 700, 650)
+
+
 def test_argument_errors_raise(gpu):
     t = gpu.t
     with pytest.raises(ValueError):

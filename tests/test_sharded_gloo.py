@@ -36,9 +36,13 @@ class OracleBackend:
         counts, totals = self.o.shape_context_counts(c.numpy(), float(md[0]), xyz.numpy(), "fixed" if nf == 4 else "moving", x0=x0.numpy())
         return torch.as_tensor(self.o.normalise_counts(counts, totals)[:, row0:row0 + nrows].copy())
 
-    def chi2_cost8(self, sc_m, sc_f):
+    def chi2_cost8(self, sc_m, sc_f, out=None):
         U = [self.o.unary_distance_matrix(sc_m[int(h[0]) - 1].numpy(), sc_f[int(h[1]) - 1].numpy()) for h in self.o.HYPOTHESES]
-        return torch.as_tensor(np.stack(U))
+        U = torch.as_tensor(np.stack(U))
+        if out is not None:
+            out.copy_(U)
+            return out
+        return U
 
     def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples):
         A, k = self.o.do_ransac(mov.numpy()[:, rows], fix.numpy()[:, cols], min_samples=min_samples, trials=trials, error=error,
@@ -119,6 +123,8 @@ def _worker(rank, world, port, name, out_path):
         # descriptor gather and cost rows, checked directly too
         mov, fix = be.cloud(d["moving"]), be.cloud(d["fixed"])
         U, bn = P.build_costs(be, mov, fix, dist.group.WORLD)
+        slabs = [(r0, blk.clone()) for r0, blk in P.iter_cost_blocks(be, mov, fix, 37, dist.group.WORLD)]
+        assert slabs[0][0] == bn[rank] and torch.equal(torch.cat([b for _, b in slabs], dim=1), U)
         np.savez(out_path % rank, A_sc=np.asarray(A_sc), A_icp=np.asarray(A_icp), inl=inl, residuals=det["residuals"],
                  lsa_cols=np.stack([c for _, c in det["lsa"]]), U=U.numpy(), bounds=np.array(bn))
     finally:
