@@ -17,8 +17,8 @@
 //   the 360 bins stream through LDS in 30 stages of 12 (one (r,theta) shell of 12 phi sectors):
 //   B rows are read per lane (row pitch 112 B = 7 x 16 B, odd, so ds_read_b128 is conflict
 //   free), A rows are wave-uniform broadcasts.
-//   Tiles are numbered with i fastest and the block id is remapped so that each XCD walks a
-//   contiguous run of tiles: concurrent workgroups of an XCD share one B tile in its L2.
+//   The block id is remapped so that each XCD walks a contiguous run of tiles, ordered in groups of 8
+//   column tiles (tile_of): concurrent workgroups of an XCD share a few A and B tiles in its L2.
 #include "pm_common.h"
 
 namespace pm {
