@@ -7,7 +7,7 @@ Workload (BASELINE.json metric: point-pairs/s, shape-context + chi-square cost +
   matrices (float64, written to HBM) -> 200 iterations of affine ICP.
 value = N*M point pairs / step time (whole job, all ranks).  With --gpus G > 1 the SAME problem is
 row-sharded (strong scaling): descriptors and cost rows by block with one all-gather of the fixed
-descriptors over RCCL, ICP with per-iteration all-gathers of 24 moment sums.  The Hungarian solve is not
+descriptors over RCCL; the ICP refinement (1 % of the step with the grid search) is run whole by every rank.  The Hungarian solve is not
 part of the step: at 50k it needs hours and 20 GB of host memory per matrix.
 
 Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
@@ -143,7 +143,9 @@ def main():
         if marks: marks[2].record()
         K.chi2_cost8(sc_m, sc_f, out=U, path=chi2_path[0])
         if marks: marks[3].record()
-        if world == 1:
+        if world == 1 or n < P.ICP_SHARD_MIN_POINTS:
+            # every rank refines on its own (replicas): one grid-search iteration over 50k points costs less than the
+            # latency of the collective a sharded iteration would need (pipeline.ICP_SHARD_MIN_POINTS)
             work = start.clone()
             A, res, _ = K.icp(work, fix, args.icp_iters, ws=icp_ws)
         else:

@@ -197,6 +197,12 @@ def assign(U_loc, bounds, group=None):
     return out
 
 
+# Below this many moving points every rank simply runs the whole ICP itself: with the grid search one iteration
+# over 50 000 points costs ~80 us on one GPU, less than the latency of the collective a sharded iteration needs
+# ("latency-bound, so for N <= 50k single-GPU ICP is preferable").  Replicas give identical results.
+ICP_SHARD_MIN_POINTS = 400_000
+
+
 def icp_sharded(be, moved, fix, iters, group=None):
     """Affine ICP with the moving rows sharded (perform_icp.py:7-26).  -> (A_icp [4,4], residuals [iters])."""
     import torch
@@ -250,7 +256,7 @@ def pca_alignment(moving, fixed):
 
 def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
                        ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, group=None,
-                       backend=None):
+                       backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS):
     """Reproduces _dock_widget.py:526-718 -> (A_sc, A_icp, inliers[8]); final transform = A_icp @ A_sc (:428).
 
     moving, fixed   3 x N / 3 x M float64 (rows z, y, x), NumPy or torch
@@ -261,6 +267,7 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     seed            if not None, np.random.seed(seed) right before the eight RANSAC runs
     group           torch.distributed process group to shard over (None = this GPU only); every rank
                     passes the same clouds and gets the same results
+    icp_shard_min_points  moving-cloud size from which ICP is sharded too (below it every rank runs it whole)
     details         optional dict filled with intermediate results (lsa, ransac_A, residuals)
     """
     import torch
@@ -290,7 +297,7 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     else:
         raise ValueError("mode must be 'unsupervised' or 'supervised'")
     moved = be.apply_affine(A_sc, mov)                                              # :714
-    if world > 1 and transform == 'Affine':
+    if world > 1 and transform == 'Affine' and mov.shape[1] >= icp_shard_min_points:
         A_icp, res = icp_sharded(be, moved, fix, int(icp_iterations), group)
         if details is not None:
             details['residuals'] = res.cpu().numpy()

@@ -119,7 +119,8 @@ def _worker(rank, world, port, name, out_path):
         det = {}
         A_sc, A_icp, inl = P.estimate_transform(d["moving"], d["fixed"], ransac_trials=int(d["ransac_trials"]),
                                                 ransac_error=float(d["ransac_error"]), icp_iterations=int(d["icp_iters"]),
-                                                seed=int(d["ransac_seed"]), details=det, group=dist.group.WORLD, backend=be)
+                                                seed=int(d["ransac_seed"]), details=det, group=dist.group.WORLD, backend=be,
+                                                icp_shard_min_points=0)          # force the sharded ICP loop
         # descriptor gather and cost rows, checked directly too
         mov, fix = be.cloud(d["moving"]), be.cloud(d["fixed"])
         U, bn = P.build_costs(be, mov, fix, dist.group.WORLD)
