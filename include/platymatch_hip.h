@@ -16,7 +16,7 @@
  *     `transposed=False`), i.e. structure-of-arrays, so every coordinate load is coalesced;
  *   - descriptors are float64 [N][360] row-major per frame, as get_unary returns them;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue
- *     work and return; no entry point allocates, frees or synchronises (graph-capture safe);
+ *     work and return; no entry point allocates, frees or synchronises;
  *   - scratch comes from the caller: ask pm_*_workspace() for the size (bytes), pass a device
  *     buffer at least that large; workspace contents need not be initialised;
  *   - re-entrant: no global mutable state; safe from any host thread, any device, any stream;
