@@ -24,6 +24,7 @@ struct GridHeader {          // lives at the start of the workspace, written by 
     double lo[3];            // bounding box minimum
     double h;                // cell edge
     double inv_h;
+    double reach_scale;      // < 1: slack for the rounding of the point -> cell map (grows with |coordinate| / h)
     int g[3];                // cells per axis
     int ncells;
 };
@@ -108,6 +109,11 @@ __global__ __launch_bounds__(1024) void grid_plan_kernel(const double *__restric
         for (int c = 0; c < 3; ++c) { hd->lo[c] = lo[c]; hd->g[c] = g[c]; }
         hd->h = h;
         hd->inv_h = 1.0 / h;
+        // A point's cell coordinate (x - lo) / h carries a rounding error of a few ulps of |x| / h cells; the
+        // "unexplored points are farther than r*h" bound is therefore taken with that much slack (plus 1e-6).
+        double maxabs = 0.0;
+        for (int c = 0; c < 3; ++c) maxabs = fmax(maxabs, fmax(fabs(lo[c]), fabs(lo[c] + len[c])));
+        hd->reach_scale = 1.0 - (1e-6 + 16.0 * maxabs * 0x1p-52 / h);
         hd->ncells = g[0] * g[1] * g[2];
     }
 }
@@ -219,7 +225,8 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__
     merge();
     int r = 1;
     // everything not yet visited is farther than r*h (minus the rounding slack of the cell map)
-    while (!(bS < (r * hd.h * (1.0 - 1e-6)) * (r * hd.h * (1.0 - 1e-6))) && r < rmax) {
+    // (reach_scale <= 0 for absurd coordinate / cell-size ratios simply widens the search to the full scan)
+    while (!(hd.reach_scale > 0.0 && bS < (r * hd.h * hd.reach_scale) * (r * hd.h * hd.reach_scale)) && r < rmax) {
         ++r;
         if (r > GR_RING_CAP) {                                  // sparse neighbourhood: scan every point (always exact)
             const int m_all = start[hd.ncells];

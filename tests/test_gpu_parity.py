@@ -319,6 +319,9 @@ def test_nn_grid_equals_brute_force_on_awkward_geometry(gpu, oracle):
     cases["clustered"] = (rng.normal(size=(3, 400)) * np.array([[1e4], [1.0], [0.01]]), blob)
     cases["moving_equals_fixed"] = (fx[:, ::3].copy(), fx)
     cases["tiny"] = (rng.normal(size=(3, 3)), rng.normal(size=(3, 5)))
+    far = rng.normal(size=(3, 2000)) + 1e9                                  # coordinates 1e9 x the cell size: the cell map is coarse
+    cases["huge_offset"] = (far[:, :600] + rng.normal(scale=0.3, size=(3, 600)), far)
+    cases["huge_offset_lattice"] = (np.round(far[:, :500] * 4) / 4, np.round(far * 4) / 4)     # plus exact ties
     for name, (mv, fxc) in cases.items():
         g_nn, g_d = gpu.K.icp_nn(gpu.d(mv), gpu.d(fxc))
         b_nn, b_d = gpu.K.icp_nn(gpu.d(mv), gpu.d(fxc), brute=True)
