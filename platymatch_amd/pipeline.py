@@ -16,12 +16,15 @@ Cloud statistics (centroid, mean distance, PCA axis) are O(N)…O(N^2) on 24·N 
 redundantly by every rank: identical inputs and a fixed reduction order give identical values
 without a collective.
 """
+import threading
+
 import numpy as np
 
 from . import _native as nat
 from .lsap import linear_sum_assignment, solve_many
 
 HYPOTHESES = ("11", "12", "13", "14", "21", "22", "23", "24")
+_RNG_LOCK = threading.RLock()
 
 
 class GpuBackend:
@@ -279,14 +282,15 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         U, bn = build_costs(be, mov, fix, group)
         lsa = assign(U, bn, group)
         del U
-        if seed is not None:
-            np.random.seed(seed)
         A_h = []
-        for h, (r, c) in enumerate(lsa):            # every rank runs the same 8 x trials: same RNG stream everywhere
-            A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
-                                ransac_samples)
-            A_h.append(nat.to_dev(A, dev=mov.device))
-            inliers[h] = k
+        with _RNG_LOCK:                              # NumPy's global generator is shared by every thread of a batch run
+            if seed is not None:
+                np.random.seed(seed)
+            for h, (r, c) in enumerate(lsa):        # every rank runs the same 8 x trials: same RNG stream everywhere
+                A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
+                                    ransac_samples)
+                A_h.append(nat.to_dev(A, dev=mov.device))
+                inliers[h] = k
         A_sc = A_h[int(np.argmax(inliers))]          # first maximum (_dock_widget.py:683-703)
         if details is not None:
             details.update(lsa=lsa, ransac_A=torch.stack(A_h).cpu().numpy())
@@ -309,3 +313,31 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     if nat.is_torch(moving):
         return A_sc, nat.to_dev(A_icp, dev=mov.device), inliers
     return A_sc.cpu().numpy(), (A_icp.cpu().numpy() if nat.is_torch(A_icp) else np.asarray(A_icp)), inliers
+
+
+def estimate_transform_batch(pairs, workers=4, seeds=None, **kwargs):
+    """Several independent registrations on one GPU (BASELINE config 5: "replicas only", no collective): each worker thread
+    drives its pairs on its own HIP stream, so the GPU stages of different pairs overlap, the Hungarian solves (GIL-free,
+    lsap.py) run concurrently on the host, and only the RANSAC stage — which draws from NumPy's global generator exactly as
+    the reference does — is serialised.  pairs: iterable of (moving, fixed); seeds: optional per-pair RANSAC seeds.
+    -> list of (A_sc, A_icp, inliers) in input order, each identical to a stand-alone estimate_transform call."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    pairs = list(pairs)
+    seeds = list(seeds) if seeds is not None else [None] * len(pairs)
+    if len(seeds) != len(pairs):
+        raise ValueError("one seed per pair")
+    dev = nat.device()
+    nat.load()
+
+    def one(k):
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.device(dev), torch.cuda.stream(stream):
+            out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], **kwargs)
+            stream.synchronize()
+        return out
+
+    if workers <= 1 or len(pairs) <= 1:
+        return [one(k) for k in range(len(pairs))]
+    with ThreadPoolExecutor(max_workers=min(workers, len(pairs))) as ex:
+        return list(ex.map(one, range(len(pairs))))

@@ -217,6 +217,11 @@ def scenario(ref, name):
         fx = np.ascontiguousarray(fx[:, rng.permutation(128)])
         mv = np.ascontiguousarray(mv[:, :96])
         return run_pipeline(ref, mv, fx, 500, 16, 20, 1, name), A_GT
+    if name == "synth1000":
+        rng, mv = synth_cloud(1000, 2)
+        fx = at.apply_affine_transform(mv, A_GT) + rng.normal(scale=1.0, size=mv.shape)
+        fx = np.ascontiguousarray(fx[:, rng.permutation(1000)])
+        return run_pipeline(ref, mv, fx, 300, 16, 20, 50, name), A_GT
     raise KeyError(name)
 
 

@@ -542,6 +542,25 @@ def test_c2_scale_costs_and_assignment(gpu, oracle):
     assert np.array_equal(linear_sum_assignment(sub)[1], linear_sum_assignment(ref)[1])
 
 
+def test_batch_of_pairs_on_streams_equals_sequential(gpu):
+    """BASELINE config 5 shape (independent pairs of mixed sizes, one HIP stream per worker): results identical to
+    stand-alone calls, whatever the interleaving."""
+    from platymatch_amd import pipeline as P
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    sizes = [(200, 230), (450, 450), (333, 300), (500, 520), (128, 128), (260, 400)]
+    pairs = []
+    for k, (n, m) in enumerate(sizes):
+        mv, fx, _ = synth_pair(max(n, m), 100 + k)
+        pairs.append((np.ascontiguousarray(mv[:, :n]), np.ascontiguousarray(fx[:, :m])))
+    seeds = [7 * k + 1 for k in range(len(pairs))]
+    kw = dict(ransac_trials=300, icp_iterations=8)
+    seq = [P.estimate_transform(a, b, seed=s, **kw) for (a, b), s in zip(pairs, seeds)]
+    par = P.estimate_transform_batch(pairs, workers=3, seeds=seeds, **kw)
+    for (s_sc, s_icp, s_inl), (p_sc, p_icp, p_inl) in zip(seq, par):
+        assert np.array_equal(s_inl, p_inl) and np.array_equal(s_sc, p_sc) and np.array_equal(s_icp, p_icp)
+
+
 def test_cost_rows_in_slabs(gpu):
     """iter_cost_blocks (for sizes whose eight row blocks exceed HBM, BASELINE config 4) reproduces build_costs slab by slab."""
     from platymatch_amd import pipeline as P
