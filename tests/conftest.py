@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-SCENARIOS = ["synth128", "synth96x128", "insitu02_identity", "insitu02_affine", "insitu04_affine"]
+SCENARIOS = ["synth128", "synth96x128", "insitu02_identity", "insitu02_affine", "insitu04_affine", "synth1000"]
 
 
 def pytest_configure(config):
