@@ -137,6 +137,14 @@ int pm_chi2_symmetry_check(const double *sc_m1, const double *sc_m2, int nM, con
 int pm_chi2_cost8_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
                       size_t matrix_stride, void *stream);
 
+/* np.argmin(U_h, axis=1) for n_mat stacked cost matrices (U_h = U + h*matrix_stride, rows x cols, leading
+ * dimension ld): idx[h*rows + i] = first index of the minimum of row i, or of the first NaN if the row holds one
+ * (NumPy's rule); val (may be NULL) receives the minimum itself.  This is the per-row check BASELINE.json's
+ * 200k-point configuration is compared on, and the greedy correspondence for clouds too large for the
+ * assignment solver: rows are sharded across ranks like the matrices, so no exchange is needed. */
+int pm_row_argmin(const double *U, int n_mat, int rows, int cols, size_t ld, size_t matrix_stride, int32_t *idx,
+                  double *val, void *stream);
+
 /* ---- assignment (HOST function: host pointers, no stream) ---------------------------------------- */
 
 /* scipy.optimize.linear_sum_assignment(cost) as the widget calls it (_dock_widget.py:604-611): cost is an

@@ -95,6 +95,29 @@ def cdist(a, b, out=None):
     return out
 
 
+def row_argmin(U, return_values=False):
+    """np.argmin(U, axis=-1) of a float64 GPU cost matrix [rows, cols] or stack [n_mat, rows, cols] -> int32 indices
+    (first minimum; first NaN if the row holds one), optionally with the minima."""
+    torch = _t()
+    if not (nat.is_torch(U) and U.is_cuda and U.dtype == torch.float64 and U.dim() in (2, 3) and U.numel() > 0
+            and U.stride(-1) == 1):
+        raise ValueError("U must be a non-empty float64 GPU tensor [rows, cols] or [n_mat, rows, cols] with unit column stride")
+    stack = U if U.dim() == 3 else U.unsqueeze(0)
+    n_mat, rows, cols = stack.shape
+    ld = stack.stride(1) if rows > 1 else cols
+    ms = stack.stride(0) if n_mat > 1 else rows * ld
+    if ld < cols or (n_mat > 1 and ms < (rows - 1) * ld + cols):
+        raise ValueError("U rows / matrices must not overlap")
+    idx = torch.empty((n_mat, rows), dtype=torch.int32, device=U.device)
+    val = torch.empty((n_mat, rows), dtype=torch.float64, device=U.device) if return_values else None
+    check(nat.load().pm_row_argmin(ptr(stack), n_mat, rows, cols, ld, ms, ptr(idx), ptr(val) if val is not None else None,
+                                   nat.stream_ptr()))
+    if U.dim() == 2:
+        idx = idx[0]
+        val = val[0] if val is not None else None
+    return (idx, val) if return_values else idx
+
+
 def label_moments(labels, n_labels=None):
     """labels: int32 GPU [Z, Y, X] -> (counts [L] int64, sums [3, L] int64 of z, y, x indices), L = max label + 1."""
     torch = _t()

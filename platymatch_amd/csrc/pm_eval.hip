@@ -83,9 +83,64 @@ __global__ __launch_bounds__(256) void label_moments_kernel(const int32_t *__res
     }
 }
 
+// ---- row arg-min of stacked cost matrices --------------------------------------------------------------------------
+// np.argmin(U, axis=1): first index of the row minimum; a NaN anywhere in the row wins (NumPy's `mp < min ||
+// isnan(mp)` scan stops at the first NaN).  One wave per row, 16-byte loads when the row is 16-byte aligned, a
+// butterfly of (value, index) pairs at the end.  8 bytes read per entry, nothing else: HBM-read bound.
+__global__ __launch_bounds__(256) void row_argmin_kernel(const double *__restrict__ U, long long total_rows, int rows, int cols,
+                                                         size_t ld, size_t matrix_stride, int32_t *__restrict__ idx,
+                                                         double *__restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= total_rows) return;                               // whole wave leaves together
+    const int h = (int)(r / rows), i = (int)(r % rows);
+    const double *row = U + (size_t)h * matrix_stride + (size_t)i * ld;
+    double best = __builtin_inf();
+    int bi = 0x7fffffff, first_nan = 0x7fffffff;
+    auto take = [&](double x, int j) {
+        if (x != x) first_nan = min(first_nan, j);
+        else if (x < best || bi == 0x7fffffff) { best = x; bi = j; }
+    };
+    if ((((uintptr_t)row) & 15) == 0) {
+        const int pairs = cols >> 1;
+        const double2 *row2 = reinterpret_cast<const double2 *>(row);
+        for (int p = lane; p < pairs; p += 64) {
+            const double2 v = row2[p];
+            take(v.x, 2 * p);
+            take(v.y, 2 * p + 1);
+        }
+        if ((cols & 1) && lane == 0) take(row[cols - 1], cols - 1);
+    } else {
+        for (int j = lane; j < cols; j += 64) take(row[j], j);
+    }
+    for (int off = 32; off; off >>= 1) {
+        const double ov = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        const int on = __shfl_xor(first_nan, off);
+        first_nan = min(first_nan, on);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov < best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        const bool nan = first_nan != 0x7fffffff;
+        idx[r] = nan ? first_nan : bi;
+        if (val) val[r] = nan ? __builtin_nan("") : best;
+    }
+}
+
 }  // namespace pm
 
 extern "C" {
+
+int pm_row_argmin(const double *U, int n_mat, int rows, int cols, size_t ld, size_t matrix_stride, int32_t *idx,
+                  double *val, void *stream) {
+    if (!U || !idx || n_mat <= 0 || rows <= 0 || cols <= 0 || ld < (size_t)cols) return PM_ERR_INVALID_ARG;
+    if (n_mat > 1 && matrix_stride < (size_t)(rows - 1) * ld + (size_t)cols) return PM_ERR_INVALID_ARG;
+    const long long total = (long long)n_mat * rows;
+    const long long blocks = (total + 3) / 4;
+    if (blocks > 0x7fffffffLL) return PM_ERR_INVALID_ARG;
+    pm::row_argmin_kernel<<<(unsigned int)blocks, 256, 0, (hipStream_t)stream>>>(U, total, rows, cols, ld, matrix_stride, idx, val);
+    return pm::launch_status();
+}
 
 int pm_cdist(const double *a, int n, const double *b, int m, double *out, size_t ld, void *stream) {
     if (!a || !b || !out || n <= 0 || m <= 0 || ld < (size_t)m) return PM_ERR_INVALID_ARG;

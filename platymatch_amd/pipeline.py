@@ -50,6 +50,9 @@ class GpuBackend:
     def chi2_cost8(self, sc_m, sc_f, out=None):
         return self.K.chi2_cost8(sc_m, sc_f, out=out)
 
+    def row_argmin(self, U):
+        return self.K.row_argmin(U)
+
     def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples):
         from .estimate_transform.shape_context import do_ransac
         return do_ransac(mov, fix, min_samples=min_samples, trials=trials, error=error, transform=transform,
@@ -162,6 +165,24 @@ def iter_cost_blocks(be, mov, fix, rows_per_block, group=None):
         r1 = min(rows, r0 + rows_per_block)
         out = buf[:, :r1 - r0]
         yield bn[rank] + r0, be.chi2_cost8(sc_m[:, r0:r1].contiguous(), sc_f, out=out)
+
+
+def cost_row_argmins(be, mov, fix, rows_per_block=None, group=None):
+    """np.argmin(U_h, axis=1) for the eight cost matrices without ever holding them: each rank streams its rows
+    through a slab of `rows_per_block` rows (default: its whole block), reduces the slab on the device and keeps 4
+    bytes per (hypothesis, row).  Returns int32 [8, N], identical on every rank (one all-gather of the indices).
+    This is the greedy correspondence for clouds beyond the assignment solver's reach, and the quantity
+    BASELINE.json's 200k-point configuration is checked on."""
+    import torch
+    rank, world = _world(group)
+    n = mov.shape[1]
+    bn = shard_bounds(n, world)
+    rows = bn[rank + 1] - bn[rank]
+    idx = torch.empty((8, rows), dtype=torch.int32, device=mov.device)
+    for first, U in iter_cost_blocks(be, mov, fix, rows if rows_per_block is None else rows_per_block, group):
+        r0 = first - bn[rank]
+        idx[:, r0:r0 + U.shape[1]] = be.row_argmin(U)
+    return all_gather_rows(idx, bn, 1, group)
 
 
 def assign(U_loc, bounds, group=None):

@@ -52,6 +52,19 @@ def test_half_cost_kernel_equals_general_kernel_on_full_width_rows(big):
     assert t.equal(K.chi2_cost(a, b), K.chi2_cost(b, a).t())
 
 
+def test_row_argmin_on_full_width_rows(big):
+    K, t = big["K"], big["t"]
+    hf = K.shape_context(big["fix"], *big["fix_stats"], 4)["hist"]
+    U = K.chi2_cost8(hf[:2, 30000:31024].contiguous(), hf)           # fixed rows against the fixed cloud itself
+    idx, val = K.row_argmin(U, return_values=True)
+    assert t.equal(val, U.amin(-1))
+    assert t.equal(U.gather(2, idx.long().unsqueeze(-1)).squeeze(-1), val)
+    first = (U == val.unsqueeze(-1)).int().cumsum(-1).eq(0).sum(-1)  # columns before the first minimum
+    assert t.equal(first.int(), idx)
+    # U11 of a descriptor set against itself: row i's minimum is the exact zero on its own column
+    assert t.equal(idx[0], t.arange(30000, 31024, device=idx.device, dtype=t.int32)) and float(val[0].abs().max()) == 0.0
+
+
 def test_grid_search_equals_brute_force_at_50k(big):
     K, t = big["K"], big["t"]
     g_nn, g_d = K.icp_nn(big["start"], big["fix"])

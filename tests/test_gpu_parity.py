@@ -573,6 +573,43 @@ def test_cost_rows_in_slabs(gpu):
     assert gpu.t.equal(gpu.t.cat([b for _, b in got], dim=1), U) and U.shape == (8, 700, 650)
 
 
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_row_argmin_matches_reference_fixture(gpu, oracle, name):
+    """np.argmin(U_h, axis=1) of the reference's own matrices (stored for every row by gen_golden.py)."""
+    from platymatch_amd import pipeline as P
+    d = load_golden(name)
+    be = P.GpuBackend()
+    got = P.cost_row_argmins(be, be.cloud(d["moving"]), be.cloud(d["fixed"]), rows_per_block=53)
+    assert got.dtype == gpu.t.int32 and np.array_equal(got.cpu().numpy(), d["U_rowmin_idx"])
+
+
+def test_row_argmin_numpy_rules(gpu):
+    """First index on ties, first NaN wins, -0.0 == +0.0, +inf rows, odd widths, unaligned and strided rows."""
+    t = gpu.t
+    rng = np.random.default_rng(5)
+    for rows, cols in [(1, 1), (3, 2), (7, 63), (5, 64), (9, 129), (33, 1000), (4, 4097)]:
+        U = rng.integers(0, 6, size=(3, rows, cols)).astype(np.float64)          # many ties
+        U[0, 0, cols // 2] = -0.0
+        if cols > 2:
+            U[1, rows - 1, cols - 1] = np.nan
+            U[1, rows - 1, 1] = np.nan
+            U[2, 0, :] = np.inf
+        with np.errstate(invalid="ignore"):
+            want = np.argmin(U, axis=-1)
+        idx, val = gpu.K.row_argmin(gpu.d(U), return_values=True)
+        assert np.array_equal(idx.cpu().numpy(), want)
+        assert np.array_equal(val.cpu().numpy(), np.take_along_axis(U, want[..., None], -1)[..., 0], equal_nan=True)
+        assert np.array_equal(gpu.K.row_argmin(gpu.d(U[1])).cpu().numpy(), want[1])     # single matrix
+        if cols > 3:                                                                     # odd offset: rows not 16-byte aligned
+            view = gpu.d(U)[:, :, 1:cols - 1]
+            with np.errstate(invalid="ignore"):
+                assert np.array_equal(gpu.K.row_argmin(view).cpu().numpy(), np.argmin(U[:, :, 1:cols - 1], axis=-1))
+    with pytest.raises(ValueError):
+        gpu.K.row_argmin(t.zeros((2, 3), dtype=t.float32, device=gpu.dev))
+    with pytest.raises(ValueError):
+        gpu.K.row_argmin(t.zeros((2, 0), dtype=t.float64, device=gpu.dev))
+
+
 def test_argument_errors_raise(gpu):
     t = gpu.t
     with pytest.raises(ValueError):

@@ -44,6 +44,9 @@ class OracleBackend:
             return out
         return U
 
+    def row_argmin(self, U):
+        return torch.as_tensor(np.argmin(U.numpy(), axis=-1).astype(np.int32))
+
     def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples):
         A, k = self.o.do_ransac(mov.numpy()[:, rows], fix.numpy()[:, cols], min_samples=min_samples, trials=trials, error=error,
                                 transform=transform)
@@ -126,8 +129,9 @@ def _worker(rank, world, port, name, out_path):
         U, bn = P.build_costs(be, mov, fix, dist.group.WORLD)
         slabs = [(r0, blk.clone()) for r0, blk in P.iter_cost_blocks(be, mov, fix, 37, dist.group.WORLD)]
         assert slabs[0][0] == bn[rank] and torch.equal(torch.cat([b for _, b in slabs], dim=1), U)
+        amin = P.cost_row_argmins(be, mov, fix, 29, dist.group.WORLD)          # streamed in slabs, gathered
         np.savez(out_path % rank, A_sc=np.asarray(A_sc), A_icp=np.asarray(A_icp), inl=inl, residuals=det["residuals"],
-                 lsa_cols=np.stack([c for _, c in det["lsa"]]), U=U.numpy(), bounds=np.array(bn))
+                 lsa_cols=np.stack([c for _, c in det["lsa"]]), U=U.numpy(), bounds=np.array(bn), amin=amin.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -140,8 +144,9 @@ def test_two_rank_pipeline_matches_single_process(tmp_path, oracle, name):
     r0, r1 = np.load(out % 0), np.load(out % 1)
     d = load_golden(name)
     # every rank returns the same thing
-    for k in ("A_sc", "A_icp", "inl", "lsa_cols", "residuals"):
+    for k in ("A_sc", "A_icp", "inl", "lsa_cols", "residuals", "amin"):
         assert np.array_equal(r0[k], r1[k]), k
+    assert np.array_equal(r0["amin"], d["U_rowmin_idx"])            # the reference's np.argmin(U_h, axis=1)
     # row blocks of the cost matrices: disjoint, complete, bit-exact vs the reference fixture rows
     b = r0["bounds"]
     assert list(b) == [0, (d["moving"].shape[1] + 1) // 2, d["moving"].shape[1]]
