@@ -143,9 +143,18 @@ def main():
         if marks: marks[1].record()
         sc_m = be.shape_context(mov, cm, mdm, x0m, 2, r0, r1 - r0)
         sc_f = be.shape_context(fix, cf, mdf, x0f, 4, bm[rank], bm[rank + 1] - bm[rank])
-        sc_f = P.all_gather_rows(sc_f, bm, 1, group)
+        # verify the frame-permutation relation on the local rows (a 4-byte read-back; sharded: flags max-reduced, then
+        # only frame 1 is gathered) -- inside the timed step, because the choice of kernel depends on it
+        if world == 1:
+            symmetric[0] = K.chi2_symmetric(sc_m, sc_f)
+        else:
+            sc_f = P.gather_fixed_descriptors(be, sc_m, sc_f, bm, group)
+            symmetric[0] = sc_f.shape[0] == 1
         if marks: marks[2].record()
-        K.chi2_cost8(sc_m, sc_f, out=U, path=chi2_path[0])
+        if symmetric[0]:
+            K.chi2_cost8_frame1(sc_m[0], sc_f[0], out=U)
+        else:
+            K.chi2_cost8(sc_m, sc_f, out=U, path="general")
         if marks: marks[3].record()
         if world == 1 or n < P.ICP_SHARD_MIN_POINTS:
             # every rank refines on its own (replicas): one grid-search iteration over 50k points costs less than the
@@ -157,9 +166,7 @@ def main():
         if marks: marks[4].record()
         return A, res
 
-    # which chi-square kernel the descriptors allow is decided once, outside the timed region (a 4-byte read-back);
-    # the verification kernel itself is re-run inside every step only when path == "auto"
-    chi2_path = ["auto"]
+    symmetric = [False]                          # which chi-square kernel the last step's descriptors selected
 
     def fence():
         torch.cuda.synchronize()
@@ -169,11 +176,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # (reporting only) which chi-square kernel these descriptors select; probed on a row sample before the timed region
-    cm, mdm, x0m = be.stats(mov)
-    cf, mdf, x0f = be.stats(fix)
-    sym = K.chi2_symmetric(be.shape_context(mov, cm, mdm, x0m, 2, 0, min(n, 2048)), be.shape_context(fix, cf, mdf, x0f, 4, 0, min(m, 2048)))
-    del cm, mdm, x0m, cf, mdf, x0f
     fence()                                      # barrier + synchronize on both sides of exactly `steps` steps
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -194,6 +196,7 @@ def main():
     # float64 VALU view of the same launch.  Half-cost kernel: per (pair, bin) 4 terms x (sub, 2 mul, add, rcp, 5 fma) + 8
     # running-sum adds = 48 instructions, 68 flop (fma = 2); general kernel: 8 terms x 11 instructions, 128 flop.
     # Issue model (measured, tools/microbench/fp64_issue.hip + SQ counters): 4 cycles per instruction, 16 for v_rcp_f64.
+    sym = bool(symmetric[0])
     kernel_name = "pm::chi2_sym_kernel<4,2>" if sym else "pm::chi2_kernel<2,4>"
     flops = (68.0 if sym else 128.0) * 360 * rows * m
     instr = (48.0 if sym else 88.0) * 360 * rows * m / 64.0                  # wave64 VALU instructions

@@ -195,15 +195,42 @@ def chi2_cost(scA, scB, out=None):
     return out
 
 
-def chi2_symmetric(sc_m, sc_f):
-    """True if frames 2..4 are, bit for bit, the phi-sector permutations of frame 1 (one tiny kernel + a 4-byte read)."""
+def chi2_symmetry_flag(sc_m, sc_f):
+    """int32 GPU tensor [1]: 0 if frames 2..4 are, bit for bit, the phi-sector permutations of frame 1 for every given
+    row of both clouds, 1 otherwise.  No read-back: ranks of a sharded run max-reduce their flags before looking."""
     torch = _t()
     m = [_desc(sc_m[k], "sc_m[%d]" % k) for k in range(2)]
     f = [_desc(sc_f[k], "sc_f[%d]" % k) for k in range(4)]
     flag = torch.empty(1, dtype=torch.int32, device=sc_m.device)
     check(nat.load().pm_chi2_symmetry_check(ptr(m[0]), ptr(m[1]), m[0].shape[0], ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]),
                                             f[0].shape[0], ptr(flag), nat.stream_ptr()))
-    return int(flag.item()) == 0
+    return flag
+
+
+def chi2_symmetric(sc_m, sc_f):
+    """True if the permutation relation holds (one tiny kernel + a 4-byte read)."""
+    return int(chi2_symmetry_flag(sc_m, sc_f).item()) == 0
+
+
+def chi2_cost8_frame1(sc_m1, sc_f1, out=None):
+    """The eight matrices from the frame-1 descriptors alone ([nM, 360], [nF, 360]) by the half-cost kernel.  Only for
+    descriptor sets whose frames 2..4 were verified (chi2_symmetry_flag == 0) to be permutations of frame 1."""
+    torch = _t()
+    a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
+    nM, nF = a.shape[0], b.shape[0]
+    out = _out8(out, nM, nF, a.device)
+    check(nat.load().pm_chi2_cost8_sym(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), nat.stream_ptr()))
+    return out
+
+
+def _out8(out, nM, nF, device):
+    torch = _t()
+    if out is None:
+        return torch.empty((8, nM, nF), dtype=torch.float64, device=device)
+    if not (out.is_cuda and out.dtype == torch.float64 and tuple(out.shape) == (8, nM, nF) and out.stride(2) == 1
+            and out.stride(0) >= nM * out.stride(1) and out.stride(1) >= nF):
+        raise ValueError("out must be float64 GPU [8, nM, nF] with unit column stride")
+    return out
 
 
 def chi2_cost8(sc_m, sc_f, out=None, path="auto"):
@@ -217,11 +244,7 @@ def chi2_cost8(sc_m, sc_f, out=None, path="auto"):
     m = [_desc(sc_m[k], "sc_m[%d]" % k) for k in range(2)]
     f = [_desc(sc_f[k], "sc_f[%d]" % k) for k in range(4)]
     nM, nF = m[0].shape[0], f[0].shape[0]
-    if out is None:
-        out = torch.empty((8, nM, nF), dtype=torch.float64, device=sc_m.device)
-    elif not (out.is_cuda and out.dtype == torch.float64 and tuple(out.shape) == (8, nM, nF) and out.stride(2) == 1
-              and out.stride(0) >= nM * out.stride(1) and out.stride(1) >= nF):
-        raise ValueError("out must be float64 GPU [8, nM, nF] with unit column stride")
+    out = _out8(out, nM, nF, sc_m.device)
     if path not in ("auto", "general", "symmetric"):
         raise ValueError("path must be 'auto', 'general' or 'symmetric'")
     sym = path == "symmetric" or (path == "auto" and chi2_symmetric(sc_m, sc_f))

@@ -47,7 +47,12 @@ class GpuBackend:
     def shape_context(self, xyz, c, md, x0, nf, row0, nrows):
         return self.K.shape_context(xyz, c, x0, md, nf, row0=row0, nrows=nrows)["hist"]
 
+    def symmetry_flag(self, sc_m, sc_f):
+        return self.K.chi2_symmetry_flag(sc_m, sc_f)
+
     def chi2_cost8(self, sc_m, sc_f, out=None):
+        if sc_f.shape[0] == 1:            # frame 1 only: gather_fixed_descriptors verified the permutation relation
+            return self.K.chi2_cost8_frame1(sc_m[0], sc_f[0], out=out)
         return self.K.chi2_cost8(sc_m, sc_f, out=out)
 
     def row_argmin(self, U):
@@ -130,9 +135,25 @@ def all_gather_rows(local, bounds, dim, group):
     return torch.cat([gathered[g].narrow(dim, 0, bounds[g + 1] - bounds[g]) for g in range(world)], dim=dim)
 
 
+def gather_fixed_descriptors(be, sc_m_loc, sc_f_loc, bounds, group=None):
+    """Complete fixed-cloud descriptors on every rank.  Frames 2..4 of get_unary are, for all but edge-case rows,
+    phi-sector permutations of frame 1: every rank verifies that bit for bit on its own rows of both
+    clouds, the flags are max-reduced (4 bytes), and if it holds everywhere only frame 1 travels — [1, M, 360], a
+    quarter of the bytes over xGMI; chi2_cost8 derives the rest.  Otherwise all four frames are gathered [4, M, 360]."""
+    _, world = _world(group)
+    if world == 1:
+        return sc_f_loc
+    dist = _dist()
+    flag = be.symmetry_flag(sc_m_loc, sc_f_loc)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()) == 0:
+        return all_gather_rows(sc_f_loc[:1].contiguous(), bounds, 1, group)
+    return all_gather_rows(sc_f_loc, bounds, 1, group)
+
+
 def build_descriptors(be, mov, fix, group=None):
     """Stages 526-545 of the widget: statistics and get_unary for both clouds.
-    -> (sc_m [2, rows_g, 360], sc_f [4, M, 360] complete, moving row bounds)."""
+    -> (sc_m [2, rows_g, 360], sc_f [4, M, 360] complete (or [1, M, 360], see gather_fixed_descriptors), moving row bounds)."""
     rank, world = _world(group)
     n, m = mov.shape[1], fix.shape[1]
     cm, mdm, x0m = be.stats(mov)
@@ -140,7 +161,7 @@ def build_descriptors(be, mov, fix, group=None):
     bn, bm = shard_bounds(n, world), shard_bounds(m, world)
     sc_m = be.shape_context(mov, cm, mdm, x0m, 2, bn[rank], bn[rank + 1] - bn[rank])
     sc_f_loc = be.shape_context(fix, cf, mdf, x0f, 4, bm[rank], bm[rank + 1] - bm[rank])
-    sc_f = all_gather_rows(sc_f_loc, bm, 1, group)
+    sc_f = gather_fixed_descriptors(be, sc_m, sc_f_loc, bm, group)
     return sc_m, sc_f, bn
 
 

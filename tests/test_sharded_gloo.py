@@ -15,6 +15,9 @@ import torch.multiprocessing as mp
 from conftest import ROOT, load_golden
 
 
+SYMMETRY_SEEN = []
+
+
 class OracleBackend:
     """Same interface as pipeline.GpuBackend, CPU tensors, arithmetic from oracle/ (tests only)."""
 
@@ -36,7 +39,22 @@ class OracleBackend:
         counts, totals = self.o.shape_context_counts(c.numpy(), float(md[0]), xyz.numpy(), "fixed" if nf == 4 else "moving", x0=x0.numpy())
         return torch.as_tensor(self.o.normalise_counts(counts, totals)[:, row0:row0 + nrows].copy())
 
+    @staticmethod
+    def _frames_from_first(f1):
+        s = f1.reshape(-1, 30, 12)
+        q = np.arange(12)
+        return np.stack([s, s[:, :, (q + 6) % 12], s[:, :, 11 - q], s[:, :, (17 - q) % 12]]).reshape(4, -1, 360)
+
+    def symmetry_flag(self, sc_m, sc_f):
+        m, f = sc_m.numpy(), sc_f.numpy()
+        same = lambda a, b: np.array_equal(a.view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
+        ok = same(m, self._frames_from_first(m[0])[:2]) and same(f, self._frames_from_first(f[0]))
+        SYMMETRY_SEEN.append(ok)
+        return torch.tensor([0 if ok else 1], dtype=torch.int32)
+
     def chi2_cost8(self, sc_m, sc_f, out=None):
+        if sc_f.shape[0] == 1:
+            sc_f = torch.as_tensor(self._frames_from_first(sc_f[0].numpy()))
         U = [self.o.unary_distance_matrix(sc_m[int(h[0]) - 1].numpy(), sc_f[int(h[1]) - 1].numpy()) for h in self.o.HYPOTHESES]
         U = torch.as_tensor(np.stack(U))
         if out is not None:
@@ -117,8 +135,11 @@ def _worker(rank, world, port, name, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from platymatch_amd import pipeline as P
+        name, _, variant = name.partition("|")
         d = load_golden(name)
         be = OracleBackend()
+        if variant == "general":             # as if some row sat on a sector edge: all four frames must travel
+            be.symmetry_flag = lambda sc_m, sc_f: (SYMMETRY_SEEN.append(False), torch.tensor([1], dtype=torch.int32))[1]
         det = {}
         A_sc, A_icp, inl = P.estimate_transform(d["moving"], d["fixed"], ransac_trials=int(d["ransac_trials"]),
                                                 ransac_error=float(d["ransac_error"]), icp_iterations=int(d["icp_iters"]),
@@ -131,18 +152,22 @@ def _worker(rank, world, port, name, out_path):
         assert slabs[0][0] == bn[rank] and torch.equal(torch.cat([b for _, b in slabs], dim=1), U)
         amin = P.cost_row_argmins(be, mov, fix, 29, dist.group.WORLD)          # streamed in slabs, gathered
         np.savez(out_path % rank, A_sc=np.asarray(A_sc), A_icp=np.asarray(A_icp), inl=inl, residuals=det["residuals"],
-                 lsa_cols=np.stack([c for _, c in det["lsa"]]), U=U.numpy(), bounds=np.array(bn), amin=amin.numpy())
+                 lsa_cols=np.stack([c for _, c in det["lsa"]]), U=U.numpy(), bounds=np.array(bn), amin=amin.numpy(),
+                 sym=np.array(SYMMETRY_SEEN))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["synth96x128", "insitu02_affine"])
+@pytest.mark.parametrize("name", ["synth96x128", "insitu02_affine", "synth96x128|general"])
 def test_two_rank_pipeline_matches_single_process(tmp_path, oracle, name):
     world = 2
     out = str(tmp_path / "rank%d.npz")
     mp.spawn(_worker, args=(world, _free_port(), name, out), nprocs=world, join=True)
     r0, r1 = np.load(out % 0), np.load(out % 1)
+    name, _, variant = name.partition("|")
     d = load_golden(name)
+    # the frame-1-only gather was taken (generic data) unless the variant forbids it; both ranks decided alike
+    assert len(r0["sym"]) > 0 and np.array_equal(r0["sym"], r1["sym"]) and bool(r0["sym"].all()) == (variant != "general")
     # every rank returns the same thing
     for k in ("A_sc", "A_icp", "inl", "lsa_cols", "residuals", "amin"):
         assert np.array_equal(r0[k], r1[k]), k
