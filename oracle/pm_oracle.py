@@ -239,12 +239,14 @@ def draw_ransac_samples(n, min_samples, trials):
     return np.stack([np.random.choice(n, min_samples, replace=False) for _ in range(trials)]).astype(np.int32)
 
 
-def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transform="Affine"):
-    """shape_context.py:103-139.  First strictly-better trial wins; A_best starts as ones((4,4))."""
+def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transform="Affine", samples=None):
+    """shape_context.py:103-139.  First strictly-better trial wins; A_best starts as ones((4,4)).
+    `samples`: the index sets, if the caller has already drawn them with draw_ransac_samples (same RNG calls)."""
     moving_all, fixed_all = np.asarray(moving_all), np.asarray(fixed_all)
     if moving_all.shape[0] == 4 or fixed_all.shape[0] == 4:
         moving_all, fixed_all = moving_all[:3, :], fixed_all[:3, :]
-    samples = draw_ransac_samples(fixed_all.shape[1], min_samples, trials)
+    if samples is None:
+        samples = draw_ransac_samples(fixed_all.shape[1], min_samples, trials)
     fit = get_affine_transform if transform == "Affine" else get_similar_transform
     A = np.stack([fit(moving_all[:, s], fixed_all[:, s]) for s in samples]) if trials else np.zeros((0, 4, 4))
     inl = ransac_score(moving_all, fixed_all, A, error)

@@ -17,10 +17,14 @@
 
 namespace {
 
+// MT19937 with the 624 tempered outputs of a state block produced in one (vectorisable) sweep.  `pos` counts the
+// outputs of the current block already consumed, exactly NumPy's `pos`.
 struct MT {
     uint32_t *key;
     int pos;
-    void refill() {
+    uint32_t out[624];
+
+    void twist() {
         const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX = 0x9908b0dfu;
         int i;
         uint32_t y;
@@ -34,18 +38,25 @@ struct MT {
         }
         y = (key[623] & UPPER) | (key[0] & LOWER);
         key[623] = key[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX);
+    }
+    void temper() {
+        for (int i = 0; i < 624; i++) {
+            uint32_t y = key[i];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            out[i] = y;
+        }
+    }
+    void refill() {       // all outputs of the current block are consumed: advance the state by one block
+        twist();
+        temper();
         pos = 0;
     }
-    inline uint32_t next() {
-        if (pos == 624) refill();
-        uint32_t y = key[pos++];
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        return y;
-    }
 };
+
+constexpr int CHUNK = 64;
 
 }  // namespace
 
@@ -54,25 +65,50 @@ struct MT {
 extern "C" int pm_legacy_choice(uint32_t *key, int *pos, long n, int k, long trials, int32_t *out) {
     if (!key || !pos || !out || n <= 0 || k <= 0 || k > n || trials < 0 || n > 0x7fffffffL || *pos < 0 || *pos > 624)
         return PM_ERR_INVALID_ARG;
-    MT mt{key, *pos};
-    std::vector<int32_t> a((size_t)n);
-    uint32_t mask_for_top = (uint32_t)(n - 1);
-    mask_for_top |= mask_for_top >> 1; mask_for_top |= mask_for_top >> 2; mask_for_top |= mask_for_top >> 4;
-    mask_for_top |= mask_for_top >> 8; mask_for_top |= mask_for_top >> 16;
+    MT mt;
+    mt.key = key;
+    mt.pos = *pos;
+    mt.temper();                                        // outputs pos..623 of the block the caller's state is in
+    std::vector<int32_t> perm((size_t)n);
+    int32_t *__restrict a = perm.data();
+    const uint32_t *__restrict rnd = mt.out;           // locals the compiler can keep apart from the stores into a[]
+    int p = mt.pos;
     for (long t = 0; t < trials; ++t) {
-        for (long i = 0; i < n; ++i) a[(size_t)i] = (int32_t)i;
-        uint32_t mask = mask_for_top;
-        for (long i = n - 1; i >= 1; --i) {
-            const uint32_t max = (uint32_t)i;
-            while ((mask >> 1) >= max) mask >>= 1;          // smallest all-ones mask >= i (i only decreases)
-            uint32_t j;
-            while ((j = (mt.next() & mask)) > max) {}
-            const int32_t tmp = a[(size_t)i];
-            a[(size_t)i] = a[j];
-            a[j] = tmp;
+        for (long i = 0; i < n; ++i) a[i] = (int32_t)i;
+        // Fisher-Yates from the top, in runs of i that share one rejection mask (2^b - 1 for i in [2^(b-1), 2^b)).
+        // Two passes per chunk of generator outputs: (1) rejection only -- a draw is accepted if it is <= the current i,
+        // which then drops by one; accepted values are compacted without a data-dependent branch; (2) the swaps for the
+        // accepted values, in order.  Separating them keeps the ~30 % rejections out of the load/store stream.
+        long i = n - 1;
+        uint32_t js[CHUNK];
+        while (i >= 1) {
+            const uint32_t mask = 0xffffffffu >> __builtin_clz((uint32_t)i);   // smallest all-ones mask >= i
+            const long lo = (long)(mask >> 1) + 1;                             // last i that uses this mask
+            while (i >= lo) {
+                int cnt = 0;
+                long ii = i;
+                for (int q = 0; q < CHUNK && ii >= lo; ++q) {
+                    if (p == 624) {
+                        mt.refill();
+                        p = 0;
+                    }
+                    const uint32_t v = rnd[p++] & mask;
+                    const bool take = v <= (uint32_t)ii;
+                    js[cnt] = v;
+                    cnt += take;
+                    ii -= take;
+                }
+                for (int q = 0; q < cnt; ++q, --i) {
+                    const uint32_t j = js[q];
+                    const int32_t ai = a[i];
+                    a[i] = a[j];
+                    a[j] = ai;
+                }
+            }
         }
-        for (int q = 0; q < k; ++q) out[t * k + q] = a[(size_t)q];
+        for (int q = 0; q < k; ++q) out[t * k + q] = a[q];
     }
+    mt.pos = p;
     *pos = mt.pos;
     return PM_OK;
 }

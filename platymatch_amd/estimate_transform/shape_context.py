@@ -95,34 +95,38 @@ def _stacked(x, k):
     return nat.is_torch(x) and x.dim() == 3 and x.shape[0] == k and x.is_cuda
 
 
-def draw_ransac_samples(n, min_samples, trials):
+def draw_ransac_samples(n, min_samples, trials, rng=None):
     """The index sets do_ransac draws: one np.random.choice(n, min_samples, replace=False) per trial
     from NumPy's global RNG, in trial order (shape_context.py:122) — so np.random.seed(s) before a
-    call reproduces the reference's sets exactly."""
-    state = np.random.get_state()
+    call reproduces the reference's sets exactly.  `rng`: a np.random.RandomState to draw from instead of
+    the global one (RandomState(s) yields what np.random.seed(s) + the global generator would)."""
+    src = np.random if rng is None else rng
+    state = src.get_state()
     if state[0] != 'MT19937' or trials == 0 or n > 2 ** 31 - 1 or min_samples > n:
         # (min_samples > n raises inside np.random.choice exactly as in the reference)
-        return np.stack([np.random.choice(n, min_samples, replace=False) for _ in range(trials)]).astype(np.int32)
+        return np.stack([src.choice(n, min_samples, replace=False) for _ in range(trials)]).astype(np.int32)
     # Same generator outputs, consumed in C (pm_legacy_choice restates RandomState.choice -> permutation -> shuffle ->
-    # random_interval on MT19937); the advanced state is handed back so the global stream continues as NumPy's would.
+    # random_interval on MT19937); the advanced state is handed back so the stream continues as NumPy's would.
     import ctypes
     key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
     pos = ctypes.c_int(int(state[2]))
     out = np.empty((trials, int(min_samples)), dtype=np.int32)
     nat.check(nat.load().pm_legacy_choice(key.ctypes.data, ctypes.byref(pos), int(n), int(min_samples), int(trials),
                                           out.ctypes.data))
-    np.random.set_state(('MT19937', key, pos.value, state[3], state[4]))
+    src.set_state(('MT19937', key, pos.value, state[3], state[4]))
     return out
 
 
-def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transform='Affine', rows=None, cols=None):
+def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transform='Affine', rows=None, cols=None,
+              samples=None):
     """shape_context.py:103-139 -> (A_best 4 x 4, inliers_best).
 
     The host draws the index sets (same RNG calls as the reference); one kernel launch fits and
     scores every trial.  The first trial with strictly more inliers than all before it wins;
     with no inliers at all A_best stays np.ones((4, 4)), as in the reference (:119-120, 136-138).
     `rows`/`cols` (optional) select matched pairs without gathering on the host:
-    pairs are (moving_all[:, rows[k]], fixed_all[:, cols[k]])."""
+    pairs are (moving_all[:, rows[k]], fixed_all[:, cols[k]]).  `samples` (optional, [trials, min_samples] int32):
+    index sets already drawn with draw_ransac_samples (pipeline.estimate_transform draws them ahead of time)."""
     torch = nat.torch_mod()
     m, f = nat.to_dev(moving_all), nat.to_dev(fixed_all)
     if m.dim() != 2 or f.dim() != 2:
@@ -140,7 +144,12 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
     ones = np.ones((4, 4))
     if trials <= 0:
         return (torch.as_tensor(ones, device=m.device) if nat.is_torch(moving_all) else ones), 0
-    samples = draw_ransac_samples(n, int(min_samples), trials)
+    if samples is None:
+        samples = draw_ransac_samples(n, int(min_samples), trials)
+    else:
+        samples = np.ascontiguousarray(samples, dtype=np.int32)
+        if samples.shape != (trials, int(min_samples)):
+            raise ValueError("samples must be [trials, min_samples]")
     if transform == 'Affine':
         if int(min_samples) != 4:
             raise ValueError("the device path fits the affine through exactly 4 pairs (the widget's default, "

@@ -34,11 +34,17 @@ def linear_sum_assignment(cost_matrix):
 
 
 def solve_many(cost_matrices, threads=None):
-    """linear_sum_assignment for each matrix, concurrently (the foreign call releases the GIL) -> list of (rows, cols)."""
+    """linear_sum_assignment for each matrix, concurrently (the foreign call releases the GIL) -> list of (rows, cols).
+    An entry may be a zero-argument callable producing the matrix (e.g. a device-to-host copy): it is called on the
+    worker thread, so fetching one matrix overlaps with solving another."""
     mats = list(cost_matrices)
     if threads is None:
         threads = min(len(mats), os.cpu_count() or 1, 8)
+
+    def one(m):
+        return linear_sum_assignment(m() if callable(m) else m)
+
     if threads <= 1 or len(mats) <= 1:
-        return [linear_sum_assignment(m) for m in mats]
+        return [one(m) for m in mats]
     with ThreadPoolExecutor(max_workers=threads) as ex:
-        return list(ex.map(linear_sum_assignment, mats))
+        return list(ex.map(one, mats))

@@ -58,10 +58,14 @@ class GpuBackend:
     def row_argmin(self, U):
         return self.K.row_argmin(U)
 
-    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples):
+    def draw_samples(self, n, min_samples, trials, rng=None):
+        from .estimate_transform.shape_context import draw_ransac_samples
+        return draw_ransac_samples(n, min_samples, trials, rng=rng)
+
+    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples, samples=None):
         from .estimate_transform.shape_context import do_ransac
         return do_ransac(mov, fix, min_samples=min_samples, trials=trials, error=error, transform=transform,
-                         rows=rows, cols=cols)
+                         rows=rows, cols=cols, samples=samples)
 
     def fit(self, kp_m, kp_f, transform):
         from .estimate_transform.find_transform import get_affine_transform, get_similar_transform
@@ -214,7 +218,16 @@ def assign(U_loc, bounds, group=None):
     import torch
     rank, world = _world(group)
     if world == 1:
-        return solve_many([U_loc[h].cpu().numpy() for h in range(8)])       # eight host threads, GIL released
+        # eight host threads, GIL released in the copy and in the solver: thread h fetches its matrix and starts solving
+        # while the later matrices are still crossing PCIe
+        stream = torch.cuda.current_stream(U_loc.device) if U_loc.is_cuda else None
+
+        def fetch(h):
+            if stream is None:
+                return U_loc[h].numpy()
+            with torch.cuda.stream(stream):
+                return U_loc[h].cpu().numpy()
+        return solve_many([lambda h=h: fetch(h) for h in range(8)])
     dist = _dist()
     n = bounds[-1]
     biggest = max(bounds[g + 1] - bounds[g] for g in range(world))
@@ -299,9 +312,48 @@ def pca_alignment(moving, fixed):
     return mt.cpu().numpy(), ft.cpu().numpy()
 
 
+class _SampleDraws:
+    """The index sets of the eight RANSAC runs, drawn on a helper thread while the Hungarian solves run.
+
+    What do_ransac draws depends only on the number of matched pairs (min(N, M)), min_samples and trials — not on the
+    matching — so the 8 x trials np.random.choice calls (each a full permutation of the pair list: the dominant host cost
+    after the solver) need not wait for it.  The draws come from NumPy's global generator in exactly the order the
+    reference consumes it (optional seed, then run 11, 12, ... 24), under _RNG_LOCK.  `private` (seeded runs of a
+    batch): draw from a RandomState(seed) of the run's own instead — the same sets, but runs no longer queue for the
+    global generator (whose state after a batch of concurrent runs would be order-dependent anyway)."""
+
+    def __init__(self, be, n_pairs, min_samples, trials, seed, private=False):
+        import threading
+        self.sets, self.error = None, None
+
+        def work():
+            try:
+                if trials <= 0:
+                    self.sets = [None] * 8
+                elif private and seed is not None:
+                    rng = np.random.RandomState(seed)
+                    self.sets = [be.draw_samples(n_pairs, min_samples, trials, rng=rng) for _ in range(8)]
+                else:
+                    with _RNG_LOCK:
+                        if seed is not None:
+                            np.random.seed(seed)
+                        self.sets = [be.draw_samples(n_pairs, min_samples, trials) for _ in range(8)]
+            except BaseException as e:                # e.g. min_samples > n: raised where the reference would raise it
+                self.error = e
+
+        self.thread = threading.Thread(target=work, name="pm-ransac-draws")
+        self.thread.start()
+
+    def result(self):
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+        return self.sets
+
+
 def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
                        ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, group=None,
-                       backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS):
+                       backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS, private_rng=False):
     """Reproduces _dock_widget.py:526-718 -> (A_sc, A_icp, inliers[8]); final transform = A_icp @ A_sc (:428).
 
     moving, fixed   3 x N / 3 x M float64 (rows z, y, x), NumPy or torch
@@ -310,6 +362,8 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     ransac_error    16 for CSV detections (_dock_widget.py:613-614); with nucleus sizes the widget uses
                     0.5 * (mean(size_m)**(1/3) + mean(size_f)**(1/3)) — pass that value
     seed            if not None, np.random.seed(seed) right before the eight RANSAC runs
+    private_rng     with a seed: draw from a private RandomState(seed) and leave NumPy's global generator untouched
+                    (same index sets; what estimate_transform_batch uses so that concurrent runs do not queue)
     group           torch.distributed process group to shard over (None = this GPU only); every rank
                     passes the same clouds and gets the same results
     icp_shard_min_points  moving-cloud size from which ICP is sharded too (below it every rank runs it whole)
@@ -322,17 +376,18 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     rank, world = _world(group)
     if mode == 'unsupervised':
         U, bn = build_costs(be, mov, fix, group)
-        lsa = assign(U, bn, group)
-        del U
+        draws = _SampleDraws(be, min(mov.shape[1], fix.shape[1]), int(ransac_samples), int(ransac_trials), seed, private_rng)
+        try:
+            lsa = assign(U, bn, group)
+        finally:
+            del U
+            sets = draws.result()                    # every rank draws the same 8 x trials: same RNG stream everywhere
         A_h = []
-        with _RNG_LOCK:                              # NumPy's global generator is shared by every thread of a batch run
-            if seed is not None:
-                np.random.seed(seed)
-            for h, (r, c) in enumerate(lsa):        # every rank runs the same 8 x trials: same RNG stream everywhere
-                A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
-                                    ransac_samples)
-                A_h.append(nat.to_dev(A, dev=mov.device))
-                inliers[h] = k
+        for h, (r, c) in enumerate(lsa):
+            A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
+                                ransac_samples, samples=sets[h])
+            A_h.append(nat.to_dev(A, dev=mov.device))
+            inliers[h] = k
         A_sc = A_h[int(np.argmax(inliers))]          # first maximum (_dock_widget.py:683-703)
         if details is not None:
             details.update(lsa=lsa, ransac_A=torch.stack(A_h).cpu().numpy())
@@ -360,8 +415,8 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
 def estimate_transform_batch(pairs, workers=4, seeds=None, **kwargs):
     """Several independent registrations on one GPU (BASELINE config 5: "replicas only", no collective): each worker thread
     drives its pairs on its own HIP stream, so the GPU stages of different pairs overlap, the Hungarian solves (GIL-free,
-    lsap.py) run concurrently on the host, and only the RANSAC stage — which draws from NumPy's global generator exactly as
-    the reference does — is serialised.  pairs: iterable of (moving, fixed); seeds: optional per-pair RANSAC seeds.
+    lsap.py) run concurrently on the host.  Seeded pairs draw their RANSAC index sets from a private RandomState(seed) (the
+    sets np.random.seed(seed) would give); unseeded pairs draw from NumPy's global generator one after the other.  pairs: iterable of (moving, fixed); seeds: optional per-pair RANSAC seeds.
     -> list of (A_sc, A_icp, inliers) in input order, each identical to a stand-alone estimate_transform call."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
@@ -375,7 +430,7 @@ def estimate_transform_batch(pairs, workers=4, seeds=None, **kwargs):
     def one(k):
         stream = torch.cuda.Stream(device=dev)
         with torch.cuda.device(dev), torch.cuda.stream(stream):
-            out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], **kwargs)
+            out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, **kwargs)
             stream.synchronize()
         return out
 

@@ -37,6 +37,17 @@ def test_ransac_draws_follow_the_reference_rng_sequence(oracle):
     b = draw_ransac_samples(100, 4, 10)          # second call continues the stream: eight hypotheses draw one after another
     np.random.seed(5)
     assert np.array_equal(np.concatenate([a, b]), np.stack([np.random.choice(100, 4, replace=False) for _ in range(20)]))
+    # a private RandomState(seed) gives what np.random.seed(seed) + the global generator gives, and leaves the latter alone;
+    # sizes chosen so that draws start at every kind of position inside a 624-word state block, 1, 2 and 3 also as k
+    np.random.seed(77)
+    before = np.random.get_state()
+    for n, k in ((1, 1), (2, 2), (3, 3), (9, 4), (1023, 4), (1024, 4), (1025, 3), (33000, 4)):
+        rng = np.random.RandomState(n)
+        got = np.concatenate([draw_ransac_samples(n, k, 7, rng=rng) for _ in range(3)])
+        np.random.seed(n)
+        want = np.stack([np.random.choice(n, k, replace=False) for _ in range(21)])
+        assert np.array_equal(got, want), (n, k)
+        np.random.set_state(before)
     import pytest
     with pytest.raises(ValueError):
         draw_ransac_samples(3, 4, 2)            # fewer pairs than samples: NumPy's own error, as in the reference

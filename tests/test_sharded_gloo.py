@@ -65,9 +65,13 @@ class OracleBackend:
     def row_argmin(self, U):
         return torch.as_tensor(np.argmin(U.numpy(), axis=-1).astype(np.int32))
 
-    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples):
+    def draw_samples(self, n, min_samples, trials, rng=None):
+        assert rng is None
+        return self.o.draw_ransac_samples(n, min_samples, trials)
+
+    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples, samples=None):
         A, k = self.o.do_ransac(mov.numpy()[:, rows], fix.numpy()[:, cols], min_samples=min_samples, trials=trials, error=error,
-                                transform=transform)
+                                transform=transform, samples=samples)
         return torch.as_tensor(np.asarray(A, dtype=np.float64)), k
 
     def fit(self, kp_m, kp_f, transform):

@@ -44,3 +44,10 @@ moved = be.apply_affine(P.nat.to_dev(A_sc, dev=mov.device), mov)
 A_icp = timed("ICP, 50 iterations (GPU)", lambda: be.icp(moved, fix, 50, "Affine", None))
 final = A_icp.cpu().numpy() @ (A_sc.cpu().numpy() if hasattr(A_sc, "cpu") else A_sc)
 print("inliers", inl, " rel. error vs ground truth %.2e" % (np.linalg.norm(final - A_gt) / np.linalg.norm(A_gt)))
+
+# the same registration through the driver, where the RANSAC index sets are drawn while the solver runs and each
+# solver thread fetches its own matrix
+t = time.perf_counter()
+A_sc2, A_icp2, inl2 = P.estimate_transform(mov, fix, ransac_trials=trials, ransac_error=16, icp_iterations=50, seed=0)
+torch.cuda.synchronize()
+print("%-34s %9.1f ms   (same inliers: %s)" % ("estimate_transform, whole", (time.perf_counter() - t) * 1e3, list(inl2) == inl))
