@@ -42,6 +42,28 @@ def test_identical_to_scipy_on_random_tied_rectangular_matrices():
     assert same(rng.random((600, 600))) and same(rng.random((300, 700))) and same(rng.random((700, 300)))
 
 
+def test_scalar_and_vector_paths_agree_with_scipy(monkeypatch):
+    """pm_lsap_solve has SciPy's scalar scan and an AVX-512 scan (column order + tie replay): both must be SciPy's
+    answer, also where ties are everywhere and the tie replay decides nearly every step."""
+    rng = np.random.default_rng(11)
+    mats = [rng.integers(0, 3, size=(97, 131)).astype(float), rng.integers(0, 5, size=(200, 200)).astype(float),
+            np.round(rng.random((150, 90)), 2), rng.random((257, 263)), np.zeros((33, 65)),
+            np.where(rng.random((120, 120)) < 0.3, np.inf, rng.integers(0, 4, size=(120, 120)).astype(float))]
+    for M in mats:
+        try:
+            want = scipy_lsa(M)
+        except ValueError:
+            want = None
+        for scalar in ("1", "0"):
+            monkeypatch.setenv("PM_LSAP_SCALAR", scalar)
+            if want is None:
+                with pytest.raises(ValueError):
+                    lsap.linear_sum_assignment(M)
+            else:
+                got = lsap.linear_sum_assignment(M)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (M.shape, scalar)
+
+
 def test_error_behaviour_like_scipy():
     for bad in (np.array([[1.0, np.nan], [0.0, 1.0]]), np.array([[1.0, -np.inf], [0.0, 1.0]])):
         with pytest.raises(ValueError):
