@@ -111,37 +111,56 @@ int pmo_mean_distance(const double *xyz, int n, double *out) {
  * p_i -> 0 and p_i+x,y,z -> e1,e2,e3, i.e. neighbour -> [x y z]^T (p_j - p_i):
  * this restatement projects directly (measured identical
  * integer histograms). */
-int pmo_shape_context_counts(const double *xyz, int n, const double *centroid, const double *x0,
-                             double mean_dist, int n_frames, int32_t *counts, int32_t *totals) {
+static void sc_one_point(const double *xyz, int n, int i, const double *centroid, const double *x0, double mean_dist,
+                         int n_frames, int32_t *counts, int32_t *totals, size_t frame_stride_counts, size_t frame_stride_totals) {
     const double *P0 = xyz, *P1 = xyz + n, *P2 = xyz + 2 * (size_t)n;
-    memset(counts, 0, sizeof(int32_t) * (size_t)n_frames * n * PM_NBINS);
-    memset(totals, 0, sizeof(int32_t) * (size_t)n_frames * n);
-    for (int i = 0; i < n; ++i) {
-        double p[3] = {P0[i], P1[i], P2[i]};
-        double w[3] = {p[0] - centroid[0], p[1] - centroid[1], p[2] - centroid[2]};
-        double nw = norm3(w[0], w[1], w[2]);
-        double z[3] = {w[0] / nw, w[1] / nw, w[2] / nw};                  /* :169 */
-        double d = dot3(x0, z);
-        double x[3] = {x0[0] - z[0] * d, x0[1] - z[1] * d, x0[2] - z[2] * d}; /* :170 */
-        double nx = norm3(x[0], x[1], x[2]);
-        x[0] /= nx; x[1] /= nx; x[2] /= nx;                                /* :171 */
-        double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]}; /* get_Y :6-8 */
-        double ny = norm3(y[0], y[1], y[2]);
-        y[0] /= ny; y[1] /= ny; y[2] /= ny;
-        /* frame 2: x0 -> -x0 gives (-x, -y) exactly (:172-175); frame 3: (x, -y); frame 4: (-x, +y) (:180-181) */
-        static const double SX[4] = {1, -1, 1, -1}, SY[4] = {1, -1, -1, 1};
-        for (int j = 0; j < n; ++j) {
-            if (j == i) continue;                                          /* np.delete :168 */
-            double v[3] = {P0[j] - p[0], P1[j] - p[1], P2[j] - p[2]};
-            double vx = dot3(x, v), vy = dot3(y, v), vz = dot3(z, v);
-            for (int f = 0; f < n_frames; ++f) {
-                double idx = bin_index(SX[f] * vx, SY[f] * vy, vz, mean_dist);
-                if (idx >= 0 && idx < PM_NBINS && idx == floor(idx)) {
-                    counts[((size_t)f * n + i) * PM_NBINS + (int)idx] += 1;
-                    totals[(size_t)f * n + i] += 1;
-                }
+    double p[3] = {P0[i], P1[i], P2[i]};
+    double w[3] = {p[0] - centroid[0], p[1] - centroid[1], p[2] - centroid[2]};
+    double nw = norm3(w[0], w[1], w[2]);
+    double z[3] = {w[0] / nw, w[1] / nw, w[2] / nw};                  /* :169 */
+    double d = dot3(x0, z);
+    double x[3] = {x0[0] - z[0] * d, x0[1] - z[1] * d, x0[2] - z[2] * d}; /* :170 */
+    double nx = norm3(x[0], x[1], x[2]);
+    x[0] /= nx; x[1] /= nx; x[2] /= nx;                                /* :171 */
+    double y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]}; /* get_Y :6-8 */
+    double ny = norm3(y[0], y[1], y[2]);
+    y[0] /= ny; y[1] /= ny; y[2] /= ny;
+    /* frame 2: x0 -> -x0 gives (-x, -y) exactly (:172-175); frame 3: (x, -y); frame 4: (-x, +y) (:180-181) */
+    static const double SX[4] = {1, -1, 1, -1}, SY[4] = {1, -1, -1, 1};
+    for (int j = 0; j < n; ++j) {
+        if (j == i) continue;                                          /* np.delete :168 */
+        double v[3] = {P0[j] - p[0], P1[j] - p[1], P2[j] - p[2]};
+        double vx = dot3(x, v), vy = dot3(y, v), vz = dot3(z, v);
+        for (int f = 0; f < n_frames; ++f) {
+            double idx = bin_index(SX[f] * vx, SY[f] * vy, vz, mean_dist);
+            if (idx >= 0 && idx < PM_NBINS && idx == floor(idx)) {
+                counts[(size_t)f * frame_stride_counts + (int)idx] += 1;
+                totals[(size_t)f * frame_stride_totals] += 1;
             }
         }
+    }
+}
+
+int pmo_shape_context_counts(const double *xyz, int n, const double *centroid, const double *x0,
+                             double mean_dist, int n_frames, int32_t *counts, int32_t *totals) {
+    memset(counts, 0, sizeof(int32_t) * (size_t)n_frames * n * PM_NBINS);
+    memset(totals, 0, sizeof(int32_t) * (size_t)n_frames * n);
+    for (int i = 0; i < n; ++i)
+        sc_one_point(xyz, n, i, centroid, x0, mean_dist, n_frames, counts + (size_t)i * PM_NBINS, totals + i,
+                     (size_t)n * PM_NBINS, (size_t)n);
+    return 0;
+}
+
+/* The same for a list of query points only (against the whole cloud): counts [n_frames][n_rows][360], totals
+ * [n_frames][n_rows].  For checks at sizes where all N rows would take hours on one core. */
+int pmo_shape_context_rows(const double *xyz, int n, const int32_t *rows, int n_rows, const double *centroid, const double *x0,
+                           double mean_dist, int n_frames, int32_t *counts, int32_t *totals) {
+    memset(counts, 0, sizeof(int32_t) * (size_t)n_frames * n_rows * PM_NBINS);
+    memset(totals, 0, sizeof(int32_t) * (size_t)n_frames * n_rows);
+    for (int r = 0; r < n_rows; ++r) {
+        if (rows[r] < 0 || rows[r] >= n) return -1;
+        sc_one_point(xyz, n, rows[r], centroid, x0, mean_dist, n_frames, counts + (size_t)r * PM_NBINS, totals + r,
+                     (size_t)n_rows * PM_NBINS, (size_t)n_rows);
     }
     return 0;
 }

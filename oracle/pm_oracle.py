@@ -175,6 +175,21 @@ def shape_context_counts(centroid, mean_distance, detections, type, transposed=F
     return counts, totals
 
 
+def shape_context_counts_rows(centroid, mean_distance, detections, type, rows, x0):
+    """shape_context_counts for the listed query points only: counts [F][len(rows)][360], totals [F][len(rows)]."""
+    x = _cloud3(detections, False)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    c = _f64(np.asarray(centroid, dtype=np.float64).reshape(-1)[:3])
+    nf = 4 if type == "fixed" else 2
+    counts = np.zeros((nf, rows.size, 360), dtype=np.int32)
+    totals = np.zeros((nf, rows.size), dtype=np.int32)
+    rc = lib().pmo_shape_context_rows(_p(x), ctypes.c_int(x.shape[1]), _p(rows), ctypes.c_int(rows.size), _p(c), _p(_f64(x0)),
+                                      ctypes.c_double(float(mean_distance)), ctypes.c_int(nf), _p(counts), _p(totals))
+    if rc != 0:
+        raise IndexError("row outside the cloud")
+    return counts, totals
+
+
 def normalise_counts(counts, totals):
     """sc = sc / sc.sum() (shape_context.py:41); a row with nothing counted becomes NaN, as 0/0 does there."""
     with np.errstate(invalid="ignore", divide="ignore"):

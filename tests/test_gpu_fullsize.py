@@ -91,3 +91,41 @@ def test_fused_icp_loop_equals_stepwise_loop(big):
         assert float(parts[0] / parts[1]) == float(res[it])
     assert t.equal(A.reshape(16), A2) and t.equal(work, loc)
     assert float(res[-1]) < float(res[0])
+
+
+def test_config4_rank_slice_row_argmins_equal_cpu():
+    """BASELINE config 4 (200k x 200k chi-square rows sharded over 8 GPUs, indices checked against the CPU), one rank's
+    code path on a slice: descriptors of 200 000-point clouds, 1 024 cost rows x 200 000 columns x 8 matrices, row
+    arg-mins on the device.  The oracle (one core) follows on samples: histograms of sampled rows of both clouds bit for
+    bit, then complete cost rows -- all 200 000 columns, all 8 matrices -- and their arg-min indices for 4 moving rows."""
+    import torch
+    import bench
+    import oracle
+    from platymatch_amd import _kernels as K, _native as nat
+    n, r0, R = 200_000, 100_000, 1024
+    dev = torch.device("cuda:0")
+    mv, fx, _ = bench.synth(n, seed=4)
+    mov, fix = nat.to_dev(mv, dev=dev), nat.to_dev(fx, dev=dev)
+    sm = (K.centroid(mov), K.pca_axis(mov), K.mean_distance(mov))
+    sf = (K.centroid(fix), K.pca_axis(fix), K.mean_distance(fix))
+    hm = K.shape_context(mov, *sm, 2, row0=r0, nrows=R)["hist"]
+    hf = K.shape_context(fix, *sf, 4)["hist"]                                   # [4, 200000, 360]
+    U = K.chi2_cost8(hm, hf)                                                   # [8, 1024, 200000]
+    idx = K.row_argmin(U)
+    assert tuple(U.shape) == (8, R, n) and bool(torch.isfinite(U).all())
+
+    cm, x0m, mdm = (t.cpu().numpy() for t in sm)
+    cf, x0f, mdf = (t.cpu().numpy() for t in sf)
+    rows_m = np.array([0, 333, 700, R - 1])
+    cnt, tot = oracle.shape_context_counts_rows(cm, float(mdm[0]), mv, "moving", r0 + rows_m, x0m)
+    assert np.array_equal(oracle.normalise_counts(cnt, tot), hm[:, rows_m].cpu().numpy())
+    rows_f = np.random.default_rng(0).choice(n, 48, replace=False)
+    cnt, tot = oracle.shape_context_counts_rows(cf, float(mdf[0]), fx, "fixed", rows_f, x0f)
+    assert np.array_equal(oracle.normalise_counts(cnt, tot), hf[:, torch.as_tensor(rows_f, device=dev)].cpu().numpy())
+
+    hf_h = hf.cpu().numpy()
+    hm_h = hm[:, rows_m].cpu().numpy()
+    for h, name in enumerate(oracle.HYPOTHESES):
+        want = oracle.unary_distance_matrix(hm_h[int(name[0]) - 1], hf_h[int(name[1]) - 1])     # 4 x 200000, exact float64
+        assert np.array_equal(want, U[h, rows_m].cpu().numpy()), name
+        assert np.array_equal(want.argmin(1), idx[h, rows_m].cpu().numpy()), name
