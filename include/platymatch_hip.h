@@ -236,8 +236,8 @@ int pm_icp_update(const double *sums, const double *origin6, double *mov, int n,
                   int m, const int32_t *nn, double *A_icp16, double *A_est16, double *residual_parts2,
                   void *ws, size_t ws_bytes, void *stream);
 
-/* Same as pm_icp_update with the 4x4 given by the caller instead of solved from sums
- * (transform='Similar': the quaternion eigen-problem of find_transform.py:55-66 stays on the host). */
+/* Same as pm_icp_update with the 4x4 given by the caller instead of solved from sums (a step fitted elsewhere:
+ * apply, residual and composition A_icp = A_est . A_icp of perform_icp.py:23-25 on the device). */
 int pm_icp_apply(const double *A_est16, double *mov, int n, const double *fix, int m, const int32_t *nn,
                  double *A_icp16, double *residual_parts2, void *ws, size_t ws_bytes, void *stream);
 

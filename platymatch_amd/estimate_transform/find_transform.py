@@ -31,48 +31,163 @@ def get_affine_transform(moving, fixed, with_ones=False):
     return nat.like_input(A, moving)
 
 
-def similar_from_sums(sums, origin6):
-    """Horn's closed form (find_transform.py:27-99) from the 24 moment sums of pm_icp_accumulate.
-    Tiny host step: a 4 x 4 eigen-decomposition.  Faithful to the reference's quirk at :60-66 —
-    after sorting by eigenvalue, q is ROW 0 of the eigenvector matrix, not column 0 — so, as in the
-    reference, the result depends on LAPACK's eigenvector signs."""
-    s = np.asarray(sums, dtype=np.float64)
-    o = np.asarray(origin6, dtype=np.float64)
-    n = s[0]
-    mb, fb = s[1:4] / n, s[4:7] / n
-    Sfm = s[13:22].reshape(3, 3) - n * np.outer(fb, mb)        # sum Y_r P_c (centred)
-    S = Sfm.T                                                   # S[a][b] = sum P_a Y_b   (:43-53)
-    (Sxx, Sxy, Sxz), (Syx, Syy, Syz), (Szx, Szy, Szz) = S
+def _rotation_from_N(N):
+    """[T, 4, 4] quaternion matrices -> [T, 3, 3] rotations the reference's way (:60-84): eigenvectors sorted by
+    decreasing eigenvalue, q = ROW 0 of that matrix, R = (Qbar^T Q)[1:, 1:]."""
+    T = N.shape[0]
+    w, V = np.linalg.eig(N)
+    if np.iscomplexobj(w):      # a stack turns complex as a whole if one member does: redo each on its own, as the reference would
+        pairs = [np.linalg.eig(N[t]) for t in range(T)]
+        q = np.stack([Vt[:, wt.argsort()[::-1]][0] for wt, Vt in pairs])
+    else:
+        order = np.argsort(w, axis=1)[:, ::-1]
+        q = np.take_along_axis(V, order[:, None, :], axis=2)[:, 0, :]           # row 0 of the sorted eigenvector matrix
+    q0, q1, q2, q3 = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    Qbar = np.stack([np.stack([q0, -q1, -q2, -q3], 1), np.stack([q1, q0, q3, -q2], 1), np.stack([q2, -q3, q0, q1], 1),
+                     np.stack([q3, q2, -q1, q0], 1)], 1)
+    Q = np.stack([np.stack([q0, -q1, -q2, -q3], 1), np.stack([q1, q0, -q3, q2], 1), np.stack([q2, q3, q0, -q1], 1),
+                  np.stack([q3, -q2, q1, q0], 1)], 1)
+    return np.einsum('tki,tkj->tij', Qbar, Q)[:, 1:, 1:]       # (Qbar^T Q)[1:, 1:], summed over k in order
+
+
+def _numpy_sum_rows(x):
+    """Row sums of x [T, n] in the order np.sum uses for a contiguous 1-D float64 array of n elements (NumPy's pairwise
+    summation: plain loop below 8 elements, eight running sums per block of up to 128, halves above that) —
+    restated so that T sums are taken at once without NumPy choosing another loop order for the 2-D array."""
+    n = x.shape[1]
+    if n < 8:
+        res = np.zeros(x.shape[0])
+        for i in range(n):
+            res = res + x[:, i]
+        return res
+    if n <= 128:
+        r = [x[:, j].copy() for j in range(8)]
+        top = n - (n % 8)
+        for i in range(8, top, 8):
+            for j in range(8):
+                r[j] = r[j] + x[:, i + j]
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        for i in range(top, n):
+            res = res + x[:, i]
+        return res
+    half = n // 2
+    half -= half % 8
+    return _numpy_sum_rows(x[:, :half]) + _numpy_sum_rows(x[:, half:])
+
+
+def similar_fit_batch(P, Y):
+    """get_similar_transform (find_transform.py:21-99) for T small sets of pairs at once: P, Y are [T, 3, k] -> [T, 4, 4].
+    Host NumPy, for the RANSAC fits of transform='Similar' (k = min_samples).
+
+    The reference takes ROW 0 of np.linalg.eig's eigenvector matrix (:60-66), so its result hangs on LAPACK's eigenvector
+    signs, and those flip when the 4 x 4 matrix N changes in the last bit.  N is therefore built with the reference's
+    operations in the reference's order, as they run on what do_ransac passes in (shape_context.py:123-124: 3 x k
+    arrays made by fancy indexing, i.e. Fortran-ordered): np.mean over such an array adds the k columns one after the
+    other; np.sum over each contiguous product vector is NumPy's pairwise sum; the sixteen entries are the reference's
+    expressions.  N is then bit-identical to the reference's and np.linalg.eig on the stack runs the same LAPACK call
+    per matrix.  What follows the eigenvectors (R, s, t) is smooth in its inputs and agrees to rounding."""
+    P = np.asarray(P, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    T, k = P.shape[0], P.shape[2]
+
+    def mean_columns(x):                                       # [T, 3, k] -> [T, 3, 1]
+        acc = x[:, :, 0].copy()
+        for j in range(1, k):
+            acc = acc + x[:, :, j]
+        return (acc / k)[:, :, None]
+
+    ct, cs = mean_columns(Y), mean_columns(P)                  # :27-28
+    Yp, Pp = Y - ct, P - cs                                    # :31-32
+    Px, Py, Pz = Pp[:, 0, :], Pp[:, 1, :], Pp[:, 2, :]
+    Yx, Yy, Yz = Yp[:, 0, :], Yp[:, 1, :], Yp[:, 2, :]
+    S = _numpy_sum_rows
+    Sxx, Sxy, Sxz = S(Yx * Px), S(Px * Yy), S(Px * Yz)         # :43-53
+    Syx, Syy, Syz = S(Py * Yx), S(Py * Yy), S(Py * Yz)
+    Szx, Szy, Szz = S(Pz * Yx), S(Pz * Yy), S(Pz * Yz)
+    N = np.empty((T, 4, 4))
+    N[:, 0] = np.stack([Sxx + Syy + Szz, Syz - Szy, -Sxz + Szx, Sxy - Syx], axis=1)                 # :55-58
+    N[:, 1] = np.stack([-Szy + Syz, Sxx - Szz - Syy, Sxy + Syx, Sxz + Szx], axis=1)
+    N[:, 2] = np.stack([Szx - Sxz, Syx + Sxy, Syy - Szz - Sxx, Syz + Szy], axis=1)
+    N[:, 3] = np.stack([-Syx + Sxy, Szx + Sxz, Szy + Syz, Szz - Syy - Sxx], axis=1)
+    R = _rotation_from_N(N)
+    D = np.zeros(T)
+    Sp = np.zeros(T)
+    for j in range(k):                                         # :86-91, one point at a time
+        D = D + ((Yx[:, j] * Yx[:, j] + Yy[:, j] * Yy[:, j]) + Yz[:, j] * Yz[:, j])
+        Sp = Sp + ((Px[:, j] * Px[:, j] + Py[:, j] * Py[:, j]) + Pz[:, j] * Pz[:, j])
+    sc = np.sqrt(D / Sp)
+    c = cs[:, :, 0]
+    Rc = (R[:, :, 0] * c[:, None, 0] + R[:, :, 1] * c[:, None, 1]) + R[:, :, 2] * c[:, None, 2]
+    A = np.zeros((T, 4, 4))
+    A[:, :3, :3] = sc[:, None, None] * R
+    A[:, :3, 3] = ct[:, :, 0] - sc[:, None] * Rc               # :94
+    A[:, 3, 3] = 1
+    return A
+
+
+def similar_transform_host(moving, fixed):
+    """get_similar_transform (find_transform.py:21-99) on host arrays, operation for operation in NumPy.
+
+    Why on the host, and why literally: the reference takes ROW 0 of np.linalg.eig's eigenvector matrix (:60-66) as
+    its quaternion, so its answer hangs on LAPACK's eigenvector signs; a one-ulp change of the input flips them in
+    about one fit out of ten (measured: DESIGN.md §2), and in the ICP loop every iteration feeds the next.  Only the
+    reference's own sequence of NumPy/BLAS/LAPACK calls on arrays of the same memory layout reproduces its result, so
+    that is what runs here (SURVEY.md §8a row 14 prescribes exactly this); the O(N M) work of the mode — descriptors,
+    costs, nearest neighbours, RANSAC scoring — stays on the device."""
+    moving, fixed = np.asarray(moving, dtype=np.float64), np.asarray(fixed, dtype=np.float64)
+    ct = np.mean(fixed, 1, keepdims=True)
+    cs = np.mean(moving, 1, keepdims=True)
+    Y = fixed[:3, :] - ct[:3, :]
+    P = moving[:3, :] - cs[:3, :]
+    Px, Py, Pz = P[0, :], P[1, :], P[2, :]
+    Yx, Yy, Yz = Y[0, :], Y[1, :], Y[2, :]
+    Sxx, Sxy, Sxz = np.sum(Yx * Px), np.sum(Px * Yy), np.sum(Px * Yz)
+    Syx, Syy, Syz = np.sum(Py * Yx), np.sum(Py * Yy), np.sum(Py * Yz)
+    Szx, Szy, Szz = np.sum(Pz * Yx), np.sum(Pz * Yy), np.sum(Pz * Yz)
     N = [[Sxx + Syy + Szz, Syz - Szy, -Sxz + Szx, Sxy - Syx],
          [-Szy + Syz, Sxx - Szz - Syy, Sxy + Syx, Sxz + Szx],
          [Szx - Sxz, Syx + Sxy, Syy - Szz - Sxx, Syz + Szy],
          [-Syx + Sxy, Szx + Sxz, Szy + Syz, Szz - Syy - Sxx]]
     w, V = np.linalg.eig(N)
     V = V[:, w.argsort()[::-1]]
-    q0, q1, q2, q3 = V[0]
+    q0, q1, q2, q3 = V[0]                                      # row 0, as the reference has it
     Qbar = [[q0, -q1, -q2, -q3], [q1, q0, q3, -q2], [q2, -q3, q0, q1], [q3, q2, -q1, q0]]
     Q = [[q0, -q1, -q2, -q3], [q1, q0, -q3, q2], [q2, q3, q0, -q1], [q3, -q2, q1, q0]]
     R = np.matmul(np.transpose(Qbar), Q)[1:, 1:]
-    D = s[22] - n * fb.dot(fb)                                  # sum |Y'|^2   (:89-91)
-    Sp = (s[7] + s[10] + s[12]) - n * mb.dot(mb)                # sum |P'|^2
+    D = Sp = 0
+    for i in range(Y.shape[1]):                                # :86-91
+        D += np.matmul(np.transpose(Y[:, i]), Y[:, i])
+        Sp += np.matmul(np.transpose(P[:, i]), P[:, i])
     sc = np.sqrt(D / Sp)
-    t = (fb + o[3:6]) - sc * R.dot(mb + o[0:3])
+    t = ct[:3, :] - sc * np.matmul(R, cs[:3, :])
     A = np.zeros((4, 4))
     A[:3, :3] = sc * R
-    A[:3, 3] = t
+    A[:3, 3:4] = t
     A[3, 3] = 1
     return A
 
 
+def apply_affine_host(moving, A):
+    """apply_transform.py:3-17 on host arrays with the reference's own calls (vstack + np.matmul): the Similar-mode
+    chain needs the moved cloud to the bit (see similar_transform_host)."""
+    moving = np.asarray(moving)
+    if moving.shape[0] == 4:
+        moving = moving[:3, :]
+    hom = np.vstack((moving, np.ones((1, moving.shape[1]))))
+    return np.matmul(A, hom)[:3, :]
+
+
 def get_similar_transform(moving, fixed):
-    """find_transform.py:21-99.  Moments are accumulated on the device; the 4 x 4 quaternion
-    eigen-problem is solved on the host (see similar_from_sums)."""
+    """find_transform.py:21-99 -> 4 x 4.  Host NumPy, the reference's operations in the reference's order (see
+    similar_transform_host); GPU tensors are brought to the host and the result returned as a tensor."""
     torch = nat.torch_mod()
-    m, f = nat.to_dev(moving), nat.to_dev(fixed)
-    if m.dim() != 2 or f.dim() != 2 or m.shape[1] != f.shape[1] or m.shape[0] < 3 or f.shape[0] < 3:
+    if nat.is_torch(moving) or nat.is_torch(fixed):
+        m = moving.detach().cpu().numpy() if nat.is_torch(moving) else np.asarray(moving)
+        f = fixed.detach().cpu().numpy() if nat.is_torch(fixed) else np.asarray(fixed)
+        A = similar_transform_host(m, f)
+        dev = moving.device if nat.is_torch(moving) else fixed.device
+        return torch.as_tensor(A, device=dev)
+    m, f = np.asarray(moving), np.asarray(fixed)
+    if m.ndim != 2 or f.ndim != 2 or m.shape[1] != f.shape[1] or m.shape[0] < 3 or f.shape[0] < 3:
         raise ValueError("moving and fixed must be 3 x N")
-    m, f = m[:3, :].contiguous(), f[:3, :].contiguous()
-    origin = torch.cat([m[:, 0], f[:, 0]]).contiguous()
-    sums = K.icp_accumulate(m, f, None, origin)
-    A = similar_from_sums(sums.cpu().numpy(), origin.cpu().numpy())
-    return torch.as_tensor(A, device=m.device) if nat.is_torch(moving) else A
+    return similar_transform_host(m, f)

@@ -3,7 +3,7 @@ import numpy as np
 
 from .. import _kernels as K
 from .. import _native as nat
-from .find_transform import similar_from_sums
+from .find_transform import apply_affine_host, similar_transform_host
 
 VERBOSE = True   # the reference prints one residual line per iteration (perform_icp.py:24)
 
@@ -13,8 +13,9 @@ def perform_icp(moving, fixed, icp_iterations=50, transform='Affine', log=None):
 
     'Affine': the whole loop (nearest neighbours, refit, apply, compose) is enqueued on the
     device in one call with no host synchronisation until the result is read.
-    'Similar': nearest neighbours, moment sums, application and composition run on the device;
-    the 4 x 4 quaternion eigen-problem per iteration is solved on the host.
+    'Similar': the nearest-neighbour search of every iteration runs on the device; the fit, the application and the
+    composition are the reference's own NumPy calls on the host (find_transform.similar_transform_host explains why
+    this mode can only be reproduced that way).
     `log`, if a dict, receives 'nn' [iters, N] int32, 'residuals' [iters] and 'moved' [3, N]."""
     torch = nat.torch_mod()
     m, f = nat.to_dev(moving), nat.to_dev(fixed)
@@ -27,17 +28,26 @@ def perform_icp(moving, fixed, icp_iterations=50, transform='Affine', log=None):
     if transform == 'Affine':
         A, res, nn_all = K.icp(m, f, iters, want_nn=want_nn)
     elif transform == 'Similar':
-        A = torch.eye(4, dtype=torch.float64, device=m.device)
-        origin = torch.cat([f[:, 0], f[:, 0]]).contiguous()
+        # host copies in the layout the caller gave (np.mean's summation order follows the memory layout)
+        mh = moving.detach().cpu().numpy() if nat.is_torch(moving) else np.asarray(moving, dtype=np.float64)
+        fh = fixed.detach().cpu().numpy() if nat.is_torch(fixed) else np.asarray(fixed, dtype=np.float64)
+        mh, fh = mh[:3, :], fh[:3, :]
+        A_h = np.identity(4)
+        grid = K.icp_grid(f) if iters else None
         res_l, nn_l = [], []
-        for _ in range(iters):
-            nn, _ = K.icp_nn(m, f, want_dist=False)
-            sums = K.icp_accumulate(m, f, nn, origin)
-            A_est = torch.as_tensor(similar_from_sums(sums.cpu().numpy(), origin.cpu().numpy()), device=m.device)
-            parts = K.icp_apply(A_est.reshape(16), m, f, nn, A.reshape(16))
-            res_l.append(parts[0] / parts[1])
+        for it in range(iters):
+            nn = K.icp_nn(m, f, want_dist=False, grid=grid)[0]
+            i2 = nn.cpu().numpy()
+            matched = fh[:, i2]                                  # perform_icp.py:20 (fancy index: column-ordered copy)
+            A_est = similar_transform_host(mh, matched)
+            mh = apply_affine_host(mh, A_est)                    # :23
+            res_l.append(np.mean(np.linalg.norm(mh - matched, axis=0)))      # get_error, utils.py:77-88
+            A_h = np.matmul(A_est, A_h)                          # :25
             nn_l.append(nn)
-        res = torch.stack(res_l) if res_l else torch.empty(0, dtype=torch.float64, device=m.device)
+            if it + 1 < iters or log is not None:
+                m = nat.to_dev(np.ascontiguousarray(mh), dev=f.device)
+        A = torch.as_tensor(A_h, device=f.device)
+        res = torch.as_tensor(np.asarray(res_l, dtype=np.float64), device=f.device)
         nn_all = torch.stack(nn_l) if (want_nn and nn_l) else None
     else:
         raise ValueError("transform must be 'Affine' or 'Similar'")

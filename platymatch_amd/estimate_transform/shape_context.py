@@ -159,10 +159,19 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
         mh, fh = m.cpu().numpy(), f.cpu().numpy()
         if rows is not None:
             mh, fh = mh[:, rows.cpu().numpy()], fh[:, cols.cpu().numpy()]
-        from .find_transform import similar_from_sums
-        A_h = np.stack([similar_from_sums(_host_sums(mh[:, s], fh[:, s]), np.zeros(6)) for s in samples])
+        from .find_transform import similar_fit_batch, similar_transform_host
+        A_h = similar_fit_batch(np.moveaxis(mh[:, samples], 0, 1), np.moveaxis(fh[:, samples], 0, 1))     # [trials, 3, k] each
         A = nat.to_dev(A_h, dev=m.device)
         inl = K.ransac_score(m, f, rows, cols, A, float(error))
+        inl_h = inl.cpu().numpy()
+        best = int(np.argmax(inl_h))
+        if inl_h[best] <= 0:
+            return (torch.as_tensor(ones, device=m.device) if nat.is_torch(moving_all) else ones), 0
+        # the winning trial refitted by the reference's own call sequence (the batch agrees with it to rounding, but
+        # what follows in this mode amplifies the last bit: find_transform.similar_transform_host)
+        s = samples[best]
+        A_best = similar_transform_host(mh[:, s], fh[:, s])
+        return (torch.as_tensor(A_best, device=m.device) if nat.is_torch(moving_all) else A_best), int(inl_h[best])
     else:
         raise ValueError("transform must be 'Affine' or 'Similar'")
     inl_h = inl.cpu().numpy()
@@ -171,19 +180,6 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
         return (torch.as_tensor(ones, device=m.device) if nat.is_torch(moving_all) else ones), 0
     A_best = A[best]
     return (A_best if nat.is_torch(moving_all) else A_best.cpu().numpy()), int(inl_h[best])
-
-
-def _host_sums(P, Y):
-    """24 moment sums (pm_icp_accumulate layout, origin 0) of a handful of sampled pairs — host side,
-    used only by the 'Similar' RANSAC fit whose eigen-problem is on the host anyway."""
-    s = np.zeros(24)
-    s[0] = P.shape[1]
-    s[1:4], s[4:7] = P.sum(1), Y.sum(1)
-    PP = P @ P.T
-    s[7:13] = [PP[0, 0], PP[0, 1], PP[0, 2], PP[1, 1], PP[1, 2], PP[2, 2]]
-    s[13:22] = (Y @ P.T).reshape(-1)
-    s[22] = (Y * Y).sum()
-    return s
 
 
 def get_unary(centroid, mean_distance, detections, type, transposed=False, x0=None):

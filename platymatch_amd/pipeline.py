@@ -397,7 +397,13 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         A_sc = be.fit(keypoints[0], keypoints[1], transform)
     else:
         raise ValueError("mode must be 'unsupervised' or 'supervised'")
-    moved = be.apply_affine(A_sc, mov)                                              # :714
+    if transform == 'Similar':
+        # this mode's chain is reproduced only by the reference's own NumPy calls (find_transform.similar_transform_host)
+        from .estimate_transform.find_transform import apply_affine_host
+        mov_h = moving.detach().cpu().numpy() if nat.is_torch(moving) else np.asarray(moving, dtype=np.float64)
+        moved = apply_affine_host(np.ascontiguousarray(mov_h[:3]), A_sc.cpu().numpy() if nat.is_torch(A_sc) else np.asarray(A_sc))
+    else:
+        moved = be.apply_affine(A_sc, mov)                                          # :714
     if world > 1 and transform == 'Affine' and mov.shape[1] >= icp_shard_min_points:
         A_icp, res = icp_sharded(be, moved, fix, int(icp_iterations), group)
         if details is not None:

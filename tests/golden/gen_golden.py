@@ -370,7 +370,34 @@ def next_rows(ref):
     return out
 
 
-ALL = ["next_rows", "micro", "synth128", "synth96x128", "insitu02_identity", "insitu02_affine", "insitu04_affine"]
+def similar_mode(ref):
+    """transform='Similar' end to end on a small pair: the per-trial fits of do_ransac on fancy-indexed samples (the memory
+    layout the reference hands to get_similar_transform matters: np.mean reduces an F-ordered 3 x k array sequentially),
+    the seeded do_ransac result, and a Similar-mode ICP."""
+    sc_mod, ft, at, icp_mod, utils = ref
+    rng = np.random.default_rng(21)
+    n = 150
+    mv = rng.normal(size=(3, n)) * np.array([[60.0], [40.0], [25.0]]) + 200.0
+    th = 0.3
+    Rz = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]])
+    fx = 1.2 * Rz @ mv + np.array([[10.0], [-20.0], [5.0]]) + rng.normal(scale=0.5, size=(3, n))
+    out = {"moving": mv, "fixed": fx}
+    for k in (4, 6, 9, 20):
+        np.random.seed(100 + k)
+        sets = np.stack([np.random.choice(n, k, replace=False) for _ in range(120)])
+        out["samples_k%d" % k] = sets.astype(np.int32)
+        out["fits_k%d" % k] = np.stack([ft.get_similar_transform(mv[:, s], fx[:, s]) for s in sets])
+    for k, trials, err in ((4, 400, 3.0), (9, 150, 3.0)):
+        np.random.seed(7)
+        A, inl = sc_mod.do_ransac(mv, fx, min_samples=k, trials=trials, error=err, transform='Similar')
+        out["ransac_A_k%d" % k], out["ransac_inliers_k%d" % k] = A, np.int64(inl)
+        out["ransac_args_k%d" % k] = np.array([k, trials, err, 7], dtype=np.float64)
+    A_icp = icp_mod.perform_icp(at.apply_affine_transform(mv, out["ransac_A_k4"]), fx, 12, 'Similar')
+    out["icp_A"] = A_icp
+    return out
+
+
+ALL = ["next_rows", "micro", "similar_mode", "synth128", "synth96x128", "insitu02_identity", "insitu02_affine", "insitu04_affine"]
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or ALL
@@ -384,6 +411,8 @@ if __name__ == "__main__":
             res = micro(ref)
         elif name == "next_rows":
             res = next_rows(ref)
+        elif name == "similar_mode":
+            res = similar_mode(ref)
         else:
             res, a_gt = scenario(ref, name)
             res["A_gt"] = a_gt

@@ -454,10 +454,46 @@ def test_icp_similar_mode(gpu, oracle):
     start = 1.01 * R @ (fx - fx.mean(1, keepdims=True)) + fx.mean(1, keepdims=True) + 0.5
     A = pi.perform_icp(start, fx, 15, "Similar")
     ref = oracle.perform_icp(start, fx, 15, "Similar")
-    assert relerr(A, ref) < 1e-8
+    assert np.array_equal(A, ref)                 # the reference's own host call sequence around the device NN search
 
 
 # ------------------------------------------------------------------------------------------------ whole path
+def test_similar_mode_matches_reference(gpu, oracle):
+    """transform='Similar'.  The reference's result in this mode hangs on LAPACK's eigenvector signs and a one-ulp change
+    of the input flips it in about one fit out of ten, so the product runs the reference's own host call
+    sequence for the fit and keeps the O(N M) work on the device.  Checked against the oracle on THIS machine bit for bit
+    (BLAS kernels differ between CPU models, the reference's result with them), and for the single-fit quantities against
+    the fixture the reference produced (similar_mode.npz)."""
+    import os
+    from conftest import GOLDEN
+    from platymatch_amd.estimate_transform.shape_context import do_ransac
+    from platymatch_amd.estimate_transform.apply_transform import apply_affine_transform
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    from platymatch_amd.estimate_transform import estimate_transform
+    d = np.load(os.path.join(GOLDEN, "similar_mode.npz"))
+    mv, fx = d["moving"], d["fixed"]
+    for k in (4, 9):
+        kk, trials, err, seed = d["ransac_args_k%d" % k]
+        np.random.seed(int(seed))
+        A, inl = do_ransac(mv, fx, min_samples=int(kk), trials=int(trials), error=err, transform="Similar")
+        np.random.seed(int(seed))
+        A_o, inl_o = oracle.do_ransac(mv, fx, min_samples=int(kk), trials=int(trials), error=err, transform="Similar")
+        assert inl == inl_o == int(d["ransac_inliers_k%d" % k])
+        assert np.array_equal(A, A_o) and relerr(A, d["ransac_A_k%d" % k]) < 1e-12
+    pi.VERBOSE = False
+    start = oracle.apply_affine_transform(mv, d["ransac_A_k4"])
+    log = {}
+    A_icp = pi.perform_icp(start, fx, 12, "Similar", log=log)
+    olog = {}
+    A_ref = oracle.perform_icp(start, fx, 12, "Similar", log=olog)
+    assert np.array_equal(A_icp, A_ref)
+    assert np.array_equal(log["nn"], olog["nn"]) and np.array_equal(log["residuals"], olog["residuals"])
+    # the whole driver in this mode
+    got = estimate_transform(mv, fx, transform="Similar", ransac_trials=300, ransac_error=3.0, icp_iterations=8, seed=5)
+    ref = oracle.estimate_transform(mv, fx, transform="Similar", ransac_trials=300, ransac_error=3.0, icp_iterations=8, seed=5)
+    assert np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+
+
 @pytest.mark.parametrize("name", SCENARIOS)
 def test_estimate_transform_end_to_end(gpu, oracle, name):
     import platymatch_amd

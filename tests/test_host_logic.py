@@ -1,4 +1,6 @@
 """Host-side logic of the product that needs no GPU."""
+import os
+
 import numpy as np
 
 from conftest import load_golden
@@ -53,21 +55,21 @@ def test_ransac_draws_follow_the_reference_rng_sequence(oracle):
         draw_ransac_samples(3, 4, 2)            # fewer pairs than samples: NumPy's own error, as in the reference
 
 
-def test_similar_from_sums_matches_reference_closed_form(oracle):
-    """Horn's closed form rebuilt from moment sums (incl. the row-0 eigenvector quirk, find_transform.py:60-66)
-    against the oracle (itself bit-exact with the reference on micro.npz)."""
-    from platymatch_amd.estimate_transform.find_transform import similar_from_sums
-    from platymatch_amd.estimate_transform.shape_context import _host_sums
+def test_similar_transform_host_is_the_reference_to_the_bit(oracle):
+    """get_similar_transform's host restatement (row-0 eigenvector quirk and all, find_transform.py:21-99) against the
+    reference's own outputs: micro.npz (C-ordered inputs) and similar_mode.npz (do_ransac's fancy-indexed samples)."""
+    from conftest import GOLDEN
+    from platymatch_amd.estimate_transform.find_transform import apply_affine_host, get_similar_transform, similar_transform_host
     d = load_golden("micro")
     P, Q = d["fit_moving"], d["fit_fixed"]
-    for sl in (slice(None), slice(0, 4), slice(3, 12)):
-        A = similar_from_sums(_host_sums(P[:, sl], Q[:, sl]), np.zeros(6))
-        ref = oracle.get_similar_transform(P[:, sl], Q[:, sl])
-        assert np.abs(A - ref).max() < 1e-9 * np.abs(ref).max()
-    # with a non-zero origin (what the device accumulates about)
-    o = np.concatenate([P[:, 0], Q[:, 0]])
-    A = similar_from_sums(_host_sums(P - o[:3, None], Q - o[3:, None]), o)
-    assert np.abs(A - d["fit_similar"]).max() < 1e-9 * np.abs(d["fit_similar"]).max()
+    assert np.array_equal(similar_transform_host(P, Q), d["fit_similar"])
+    assert np.array_equal(get_similar_transform(P[:, :4], Q[:, :4]), d["fit_similar4"])          # NumPy in, NumPy out, no GPU involved
+    s = np.load(os.path.join(GOLDEN, "similar_mode.npz"))
+    mv, fx = s["moving"], s["fixed"]
+    for k in (4, 6, 9, 20):
+        got = np.stack([similar_transform_host(mv[:, i], fx[:, i]) for i in s["samples_k%d" % k]])
+        assert np.array_equal(got, s["fits_k%d" % k]), k
+    assert np.array_equal(apply_affine_host(mv, s["ransac_A_k4"]), oracle.apply_affine_transform(mv, s["ransac_A_k4"]))
 
 
 def test_legacy_get_bin_index_helper(micro):
@@ -103,3 +105,24 @@ def test_install_as_platymatch_aliases():
         for k in [k for k in sys.modules if k == "platymatch" or k.startswith("platymatch.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_similar_ransac_fits_follow_the_reference_bit_order():
+    """transform='Similar' RANSAC fits (similar_mode.npz: the reference's get_similar_transform on do_ransac's fancy-indexed
+    samples).  The 4 x 4 eigen-problem must be the reference's to the bit or LAPACK's eigenvector signs flip the result
+    (a few per cent of the trials with moments summed in any other order); after it, agreement is to rounding."""
+    from conftest import GOLDEN
+    from platymatch_amd.estimate_transform.find_transform import similar_fit_batch, _numpy_sum_rows
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 8, 9, 16, 31, 127, 128, 129, 136, 255, 257, 1000):
+        x = rng.normal(size=(40, n)) * 1e3
+        assert np.array_equal(_numpy_sum_rows(x), np.array([np.sum(r) for r in x])), n        # NumPy's own 1-D order
+    d = np.load(os.path.join(GOLDEN, "similar_mode.npz"))
+    mv, fx = d["moving"], d["fixed"]
+    for k in (4, 6, 9, 20):
+        S = d["samples_k%d" % k]
+        got = similar_fit_batch(np.moveaxis(mv[:, S], 0, 1), np.moveaxis(fx[:, S], 0, 1))
+        ref = d["fits_k%d" % k]
+        err = np.abs(got - ref).reshape(len(S), -1).max(1) / np.abs(ref).reshape(len(S), -1).max(1)
+        assert err.max() < 1e-12, (k, err.max())
+        assert np.array_equal(similar_fit_batch(np.moveaxis(mv[:, S[:1]], 0, 1), np.moveaxis(fx[:, S[:1]], 0, 1))[0], got[0])

@@ -105,3 +105,21 @@ def test_scenario_end_to_end(oracle, scenario):
     if name.startswith("insitu"):
         # the reference's own assertion (_tests/test_estimate_transform.py:72,140,208), decimal 6
         np.testing.assert_array_almost_equal(d["A_gt"], A_icp @ A_sc)
+
+
+def test_similar_mode_matches_reference(oracle):
+    """transform='Similar' (similar_mode.npz): per-sample fits, seeded do_ransac and a Similar-mode ICP, all bit for bit."""
+    from conftest import GOLDEN
+    import os
+    d = np.load(os.path.join(GOLDEN, "similar_mode.npz"))
+    mv, fx = d["moving"], d["fixed"]
+    for k in (4, 6, 9, 20):
+        got = np.stack([oracle.get_similar_transform(mv[:, s], fx[:, s]) for s in d["samples_k%d" % k]])
+        assert np.array_equal(got, d["fits_k%d" % k]), k
+    for k in (4, 9):
+        kk, trials, err, seed = d["ransac_args_k%d" % k]
+        np.random.seed(int(seed))
+        A, inl = oracle.do_ransac(mv, fx, min_samples=int(kk), trials=int(trials), error=err, transform="Similar")
+        assert np.array_equal(A, d["ransac_A_k%d" % k]) and inl == int(d["ransac_inliers_k%d" % k])
+    A_icp = oracle.perform_icp(oracle.apply_affine_transform(mv, d["ransac_A_k4"]), fx, 12, "Similar")
+    assert np.array_equal(A_icp, d["icp_A"])
