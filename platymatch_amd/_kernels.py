@@ -4,8 +4,6 @@ Every function validates shapes, dtypes and index ranges on the host before a ke
 enqueued (a faulting kernel can take the whole node down), allocates outputs/workspace with
 torch, and launches on torch's current stream.  Clouds are float64 [3, N] contiguous.
 """
-import numpy as np
-
 from . import _native as nat
 from ._native import NBINS, ICP_NSUMS, check, ptr
 

@@ -5,7 +5,6 @@ keeps the GIL, so those solves cannot overlap.  pm_lsap_solve restates SciPy 1.1
 (identical indices, ties included — tests/test_lsap.py checks it against SciPy itself) and is called through ctypes,
 which releases the GIL: `solve_many` runs the eight solves on eight host threads.  Host code only; nothing here runs on
 the GPU."""
-import ctypes
 import os
 from concurrent.futures import ThreadPoolExecutor
 

@@ -1,7 +1,6 @@
 """Pins the oracle (oracle/) to the unmodified reference: every fixture under tests/golden/ was
 produced by running the reference itself (gen_golden.py).  CPU only."""
 import numpy as np
-import pytest
 from scipy.optimize import linear_sum_assignment
 
 
