@@ -15,13 +15,13 @@
 
 namespace pm {
 
-int accumulate(const double *, int, const double *, int, const int32_t *, const double *, double *, double *, hipStream_t);
+// moment sums + solve + apply + residual of one iteration (pm_transform.hip)
+int refit_apply(double *mov, int n, const double *fix, int m, const int32_t *nn, const double *origin6, double *A_icp16,
+                double *mean_out, double *acc_ws, double *res_ws, unsigned int *done, hipStream_t s);
 // uniform-grid search (pm_icp_grid.hip): same results as the brute-force kernels below, O(N) instead of O(N*M) per iteration
 size_t grid_ws_bytes(int m);
 int grid_build(const double *fix, int m, void *ws, hipStream_t s);
 int grid_query(const double *mov, int n, int m, const void *ws, int32_t *nn, double *dist, hipStream_t s);
-int update(const double *, const double *, const double *, double *, int, const double *, int, const int32_t *, double *,
-           double *, double *, double *, double *, hipStream_t);
 
 constexpr int NN_THREADS = 256;
 constexpr int NN_TILE = 128;                   // moving points per wave (two per lane)
@@ -169,15 +169,17 @@ int nn_search(const double *mov, int n, const double *fix, int m, int32_t *nn, d
     return launch_status();
 }
 
-__global__ void icp_init_kernel(const double *__restrict__ fix, int m, double *__restrict__ origin6, double *__restrict__ A16) {
+__global__ void icp_init_kernel(const double *__restrict__ fix, int m, double *__restrict__ origin6, double *__restrict__ A16,
+                                unsigned int *done) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        *done = 0u;
         for (int c = 0; c < 3; ++c) { origin6[c] = fix[(size_t)c * m]; origin6[3 + c] = fix[(size_t)c * m]; }
         for (int k = 0; k < 16; ++k) A16[k] = (k % 5 == 0) ? 1.0 : 0.0;
     }
 }
 
 struct IcpWs {
-    size_t nn_ws, nn, acc_ws, sums, origin, total;
+    size_t nn_ws, nn, acc_ws, res_ws, done, origin, total;
 };
 
 inline IcpWs icp_layout(int n, int m) {
@@ -186,7 +188,8 @@ inline IcpWs icp_layout(int n, int m) {
     w.nn_ws = o; o += align_up(grid_ws_bytes(m), 256);
     w.nn = o; o += align_up((size_t)n * sizeof(int32_t), 256);
     w.acc_ws = o; o += align_up(pm_icp_accumulate_workspace(n), 256);
-    w.sums = o; o += 256;
+    w.res_ws = o; o += align_up(pm_icp_update_workspace(n), 256);
+    w.done = o; o += 256;
     w.origin = o; o += 256;
     w.total = o;
     return w;
@@ -242,21 +245,19 @@ int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_ic
     char *base = (char *)ws;
     int32_t *nn_buf = (int32_t *)(base + L.nn);
     double *acc_ws = (double *)(base + L.acc_ws);
-    double *sums = (double *)(base + L.sums);
+    double *res_ws = (double *)(base + L.res_ws);
+    unsigned int *done = (unsigned int *)(base + L.done);
     double *origin = (double *)(base + L.origin);
-    pm::icp_init_kernel<<<1, 64, 0, s>>>(fix, m, origin, A_icp16);
+    pm::icp_init_kernel<<<1, 64, 0, s>>>(fix, m, origin, A_icp16, done);
     if (iters > 0) {                                   // the fixed cloud never changes: bin it once
         int rc = pm::grid_build(fix, m, base + L.nn_ws, s);
         if (rc != PM_OK) return rc;
     }
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it < iters; ++it) {               // three launches per iteration: search, moments, solve + apply + residual
         int32_t *nn = nn_all ? nn_all + (size_t)it * n : nn_buf;
         int rc = pm::grid_query(mov, n, m, base + L.nn_ws, nn, nullptr, s);
         if (rc != PM_OK) return rc;
-        rc = pm::accumulate(mov, n, fix, m, nn, origin, sums, acc_ws, s);
-        if (rc != PM_OK) return rc;
-        rc = pm::update(sums, origin, nullptr, mov, n, fix, m, nn, A_icp16, nullptr, nullptr, residuals ? residuals + it : nullptr,
-                        acc_ws, s);
+        rc = pm::refit_apply(mov, n, fix, m, nn, origin, A_icp16, residuals ? residuals + it : nullptr, acc_ws, res_ws, done, s);
         if (rc != PM_OK) return rc;
     }
     return pm::launch_status();

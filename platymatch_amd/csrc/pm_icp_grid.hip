@@ -18,7 +18,9 @@ constexpr int GR_MAX_DIM = 512;
 // Cells per point.  Nucleus clouds are blobs, not uniform boxes: the bounding box is mostly empty and the core is
 // ~30x denser than the box average, so the grid is sized for ~1/8 point per cell on average (~4 in the core).
 constexpr int GR_CELLS_PER_POINT = 8;    // measured on the 50k blob: 1 -> 234, 2 -> 146, 4 -> 97, 8 -> 77, 16 -> 75 us per ICP iteration
-constexpr int GR_RING_CAP = 3;            // beyond this ring radius a group scans the whole cloud instead (sparse outliers)
+constexpr int GR_RING_CAP = 6;            // beyond this ring radius a group scans the whole cloud instead (sparse outliers)
+constexpr int GR_BATCH = 4;               // cells per lane whose ranges are fetched together
+constexpr int GR_LANES = 32;              // lanes per moving point (measured on the 50k blob: 4 -> 73, 8 -> 67, 16 -> 63, 32 -> 56 us per ICP iteration)
 
 struct GridHeader {          // lives at the start of the workspace, written by grid_plan_kernel
     double lo[3];            // bounding box minimum
@@ -182,15 +184,16 @@ __device__ __forceinline__ bool grid_better(double aS, int aI, double bS, int bI
     return (ra < rb) || (ra == rb && aI < bI);
 }
 
-// GR_LANES lanes cooperate on one moving point: lane l visits the cells l, l + GR_LANES, ... of the current ring's cube
-// (27 cells for rings 0 and 1 together), then the group's candidates are merged with the exact comparator.
-constexpr int GR_LANES = 32;
-
+// L lanes (a power of two <= 64) cooperate on one moving point: lane l takes the cells l, l + L, ... of the current pass
+// (the 3 x 3 x 3 cube around the home cell first, then shells of growing Chebyshev radius), GR_BATCH cells at a time —
+// the cell ranges of a batch are fetched together (independent loads, one round trip), then their points are compared —
+// and the group's candidates are merged with the exact comparator.
+template <int L>
 __global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__ mov, int n, const GridHeader *__restrict__ hdp,
                                                       const int *__restrict__ start, const double4 *__restrict__ pts,
                                                       int32_t *__restrict__ nn, double *__restrict__ dist) {
-    const int sub = threadIdx.x & (GR_LANES - 1);
-    const int i = (blockIdx.x * 256 + threadIdx.x) / GR_LANES;
+    const int sub = threadIdx.x & (L - 1);
+    const int i = (int)(((long)blockIdx.x * 256 + threadIdx.x) / L);
     const int ic = min(i, n - 1);                                 // surplus groups shadow the last point (no divergent exit before shuffles)
     const GridHeader hd = *hdp;
     const double p0 = mov[ic], p1 = mov[(size_t)n + ic], p2 = mov[2 * (size_t)n + ic];
@@ -200,28 +203,64 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__
     const int rmax = max(max(max(cx, hd.g[0] - 1 - cx), max(cy, hd.g[1] - 1 - cy)), max(cz, hd.g[2] - 1 - cz));
     double bS = INFINITY;
     int bI = 0x7fffffff;           // "nothing yet": loses every index tie; replaced by 0 at the end if nothing ever matched
-    auto visit = [&](int x, int y, int z) {
-        if (x < 0 || y < 0 || z < 0 || x >= hd.g[0] || y >= hd.g[1] || z >= hd.g[2]) return;
-        const int c = (z * hd.g[1] + y) * hd.g[0] + x;
-        const int q0 = start[c], q1 = start[c + 1];
-        for (int q = q0; q < q1; ++q) {
-            const double4 f = pts[q];
-            const double d0 = f.x - p0, d1 = f.y - p1, d2 = f.z - p2;
-            const double s = (d0 * d0 + d1 * d1) + d2 * d2;
-            const int j = (int)__double_as_longlong(f.w);
-            if (grid_better(s, j, bS, bI)) { bS = s; bI = j; }
+    // candidates q0, q0 + step, ... < q1, four loads in flight at a time
+    auto scan = [&](int q0, int q1, int step) {
+        for (int q = q0; q < q1; q += 4 * step) {
+            double4 f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f[u] = pts[(q + u * step < q1) ? q + u * step : q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double d0 = f[u].x - p0, d1 = f[u].y - p1, d2 = f[u].z - p2;
+                const double s = (d0 * d0 + d1 * d1) + d2 * d2;
+                const int j = (int)__double_as_longlong(f[u].w);
+                if (grid_better(s, j, bS, bI)) { bS = s; bI = j; }     // a clamped repeat of the last candidate changes nothing
+            }
+        }
+    };
+    // cells of the cube of radius r around the home cell; shell_only: those at Chebyshev distance exactly r
+    auto pass = [&](int r, bool shell_only) {
+        const int w = 2 * r + 1, cube = w * w * w;
+        for (int k0 = sub; k0 < cube; k0 += L * GR_BATCH) {
+            int q0[GR_BATCH], q1[GR_BATCH];
+#pragma unroll
+            for (int u = 0; u < GR_BATCH; ++u) {
+                const int k = k0 + u * L;
+                const int dz = k / (w * w) - r, rem = k % (w * w), dy = rem / w - r, dx = rem % w - r;
+                const int x = cx + dx, y = cy + dy, z = cz + dz;
+                const bool take = k < cube && (!shell_only || max(max(abs(dx), abs(dy)), abs(dz)) == r)
+                                  && x >= 0 && y >= 0 && z >= 0 && x < hd.g[0] && y < hd.g[1] && z < hd.g[2];
+                const int c = take ? (z * hd.g[1] + y) * hd.g[0] + x : 0;
+                q0[u] = start[c];
+                q1[u] = take ? start[c + 1] : q0[u];
+            }
+#pragma unroll
+            for (int u = 0; u < GR_BATCH; ++u) scan(q0[u], q1[u], 1);
         }
     };
     auto merge = [&]() {          // butterfly over the group: afterwards every lane holds the winner
 #pragma unroll
-        for (int off = GR_LANES / 2; off > 0; off >>= 1) {
+        for (int off = L / 2; off > 0; off >>= 1) {
             const double oS = __shfl_xor(bS, off, 64);
             const int oI = __shfl_xor(bI, off, 64);
             if (grid_better(oS, oI, bS, bI)) { bS = oS; bI = oI; }
         }
     };
-    // pass 1: rings 0 and 1 = the 3 x 3 x 3 cube around the home cell, one cell per lane (constant divisors)
-    if (sub < 27) visit(cx + sub % 3 - 1, cy + (sub / 3) % 3 - 1, cz + sub / 9 - 1);
+    // rings 0 and 1 together, the 3 x 3 x 3 cube around the home cell.  Cells adjacent in x are adjacent in memory, and so
+    // are their points: the cube is nine runs of (up to) three cells.  Three lanes share a run — the same two range
+    // loads, then interleaved points, so that neighbouring lanes touch neighbouring 32-byte records.
+    if (L >= 32) {
+        if (sub < 27) {
+            const int run = sub / 3, part = sub - 3 * run;
+            const int y = cy + run % 3 - 1, z = cz + run / 3 - 1;
+            if (y >= 0 && z >= 0 && y < hd.g[1] && z < hd.g[2]) {
+                const int row = (z * hd.g[1] + y) * hd.g[0];
+                scan(start[row + max(cx - 1, 0)] + part, start[row + min(cx + 1, hd.g[0] - 1) + 1], 3);
+            }
+        }
+    } else {
+        pass(1, false);
+    }
     merge();
     int r = 1;
     // everything not yet visited is farther than r*h (minus the rounding slack of the cell map)
@@ -230,7 +269,7 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__
         ++r;
         if (r > GR_RING_CAP) {                                  // sparse neighbourhood: scan every point (always exact)
             const int m_all = start[hd.ncells];
-            for (int q = sub; q < m_all; q += GR_LANES) {
+            for (int q = sub; q < m_all; q += L) {
                 const double4 f = pts[q];
                 const double d0 = f.x - p0, d1 = f.y - p1, d2 = f.z - p2;
                 const double s = (d0 * d0 + d1 * d1) + d2 * d2;
@@ -240,12 +279,7 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__
             merge();
             break;
         }
-        const int w = 2 * r + 1, cube = w * w * w;
-        for (int k = sub; k < cube; k += GR_LANES) {
-            const int dz = k / (w * w) - r, rem = k % (w * w), dy = rem / w - r, dx = rem % w - r;
-            if (max(max(abs(dx), abs(dy)), abs(dz)) < r) continue;               // interior: visited in earlier passes
-            visit(cx + dx, cy + dy, cz + dz);
-        }
+        pass(r, true);
         merge();
     }
     if (sub == 0 && i < n) {
@@ -273,8 +307,11 @@ int grid_build(const double *fix, int m, void *ws, hipStream_t s) {
 int grid_query(const double *mov, int n, int m, const void *ws, int32_t *nn, double *dist, hipStream_t s) {
     const GridWs L = grid_layout(m);
     const char *base = (const char *)ws;
-    grid_nn_kernel<<<(unsigned int)(((long)n * GR_LANES + 255) / 256), 256, 0, s>>>(mov, n, (const GridHeader *)(base + L.header), (const int *)(base + L.start),
-                                                   (const double4 *)(base + L.pts), nn, dist);
+    const GridHeader *hd = (const GridHeader *)(base + L.header);
+    const int *start = (const int *)(base + L.start);
+    const double4 *pts = (const double4 *)(base + L.pts);
+    const unsigned int blocks = (unsigned int)(((long)n * GR_LANES + 255) / 256);
+    grid_nn_kernel<GR_LANES><<<blocks, 256, 0, s>>>(mov, n, hd, start, pts, nn, dist);
     return launch_status();
 }
 

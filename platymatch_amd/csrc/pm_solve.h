@@ -14,7 +14,8 @@ __device__ __forceinline__ void solve_sym3(const double cmm[6], const double cfm
     const double i00 = d * f - e * e, i01 = c * e - b * f, i02 = b * e - c * d;
     const double i11 = a * f - c * c, i12 = b * c - a * e, i22 = a * d - b * b;
     const double det = (a * i00 + b * i01) + c * i02;
-    const double inv[9] = {i00 / det, i01 / det, i02 / det, i01 / det, i11 / det, i12 / det, i02 / det, i12 / det, i22 / det};
+    const double rdet = 1.0 / det;       // one division: this runs in a single lane on the critical path of every ICP iteration
+    const double inv[9] = {i00 * rdet, i01 * rdet, i02 * rdet, i01 * rdet, i11 * rdet, i12 * rdet, i02 * rdet, i12 * rdet, i22 * rdet};
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -24,9 +25,9 @@ __device__ __forceinline__ void solve_sym3(const double cmm[6], const double cfm
 
 // sums: PM_ICP_NSUMS layout about origin6 = {origin_m(3), origin_f(3)} -> A (4x4 row-major).
 __device__ __forceinline__ void affine_from_sums(const double *sums, const double *origin6, double A[16]) {
-    const double n = sums[0];
-    const double mb[3] = {sums[1] / n, sums[2] / n, sums[3] / n};
-    const double fb[3] = {sums[4] / n, sums[5] / n, sums[6] / n};
+    const double n = sums[0], rn = 1.0 / n;
+    const double mb[3] = {sums[1] * rn, sums[2] * rn, sums[3] * rn};
+    const double fb[3] = {sums[4] * rn, sums[5] * rn, sums[6] * rn};
     double cmm[6], cfm[9];
     cmm[0] = sums[7] - n * mb[0] * mb[0];
     cmm[1] = sums[8] - n * mb[0] * mb[1];

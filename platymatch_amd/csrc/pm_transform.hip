@@ -13,7 +13,7 @@
 namespace pm {
 
 constexpr int TF_THREADS = 256;
-constexpr int TF_PER_THREAD = 4;
+constexpr int TF_PER_THREAD = 2;
 constexpr int TF_BLOCK_PTS = TF_THREADS * TF_PER_THREAD;
 constexpr int NS = 22;   // accumulated slots (PM_ICP_NSUMS - count - pad)
 
@@ -26,13 +26,57 @@ __global__ __launch_bounds__(TF_THREADS) void apply_affine_kernel(const double *
     for (int r = 0; r < 3; ++r) out[(size_t)r * n + i] = ((A[4 * r] * x + A[4 * r + 1] * y) + A[4 * r + 2] * z) + A[4 * r + 3];
 }
 
-// per-block partial sums, slots 1..22 of the PM_ICP_NSUMS layout (slot 0, the count, is known)
+// Ordered sum over the blocks of one slot of the per-block partials: the same additions in the same order wherever
+// it is called from (accumulate_final, or every block of update_kernel in the fused loop).  Loads are issued eight
+// at a time so that the chain is one add per partial, not one memory round trip.
+// Ordered sum over the blocks of one slot of the per-block partials: t = (((0 + p[0]) + p[1]) + ...), the same additions
+// in the same order wherever it is called from.  Serial form (one thread per slot, loads issued eight at a time):
+__device__ __forceinline__ double ordered_partial_sum(const double *__restrict__ partial, int nblocks, int stride, int k) {
+    double t = 0.0;
+    int b = 0;
+    for (; b + 8 <= nblocks; b += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + u) * stride + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; b < nblocks; ++b) t += partial[(size_t)b * stride + k];
+    return t;
+}
+
+// Workgroup form of the same sums: all threads fetch a chunk of partials into LDS in one round trip, then thread k adds
+// slot k's values in block order.  COHERENT: the partials were written by other workgroups of the RUNNING kernel
+// (possibly on another XCD, behind another L2) and are read with device-scope atomic loads.  Result for slot k in
+// out_s[k] (k < nslots), valid after the call's final barrier.  stage: TF_STAGE doubles of LDS.
+constexpr int TF_STAGE = 2816;     // 128 blocks x 22 slots
+template <bool COHERENT>
+__device__ __forceinline__ void ordered_partial_sums_block(const double *__restrict__ partial, int nblocks, int nslots,
+                                                           double *__restrict__ stage, double *__restrict__ out_s) {
+    const int per = TF_STAGE / nslots;                   // blocks per chunk
+    double t = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += per) {
+        const int cnt = min(per, nblocks - b0) * nslots;
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt; e += blockDim.x)
+            stage[e] = COHERENT ? __hip_atomic_load(partial + (size_t)b0 * nslots + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : partial[(size_t)b0 * nslots + e];
+        __syncthreads();
+        if ((int)threadIdx.x < nslots)
+            for (int e = threadIdx.x; e < cnt; e += nslots) t += stage[e];
+    }
+    if ((int)threadIdx.x < nslots) out_s[threadIdx.x] = t;
+    __syncthreads();
+}
+
+// per-block partial sums, slots 1..22 of the PM_ICP_NSUMS layout (slot 0, the count, is known).
+// Fixed reduction tree: lane butterfly per wave (no barrier), then the block's waves in order.
 __global__ __launch_bounds__(TF_THREADS) void accumulate_kernel(const double *__restrict__ mov, int n,
                                                                 const double *__restrict__ fix, int m,
                                                                 const int32_t *__restrict__ nn,
                                                                 const double *__restrict__ origin6,
                                                                 double *__restrict__ partial) {
-    __shared__ double scratch[TF_THREADS / 64];
+    __shared__ double wsum[TF_THREADS / 64][NS];
     const double om0 = origin6[0], om1 = origin6[1], om2 = origin6[2];
     const double of0 = origin6[3], of1 = origin6[4], of2 = origin6[5];
     double s[NS];
@@ -55,10 +99,18 @@ __global__ __launch_bounds__(TF_THREADS) void accumulate_kernel(const double *__
             s[21] += (f0 * f0 + f1 * f1) + f2 * f2;
         }
     }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        double t = block_sum(s[k], scratch);
-        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * NS + k] = t;
+        const double t = wave_sum(s[k]);
+        if (lane == 0) wsum[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < TF_THREADS / 64; ++w) t += wsum[w][threadIdx.x];
+        partial[(size_t)blockIdx.x * NS + threadIdx.x] = t;
     }
 }
 
@@ -67,11 +119,7 @@ __global__ __launch_bounds__(64) void accumulate_final(const double *__restrict_
                                                        double *__restrict__ sums) {
     const int k = threadIdx.x;
     if (k == 0) sums[0] = (double)n;
-    if (k < NS) {
-        double t = 0.0;
-        for (int b = 0; b < nblocks; ++b) t += partial[(size_t)b * NS + k];
-        sums[1 + k] = t;
-    }
+    if (k < NS) sums[1 + k] = ordered_partial_sum(partial, nblocks, NS, k);
     if (k == NS) sums[1 + NS] = 0.0;
 }
 
@@ -83,19 +131,31 @@ __global__ void solve_kernel(const double *__restrict__ sums, const double *__re
     }
 }
 
-// mov <- A_est . mov ; residual partial ; block 0 composes A_icp <- A_est . A_icp
-__global__ __launch_bounds__(TF_THREADS) void update_kernel(const double *__restrict__ sums, const double *__restrict__ origin6,
+// mov <- A_est . mov ; residual partial ; block 0 composes A_icp <- A_est . A_icp.
+// A_est comes from `A_given`, or is solved from `sums`, or — fused ICP loop — from the per-block partials of
+// accumulate_kernel, which every block then sums itself in the fixed order (acc_partial != nullptr).
+// `done` (fused loop only): a counter the last block to finish uses to know it is last; it then adds the residual
+// partials in block order, writes the iteration's mean residual and re-arms the counter.
+__global__ __launch_bounds__(TF_THREADS) void update_kernel(const double *__restrict__ sums, const double *__restrict__ acc_partial,
+                                                            const double *__restrict__ origin6,
                                                             const double *__restrict__ A_given, double *mov, int n, const double *__restrict__ fix, int m,
                                                             const int32_t *__restrict__ nn, double *A_icp16, double *A_est16,
-                                                            double *__restrict__ partial) {
+                                                            double *__restrict__ partial, unsigned int *done, double *__restrict__ mean_out) {
     __shared__ double scratch[TF_THREADS / 64];
     __shared__ double As[16];
+    __shared__ double sums_s[PM_ICP_NSUMS];
+    __shared__ double stage[TF_STAGE];
+    __shared__ int is_last;
+    if (acc_partial) {
+        if (threadIdx.x == 0) { sums_s[0] = (double)n; sums_s[1 + NS] = 0.0; }
+        ordered_partial_sums_block<false>(acc_partial, gridDim.x, NS, stage, sums_s + 1);
+    }
     if (threadIdx.x == 0) {
         double A[16];
         if (A_given) {
             for (int k = 0; k < 16; ++k) A[k] = A_given[k];
         } else {
-            affine_from_sums(sums, origin6, A);   // identical operations in every block -> identical A_est
+            affine_from_sums(acc_partial ? sums_s : sums, origin6, A);   // identical operations in every block -> identical A_est
         }
         for (int k = 0; k < 16; ++k) As[k] = A[k];
         if (blockIdx.x == 0) {
@@ -132,13 +192,26 @@ __global__ __launch_bounds__(TF_THREADS) void update_kernel(const double *__rest
     }
     double t = block_sum(res, scratch);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    if (!done) return;
+    if (threadIdx.x == 0) {
+        __threadfence();                                              // this block's partial is visible before its ticket
+        is_last = (atomicAdd(done, 1u) == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (is_last) {                                                    // uniform per block
+        __threadfence();
+        ordered_partial_sums_block<true>(partial, gridDim.x, 1, stage, scratch);
+        if (threadIdx.x == 0) {
+            if (mean_out) mean_out[0] = scratch[0] / (double)n;
+            *done = 0u;                                               // re-armed for the next launch on this stream
+        }
+    }
 }
 
 __global__ void residual_final(const double *__restrict__ partial, int nblocks, int n, double *__restrict__ parts2,
                                double *__restrict__ mean_out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double t = 0.0;
-        for (int b = 0; b < nblocks; ++b) t += partial[b];
+        const double t = ordered_partial_sum(partial, nblocks, 1, 0);
         if (parts2) { parts2[0] = t; parts2[1] = (double)n; }
         if (mean_out) mean_out[0] = t / (double)n;
     }
@@ -176,8 +249,20 @@ int accumulate(const double *mov, int n, const double *fix, int m, const int32_t
 int update(const double *sums, const double *origin6, const double *A_given, double *mov, int n, const double *fix, int m,
            const int32_t *nn, double *A_icp16, double *A_est16, double *parts2, double *mean_out, double *ws, hipStream_t s) {
     const int nb = tf_blocks(n);
-    update_kernel<<<nb, TF_THREADS, 0, s>>>(sums, origin6, A_given, mov, n, fix, m, nn, A_icp16, A_est16, ws);
+    update_kernel<<<nb, TF_THREADS, 0, s>>>(sums, nullptr, origin6, A_given, mov, n, fix, m, nn, A_icp16, A_est16, ws, nullptr, nullptr);
     residual_final<<<1, 64, 0, s>>>(ws, nb, n, parts2, mean_out);
+    return launch_status();
+}
+
+// One refit + apply of the fused ICP loop in two launches: per-block moment partials, then a kernel whose every block
+// adds those partials in block order, solves, applies, and whose last block reduces the residual.  Same additions in
+// the same order as accumulate() + update(), hence the same bits.  acc_ws: tf_blocks(n) * NS doubles, res_ws: tf_blocks(n)
+// doubles, done: one zeroed counter.
+int refit_apply(double *mov, int n, const double *fix, int m, const int32_t *nn, const double *origin6, double *A_icp16,
+                double *mean_out, double *acc_ws, double *res_ws, unsigned int *done, hipStream_t s) {
+    const int nb = tf_blocks(n);
+    accumulate_kernel<<<nb, TF_THREADS, 0, s>>>(mov, n, fix, m, nn, origin6, acc_ws);
+    update_kernel<<<nb, TF_THREADS, 0, s>>>(nullptr, acc_ws, origin6, nullptr, mov, n, fix, m, nn, A_icp16, nullptr, res_ws, done, mean_out);
     return launch_status();
 }
 

@@ -513,6 +513,25 @@ def test_estimate_transform_end_to_end(gpu, oracle, name):
         np.testing.assert_array_almost_equal(d["A_gt"], A_icp @ A_sc)       # the reference's own assertion, decimal 6
 
 
+def test_estimate_transform_more_moving_than_fixed(gpu, oracle):
+    """N > M (the assignment leaves moving points unmatched; RANSAC and its draws run on the M matched pairs), 4 x N inputs."""
+    import platymatch_amd
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    mv, fx, _ = synth_pair(150, 9)
+    fx = fx[:, :110]
+    mv4, fx4 = np.vstack([mv, np.ones((1, 150))]), np.vstack([fx, np.ones((1, 110))])
+    det, odet = {}, {}
+    got = platymatch_amd.register(mv4, fx4, ransac_trials=300, ransac_error=8.0, icp_iterations=10, seed=3, details=det)
+    ref = oracle.estimate_transform(mv4, fx4, ransac_trials=300, ransac_error=8.0, icp_iterations=10, seed=3, details=odet)
+    for h in range(8):
+        assert np.array_equal(det["lsa"][h][0], odet["lsa"][h][0]) and np.array_equal(det["lsa"][h][1], odet["lsa"][h][1])
+        assert len(det["lsa"][h][0]) == 110
+    assert np.array_equal(got[2], ref[2])
+    assert relerr(got[0], ref[0]) < 1e-8 and relerr(got[1] @ got[0], ref[1] @ ref[0]) < 1e-8
+    assert np.array_equal(det["nn"], odet["nn"])
+
+
 def test_estimate_transform_supervised_and_api_kinds(gpu, oracle, micro):
     import platymatch_amd
     from platymatch_amd.estimate_transform import perform_icp as pi
