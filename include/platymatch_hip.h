@@ -60,6 +60,15 @@ int pm_centroid(const double *xyz, int n, double *out3, void *ws, size_t ws_byte
 size_t pm_mean_distance_workspace(int n);
 int pm_mean_distance(const double *xyz, int n, double *out1, void *ws, size_t ws_bytes, void *stream);
 
+/* The same in two steps, for a run sharded over G devices: pm_mean_distance_rows zeroes `partials`
+ * (pm_mean_distance_workspace(n) bytes: one float64 per 256 x 256 tile) and fills the tile rows row_offset,
+ * row_offset + row_stride, ... (rank g passes g, G); the ranks' buffers are then summed element-wise (an all-reduce:
+ * every entry is non-zero on one rank only, so the sum is exact) and pm_mean_distance_finish adds the tiles in the
+ * fixed order of pm_mean_distance — the result is bit-identical to the one-device call, whatever G. */
+int pm_mean_distance_rows(const double *xyz, int n, int row_offset, int row_stride, double *partials, size_t partial_bytes,
+                          void *stream);
+int pm_mean_distance_finish(const double *partials, int n, double *out1, void *stream);
+
 /* First principal axis as sklearn PCA(3).fit(X).components_[0] (shape_context.py:162-165):
  * unit eigenvector of the sample covariance with the largest eigenvalue, sign chosen so that its
  * largest-magnitude entry is positive.  out[3]. */

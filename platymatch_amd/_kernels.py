@@ -61,6 +61,33 @@ def mean_distance(xyz):
     return out
 
 
+def mean_distance_partials(xyz, row_offset, row_stride):
+    """Tile partial sums of the mean pairwise distance for the tile rows row_offset, row_offset + row_stride, ...
+    (zeros elsewhere) -> float64 GPU vector; ranks sum these element-wise, then mean_distance_finish."""
+    xyz = _cloud(xyz)
+    n = xyz.shape[1]
+    if n < 2:
+        raise ValueError("mean distance needs at least two points")
+    if not (0 <= int(row_offset) < int(row_stride)):
+        raise ValueError("need 0 <= row_offset < row_stride")
+    lib = nat.load()
+    nbytes = lib.pm_mean_distance_workspace(n)
+    part = _t().empty(nbytes // 8, dtype=_t().float64, device=xyz.device)
+    check(lib.pm_mean_distance_rows(ptr(xyz), n, int(row_offset), int(row_stride), ptr(part), nbytes, nat.stream_ptr()))
+    return part
+
+
+def mean_distance_finish(partials, n):
+    torch = _t()
+    lib = nat.load()
+    if not (nat.is_torch(partials) and partials.is_cuda and partials.dtype == torch.float64 and partials.is_contiguous()
+            and n >= 2 and partials.numel() * 8 >= lib.pm_mean_distance_workspace(n)):
+        raise ValueError("partials must be the float64 GPU vector mean_distance_partials returned for this n")
+    out = torch.empty(1, dtype=torch.float64, device=partials.device)
+    check(lib.pm_mean_distance_finish(ptr(partials), int(n), ptr(out), nat.stream_ptr()))
+    return out
+
+
 def pca_axis(xyz):
     xyz = _cloud(xyz)
     if xyz.shape[1] < 2:

@@ -23,9 +23,10 @@ __global__ __launch_bounds__(STAT_THREADS) void centroid_kernel(const double *__
 
 // ---- mean pairwise distance: upper-triangle tiles, then an ordered sum of the tile partials -------
 // One thread owns point i of tile bi and walks tile bj (staged in LDS, broadcast reads).
+// Tile rows row_offset, row_offset + row_stride, ... (ranks of a sharded run interleave the rows: row bi holds T - bi tiles).
 __global__ __launch_bounds__(MD_TILE) void mean_distance_tiles(const double *__restrict__ xyz, int n,
-                                                               double *__restrict__ partial) {
-    const int bi = blockIdx.y, bj = blockIdx.x, T = gridDim.x;
+                                                               double *__restrict__ partial, int row_offset, int row_stride) {
+    const int bi = row_offset + blockIdx.y * row_stride, bj = blockIdx.x, T = gridDim.x;
     if (bj < bi) return;  // partial[] for these is never read
     __shared__ double tj[3][MD_TILE];
     __shared__ double scratch[MD_TILE / 64];
@@ -164,8 +165,29 @@ int pm_mean_distance(const double *xyz, int n, double *out1, void *ws, size_t ws
     if (!ws || ws_bytes < pm_mean_distance_workspace(n)) return PM_ERR_WORKSPACE;
     const int T = (n + pm::MD_TILE - 1) / pm::MD_TILE;
     hipStream_t s = (hipStream_t)stream;
-    pm::mean_distance_tiles<<<dim3(T, T), pm::MD_TILE, 0, s>>>(xyz, n, (double *)ws);
+    pm::mean_distance_tiles<<<dim3(T, T), pm::MD_TILE, 0, s>>>(xyz, n, (double *)ws, 0, 1);
     pm::mean_distance_final<<<1, pm::STAT_THREADS, 0, s>>>((const double *)ws, T, n, out1);
+    return pm::launch_status();
+}
+
+int pm_mean_distance_rows(const double *xyz, int n, int row_offset, int row_stride, double *partials, size_t partial_bytes,
+                          void *stream) {
+    if (!xyz || !partials || n < 2 || row_offset < 0 || row_stride < 1 || row_offset >= row_stride) return PM_ERR_INVALID_ARG;
+    if (partial_bytes < pm_mean_distance_workspace(n)) return PM_ERR_WORKSPACE;
+    const int T = (n + pm::MD_TILE - 1) / pm::MD_TILE;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(partials, 0, pm_mean_distance_workspace(n), s) != hipSuccess) return pm::launch_status();
+    if (row_offset < T) {
+        const int rows = (T - row_offset + row_stride - 1) / row_stride;
+        pm::mean_distance_tiles<<<dim3(T, rows), pm::MD_TILE, 0, s>>>(xyz, n, partials, row_offset, row_stride);
+    }
+    return pm::launch_status();
+}
+
+int pm_mean_distance_finish(const double *partials, int n, double *out1, void *stream) {
+    if (!partials || !out1 || n < 2) return PM_ERR_INVALID_ARG;
+    const int T = (n + pm::MD_TILE - 1) / pm::MD_TILE;
+    pm::mean_distance_final<<<1, pm::STAT_THREADS, 0, (hipStream_t)stream>>>(partials, T, n, out1);
     return pm::launch_status();
 }
 

@@ -44,6 +44,15 @@ class GpuBackend:
     def stats(self, xyz):
         return self.K.centroid(xyz), self.K.mean_distance(xyz), self.K.pca_axis(xyz)
 
+    def mean_distance_partials(self, xyz, row_offset, row_stride):
+        return self.K.mean_distance_partials(xyz, row_offset, row_stride)
+
+    def mean_distance_finish(self, partials, n):
+        return self.K.mean_distance_finish(partials, n)
+
+    def centroid_and_axis(self, xyz):
+        return self.K.centroid(xyz), self.K.pca_axis(xyz)
+
     def shape_context(self, xyz, c, md, x0, nf, row0, nrows):
         return self.K.shape_context(xyz, c, x0, md, nf, row0=row0, nrows=nrows)["hist"]
 
@@ -139,6 +148,22 @@ def all_gather_rows(local, bounds, dim, group):
     return torch.cat([gathered[g].narrow(dim, 0, bounds[g + 1] - bounds[g]) for g in range(world)], dim=dim)
 
 
+def cloud_statistics(be, xyz, group=None):
+    """(centroid [3], mean pairwise distance [1], first PCA axis [3]) of one cloud, identical on every rank.
+    The O(N) parts are recomputed by every rank (same input, same reduction order, same bits).  The O(N^2) mean distance
+    is shared out: rank g adds up the 256 x 256 tiles of the tile rows g, g + G, ..., the tile sums (every one non-zero
+    on one rank only, so the element-wise all-reduce is exact) are combined, and every rank adds them in the fixed
+    order of the one-device kernel — the same bits as on one GPU, at 1/G of the pair work."""
+    rank, world = _world(group)
+    if world == 1:
+        return be.stats(xyz)
+    dist = _dist()
+    c, x0 = be.centroid_and_axis(xyz)
+    part = be.mean_distance_partials(xyz, rank, world)
+    dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    return c, be.mean_distance_finish(part, xyz.shape[1]), x0
+
+
 def gather_fixed_descriptors(be, sc_m_loc, sc_f_loc, bounds, group=None):
     """Complete fixed-cloud descriptors on every rank.  Frames 2..4 of get_unary are, for all but edge-case rows,
     phi-sector permutations of frame 1: every rank verifies that bit for bit on its own rows of both
@@ -160,8 +185,8 @@ def build_descriptors(be, mov, fix, group=None):
     -> (sc_m [2, rows_g, 360], sc_f [4, M, 360] complete (or [1, M, 360], see gather_fixed_descriptors), moving row bounds)."""
     rank, world = _world(group)
     n, m = mov.shape[1], fix.shape[1]
-    cm, mdm, x0m = be.stats(mov)
-    cf, mdf, x0f = be.stats(fix)
+    cm, mdm, x0m = cloud_statistics(be, mov, group)
+    cf, mdf, x0f = cloud_statistics(be, fix, group)
     bn, bm = shard_bounds(n, world), shard_bounds(m, world)
     sc_m = be.shape_context(mov, cm, mdm, x0m, 2, bn[rank], bn[rank + 1] - bn[rank])
     sc_f_loc = be.shape_context(fix, cf, mdf, x0f, 4, bm[rank], bm[rank + 1] - bm[rank])

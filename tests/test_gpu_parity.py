@@ -55,6 +55,25 @@ def test_statistics(gpu, oracle, name):
     assert np.abs(gpu.K.pca_axis(gpu.d(d["fixed"])).cpu().numpy() - d["x0_f"]).max() < 1e-11
 
 
+def test_mean_distance_shared_out_over_ranks_is_bit_identical(gpu):
+    """pm_mean_distance_rows / _finish: tile rows interleaved over G ranks, buffers summed element-wise (what the all-reduce
+    does), fixed-order finish -> the same bits as the one-device call, for any G (also G larger than the tile-row count)."""
+    t = gpu.t
+    for n, seed in ((2, 0), (257, 1), (1000, 2), (5000, 3)):
+        x = gpu.d(np.random.default_rng(seed).normal(size=(3, n)) * 50 + 100)
+        want = gpu.K.mean_distance(x)
+        for G in (1, 2, 3, 8, 64):
+            parts = [gpu.K.mean_distance_partials(x, g, G) for g in range(G)]
+            nz = t.stack([(p != 0) for p in parts]).sum(0)
+            assert int(nz.max()) <= 1                                  # every tile is computed by exactly one rank
+            total = parts[0].clone()
+            for p in parts[1:]:
+                total += p
+            assert t.equal(gpu.K.mean_distance_finish(total, n), want), (n, G)
+    with pytest.raises(ValueError):
+        gpu.K.mean_distance_partials(x, 3, 3)
+
+
 def test_statistics_ragged_sizes(gpu, oracle):
     for n in (2, 3, 63, 64, 65, 255, 256, 257, 1000, 4097):
         mv, _, _ = synth_pair(n, n)

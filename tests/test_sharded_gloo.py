@@ -16,6 +16,7 @@ from conftest import ROOT, load_golden
 
 
 SYMMETRY_SEEN = []
+MD_CALLS = []
 
 
 class OracleBackend:
@@ -34,6 +35,29 @@ class OracleBackend:
         return (torch.as_tensor(self.o.get_centroid(x, transposed=False).ravel().copy()),
                 torch.as_tensor(np.array([self.o.get_mean_distance(x, transposed=False)])),
                 torch.as_tensor(self.o.pca_axis(x.T)))
+
+    # sharded mean distance: the test double shares the pair sum out by point index instead of by tile, through the
+    # same three calls (partials -> all-reduce -> finish)
+    def centroid_and_axis(self, xyz):
+        x = xyz.numpy()
+        return torch.as_tensor(self.o.get_centroid(x, transposed=False).ravel().copy()), torch.as_tensor(self.o.pca_axis(x.T))
+
+    def mean_distance_partials(self, xyz, row_offset, row_stride):
+        x = xyz.numpy()
+        n = x.shape[1]
+        part = np.zeros(n)
+        self._last_cloud = x
+        for i in range(row_offset, n, row_stride):
+            part[i] = np.sqrt(((x[:, i + 1:] - x[:, i:i + 1]) ** 2).sum(0)).sum()
+        MD_CALLS.append((row_offset, row_stride))
+        return torch.as_tensor(part)
+
+    def mean_distance_finish(self, partials, n):
+        # the reference value itself, so that every downstream bit matches the fixtures; the all-reduced partials
+        # must add up to it
+        want = self.o.get_mean_distance(self._last_cloud, transposed=False)
+        assert abs(float(partials.sum()) / (0.5 * n * (n - 1)) - want) < 1e-9 * want
+        return torch.as_tensor(np.array([want]))
 
     def shape_context(self, xyz, c, md, x0, nf, row0, nrows):
         counts, totals = self.o.shape_context_counts(c.numpy(), float(md[0]), xyz.numpy(), "fixed" if nf == 4 else "moving", x0=x0.numpy())
