@@ -24,7 +24,8 @@ struct MT {
     int pos;
     uint32_t out[624];
 
-    void twist() {
+    // (both loops vectorise: the recurrence reaches back 227 words; clones are picked at load time by the CPU's features)
+    __attribute__((target_clones("avx512f", "avx2", "default"))) void twist() {
         const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX = 0x9908b0dfu;
         int i;
         uint32_t y;
@@ -39,7 +40,7 @@ struct MT {
         y = (key[623] & UPPER) | (key[0] & LOWER);
         key[623] = key[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX);
     }
-    void temper() {
+    __attribute__((target_clones("avx512f", "avx2", "default"))) void temper() {
         for (int i = 0; i < 624; i++) {
             uint32_t y = key[i];
             y ^= (y >> 11);
