@@ -551,6 +551,26 @@ def test_estimate_transform_more_moving_than_fixed(gpu, oracle):
     assert np.array_equal(det["nn"], odet["nn"])
 
 
+@pytest.mark.parametrize("n,m", [(5, 5), (8, 300), (300, 8), (4, 64)])
+def test_estimate_transform_small_and_lopsided(gpu, oracle, n, m):
+    """Tiny and very unequal clouds: min(N, M) matched pairs, as few as four (the RANSAC sample size)."""
+    import platymatch_amd
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    big = max(n, m)
+    mv, fx, _ = synth_pair(big, 100 + n + m)
+    mv, fx = np.ascontiguousarray(mv[:, :n]), np.ascontiguousarray(fx[:, :m])
+    det, odet = {}, {}
+    got = platymatch_amd.register(mv, fx, ransac_trials=60, ransac_error=30.0, icp_iterations=3, seed=1, details=det)
+    ref = oracle.estimate_transform(mv, fx, ransac_trials=60, ransac_error=30.0, icp_iterations=3, seed=1, details=odet)
+    for h in range(8):
+        assert np.array_equal(det["lsa"][h][0], odet["lsa"][h][0]) and np.array_equal(det["lsa"][h][1], odet["lsa"][h][1])
+    assert np.array_equal(got[2], ref[2])
+    ok = np.isfinite(ref[0]).all() and np.isfinite(ref[1]).all() and np.linalg.cond(ref[0]) < 1e8
+    if ok:
+        assert relerr(got[0], ref[0]) < 1e-6 and np.array_equal(det["nn"], odet["nn"])
+
+
 def test_estimate_transform_supervised_and_api_kinds(gpu, oracle, micro):
     import platymatch_amd
     from platymatch_amd.estimate_transform import perform_icp as pi
