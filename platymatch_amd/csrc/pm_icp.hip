@@ -17,7 +17,10 @@ namespace pm {
 
 // moment sums + solve + apply + residual of one iteration (pm_transform.hip)
 int refit_apply(double *mov, int n, const double *fix, int m, const int32_t *nn, const double *origin6, double *A_icp16,
-                double *mean_out, double *acc_ws, double *res_ws, unsigned int *done, hipStream_t s);
+                double *acc_ws, double *res_ring, int it, hipStream_t s);
+int residual_rows(const double *res_ring, int n, int count, double *mean_out, hipStream_t s);
+size_t residual_ring_bytes(int n);
+constexpr int ICP_RES_RING = 64;               // = TF_RES_RING (pm_transform.hip)
 // uniform-grid search (pm_icp_grid.hip): same results as the brute-force kernels below, O(N) instead of O(N*M) per iteration
 size_t grid_ws_bytes(int m);
 int grid_build(const double *fix, int m, void *ws, hipStream_t s);
@@ -169,17 +172,15 @@ int nn_search(const double *mov, int n, const double *fix, int m, int32_t *nn, d
     return launch_status();
 }
 
-__global__ void icp_init_kernel(const double *__restrict__ fix, int m, double *__restrict__ origin6, double *__restrict__ A16,
-                                unsigned int *done) {
+__global__ void icp_init_kernel(const double *__restrict__ fix, int m, double *__restrict__ origin6, double *__restrict__ A16) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        *done = 0u;
         for (int c = 0; c < 3; ++c) { origin6[c] = fix[(size_t)c * m]; origin6[3 + c] = fix[(size_t)c * m]; }
         for (int k = 0; k < 16; ++k) A16[k] = (k % 5 == 0) ? 1.0 : 0.0;
     }
 }
 
 struct IcpWs {
-    size_t nn_ws, nn, acc_ws, res_ws, done, origin, total;
+    size_t nn_ws, nn, acc_ws, res_ring, origin, total;
 };
 
 inline IcpWs icp_layout(int n, int m) {
@@ -188,8 +189,7 @@ inline IcpWs icp_layout(int n, int m) {
     w.nn_ws = o; o += align_up(grid_ws_bytes(m), 256);
     w.nn = o; o += align_up((size_t)n * sizeof(int32_t), 256);
     w.acc_ws = o; o += align_up(pm_icp_accumulate_workspace(n), 256);
-    w.res_ws = o; o += align_up(pm_icp_update_workspace(n), 256);
-    w.done = o; o += 256;
+    w.res_ring = o; o += align_up(residual_ring_bytes(n), 256);
     w.origin = o; o += 256;
     w.total = o;
     return w;
@@ -245,20 +245,24 @@ int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_ic
     char *base = (char *)ws;
     int32_t *nn_buf = (int32_t *)(base + L.nn);
     double *acc_ws = (double *)(base + L.acc_ws);
-    double *res_ws = (double *)(base + L.res_ws);
-    unsigned int *done = (unsigned int *)(base + L.done);
+    double *res_ring = (double *)(base + L.res_ring);
     double *origin = (double *)(base + L.origin);
-    pm::icp_init_kernel<<<1, 64, 0, s>>>(fix, m, origin, A_icp16, done);
+    pm::icp_init_kernel<<<1, 64, 0, s>>>(fix, m, origin, A_icp16);
     if (iters > 0) {                                   // the fixed cloud never changes: bin it once
         int rc = pm::grid_build(fix, m, base + L.nn_ws, s);
         if (rc != PM_OK) return rc;
     }
-    for (int it = 0; it < iters; ++it) {               // three launches per iteration: search, moments, solve + apply + residual
+    for (int it = 0; it < iters; ++it) {               // three launches per iteration: search, moments, solve + apply
         int32_t *nn = nn_all ? nn_all + (size_t)it * n : nn_buf;
         int rc = pm::grid_query(mov, n, m, base + L.nn_ws, nn, nullptr, s);
         if (rc != PM_OK) return rc;
-        rc = pm::refit_apply(mov, n, fix, m, nn, origin, A_icp16, residuals ? residuals + it : nullptr, acc_ws, res_ws, done, s);
+        rc = pm::refit_apply(mov, n, fix, m, nn, origin, A_icp16, acc_ws, res_ring, it, s);
         if (rc != PM_OK) return rc;
+        const int filled = it % pm::ICP_RES_RING + 1;  // residual partials waiting in the ring
+        if (residuals && (filled == pm::ICP_RES_RING || it + 1 == iters)) {
+            rc = pm::residual_rows(res_ring, n, filled, residuals + (it + 1 - filled), s);
+            if (rc != PM_OK) return rc;
+        }
     }
     return pm::launch_status();
 }

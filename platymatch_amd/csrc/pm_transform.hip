@@ -16,6 +16,7 @@ constexpr int TF_THREADS = 256;
 constexpr int TF_PER_THREAD = 2;
 constexpr int TF_BLOCK_PTS = TF_THREADS * TF_PER_THREAD;
 constexpr int NS = 22;   // accumulated slots (PM_ICP_NSUMS - count - pad)
+constexpr int TF_RES_RING = 64;   // iterations of the fused ICP loop whose residual partials are reduced by one launch
 
 __global__ __launch_bounds__(TF_THREADS) void apply_affine_kernel(const double *__restrict__ A, const double *in, int n,
                                                                   double *out) {
@@ -46,11 +47,9 @@ __device__ __forceinline__ double ordered_partial_sum(const double *__restrict__
 }
 
 // Workgroup form of the same sums: all threads fetch a chunk of partials into LDS in one round trip, then thread k adds
-// slot k's values in block order.  COHERENT: the partials were written by other workgroups of the RUNNING kernel
-// (possibly on another XCD, behind another L2) and are read with device-scope atomic loads.  Result for slot k in
-// out_s[k] (k < nslots), valid after the call's final barrier.  stage: TF_STAGE doubles of LDS.
+// slot k's values in block order.  Result for slot k in out_s[k] (k < nslots), valid after the call's final barrier.
+// stage: TF_STAGE doubles of LDS.
 constexpr int TF_STAGE = 2816;     // 128 blocks x 22 slots
-template <bool COHERENT>
 __device__ __forceinline__ void ordered_partial_sums_block(const double *__restrict__ partial, int nblocks, int nslots,
                                                            double *__restrict__ stage, double *__restrict__ out_s) {
     const int per = TF_STAGE / nslots;                   // blocks per chunk
@@ -58,9 +57,7 @@ __device__ __forceinline__ void ordered_partial_sums_block(const double *__restr
     for (int b0 = 0; b0 < nblocks; b0 += per) {
         const int cnt = min(per, nblocks - b0) * nslots;
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += blockDim.x)
-            stage[e] = COHERENT ? __hip_atomic_load(partial + (size_t)b0 * nslots + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                : partial[(size_t)b0 * nslots + e];
+        for (int e = threadIdx.x; e < cnt; e += blockDim.x) stage[e] = partial[(size_t)b0 * nslots + e];
         __syncthreads();
         if ((int)threadIdx.x < nslots)
             for (int e = threadIdx.x; e < cnt; e += nslots) t += stage[e];
@@ -131,24 +128,21 @@ __global__ void solve_kernel(const double *__restrict__ sums, const double *__re
     }
 }
 
-// mov <- A_est . mov ; residual partial ; block 0 composes A_icp <- A_est . A_icp.
+// mov <- A_est . mov ; residual partial per block ; block 0 composes A_icp <- A_est . A_icp.
 // A_est comes from `A_given`, or is solved from `sums`, or — fused ICP loop — from the per-block partials of
 // accumulate_kernel, which every block then sums itself in the fixed order (acc_partial != nullptr).
-// `done` (fused loop only): a counter the last block to finish uses to know it is last; it then adds the residual
-// partials in block order, writes the iteration's mean residual and re-arms the counter.
 __global__ __launch_bounds__(TF_THREADS) void update_kernel(const double *__restrict__ sums, const double *__restrict__ acc_partial,
                                                             const double *__restrict__ origin6,
                                                             const double *__restrict__ A_given, double *mov, int n, const double *__restrict__ fix, int m,
                                                             const int32_t *__restrict__ nn, double *A_icp16, double *A_est16,
-                                                            double *__restrict__ partial, unsigned int *done, double *__restrict__ mean_out) {
+                                                            double *__restrict__ partial) {
     __shared__ double scratch[TF_THREADS / 64];
     __shared__ double As[16];
     __shared__ double sums_s[PM_ICP_NSUMS];
     __shared__ double stage[TF_STAGE];
-    __shared__ int is_last;
     if (acc_partial) {
         if (threadIdx.x == 0) { sums_s[0] = (double)n; sums_s[1 + NS] = 0.0; }
-        ordered_partial_sums_block<false>(acc_partial, gridDim.x, NS, stage, sums_s + 1);
+        ordered_partial_sums_block(acc_partial, gridDim.x, NS, stage, sums_s + 1);
     }
     if (threadIdx.x == 0) {
         double A[16];
@@ -192,20 +186,12 @@ __global__ __launch_bounds__(TF_THREADS) void update_kernel(const double *__rest
     }
     double t = block_sum(res, scratch);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
-    if (!done) return;
-    if (threadIdx.x == 0) {
-        __threadfence();                                              // this block's partial is visible before its ticket
-        is_last = (atomicAdd(done, 1u) == gridDim.x - 1);
-    }
-    __syncthreads();
-    if (is_last) {                                                    // uniform per block
-        __threadfence();
-        ordered_partial_sums_block<true>(partial, gridDim.x, 1, stage, scratch);
-        if (threadIdx.x == 0) {
-            if (mean_out) mean_out[0] = scratch[0] / (double)n;
-            *done = 0u;                                               // re-armed for the next launch on this stream
-        }
-    }
+}
+
+// mean residuals of `count` iterations at once: workgroup r adds row r of partial[count][nblocks] in block order
+// (the additions of residual_final) -> mean_out[r].  The fused ICP loop calls it once per TF_RES_RING iterations.
+__global__ __launch_bounds__(64) void residual_flush(const double *__restrict__ partial, int nblocks, int n, double *__restrict__ mean_out) {
+    if (threadIdx.x == 0) mean_out[blockIdx.x] = ordered_partial_sum(partial + (size_t)blockIdx.x * nblocks, nblocks, 1, 0) / (double)n;
 }
 
 __global__ void residual_final(const double *__restrict__ partial, int nblocks, int n, double *__restrict__ parts2,
@@ -249,22 +235,30 @@ int accumulate(const double *mov, int n, const double *fix, int m, const int32_t
 int update(const double *sums, const double *origin6, const double *A_given, double *mov, int n, const double *fix, int m,
            const int32_t *nn, double *A_icp16, double *A_est16, double *parts2, double *mean_out, double *ws, hipStream_t s) {
     const int nb = tf_blocks(n);
-    update_kernel<<<nb, TF_THREADS, 0, s>>>(sums, nullptr, origin6, A_given, mov, n, fix, m, nn, A_icp16, A_est16, ws, nullptr, nullptr);
+    update_kernel<<<nb, TF_THREADS, 0, s>>>(sums, nullptr, origin6, A_given, mov, n, fix, m, nn, A_icp16, A_est16, ws);
     residual_final<<<1, 64, 0, s>>>(ws, nb, n, parts2, mean_out);
     return launch_status();
 }
 
 // One refit + apply of the fused ICP loop in two launches: per-block moment partials, then a kernel whose every block
-// adds those partials in block order, solves, applies, and whose last block reduces the residual.  Same additions in
-// the same order as accumulate() + update(), hence the same bits.  acc_ws: tf_blocks(n) * NS doubles, res_ws: tf_blocks(n)
-// doubles, done: one zeroed counter.
+// adds those partials in block order, solves and applies.  Same additions in the same order as accumulate() + update(),
+// hence the same bits.  The residual partials of iteration `it` go to row it % TF_RES_RING of res_ring; the caller
+// turns the rows into mean residuals with residual_rows().  acc_ws: tf_blocks(n) * NS doubles.
 int refit_apply(double *mov, int n, const double *fix, int m, const int32_t *nn, const double *origin6, double *A_icp16,
-                double *mean_out, double *acc_ws, double *res_ws, unsigned int *done, hipStream_t s) {
+                double *acc_ws, double *res_ring, int it, hipStream_t s) {
     const int nb = tf_blocks(n);
     accumulate_kernel<<<nb, TF_THREADS, 0, s>>>(mov, n, fix, m, nn, origin6, acc_ws);
-    update_kernel<<<nb, TF_THREADS, 0, s>>>(nullptr, acc_ws, origin6, nullptr, mov, n, fix, m, nn, A_icp16, nullptr, res_ws, done, mean_out);
+    update_kernel<<<nb, TF_THREADS, 0, s>>>(nullptr, acc_ws, origin6, nullptr, mov, n, fix, m, nn, A_icp16, nullptr,
+                                            res_ring + (size_t)(it % TF_RES_RING) * nb);
     return launch_status();
 }
+
+int residual_rows(const double *res_ring, int n, int count, double *mean_out, hipStream_t s) {
+    residual_flush<<<count, 64, 0, s>>>(res_ring, tf_blocks(n), n, mean_out);
+    return launch_status();
+}
+
+size_t residual_ring_bytes(int n) { return (size_t)TF_RES_RING * tf_blocks(n) * sizeof(double); }
 
 __global__ void origin_kernel(const double *__restrict__ mov, int n, const double *__restrict__ fix, int m,
                               double *__restrict__ origin6) {

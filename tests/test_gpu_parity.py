@@ -464,6 +464,31 @@ def test_icp_matches_reference(gpu, oracle, name):
     assert np.array_equal(pi.perform_icp(moved, d["fixed"], 0), np.eye(4))
 
 
+@pytest.mark.parametrize("iters", [1, 63, 64, 65, 130])
+def test_fused_icp_residuals_across_ring_boundaries(gpu, iters):
+    """pm_icp reduces the residual partials of up to 64 iterations per launch: every iteration's residual, the 4x4 and the
+    moved cloud must equal the step-by-step loop's (pm_icp_nn + pm_icp_accumulate + pm_icp_update) bit for bit."""
+    t, K = gpu.t, gpu.K
+    mv, fx, _ = synth_pair(700, 31)
+    fix = gpu.d(fx[:, :650])
+    hom = np.vstack([mv, np.ones((1, 700))])
+    start = gpu.d((load_golden("synth128")["A_gt"] @ hom)[:3] * 1.01 + 0.7)
+    work = start.clone()
+    A, res, nn_all = K.icp(work, fix, iters, want_nn=True)
+    loc = start.clone()
+    A2 = t.eye(4, dtype=t.float64, device=loc.device).reshape(16).contiguous()
+    origin = t.cat([fix[:, 0], fix[:, 0]]).contiguous()
+    step_res = []
+    for it in range(iters):
+        nn, _ = K.icp_nn(loc, fix, want_dist=False)
+        assert t.equal(nn, nn_all[it])
+        sums = K.icp_accumulate(loc, fix, nn, origin, nn_trusted=True)
+        _, parts = K.icp_update(sums, origin, loc, fix, nn, A2, nn_trusted=True)
+        step_res.append(float(parts[0] / parts[1]))
+    assert res.cpu().tolist() == step_res and len(step_res) == iters
+    assert t.equal(A.reshape(16), A2) and t.equal(work, loc)
+
+
 def test_icp_similar_mode(gpu, oracle):
     from platymatch_amd.estimate_transform import perform_icp as pi
     pi.VERBOSE = False
