@@ -20,6 +20,9 @@ constexpr int GR_MAX_DIM = 512;
 constexpr int GR_CELLS_PER_POINT = 8;    // measured on the 50k blob: 1 -> 234, 2 -> 146, 4 -> 97, 8 -> 77, 16 -> 75 us per ICP iteration
 constexpr int GR_RING_CAP = 6;            // beyond this ring radius a group scans the whole cloud instead (sparse outliers)
 constexpr int GR_BATCH = 4;               // cells per lane whose ranges are fetched together
+#ifndef GR_INFLIGHT
+#define GR_INFLIGHT 2                     // candidate records a lane requests before it compares them
+#endif
 constexpr int GR_LANES = 32;              // lanes per moving point (measured on the 50k blob: 4 -> 73, 8 -> 67, 16 -> 63, 32 -> 56 us per ICP iteration)
 
 struct GridHeader {          // lives at the start of the workspace, written by grid_plan_kernel
@@ -203,14 +206,14 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__
     const int rmax = max(max(max(cx, hd.g[0] - 1 - cx), max(cy, hd.g[1] - 1 - cy)), max(cz, hd.g[2] - 1 - cz));
     double bS = INFINITY;
     int bI = 0x7fffffff;           // "nothing yet": loses every index tie; replaced by 0 at the end if nothing ever matched
-    // candidates q0, q0 + step, ... < q1, four loads in flight at a time
+    // candidates q0, q0 + step, ... < q1, GR_INFLIGHT loads in flight at a time
     auto scan = [&](int q0, int q1, int step) {
-        for (int q = q0; q < q1; q += 4 * step) {
-            double4 f[4];
+        for (int q = q0; q < q1; q += GR_INFLIGHT * step) {
+            double4 f[GR_INFLIGHT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) f[u] = pts[(q + u * step < q1) ? q + u * step : q];
+            for (int u = 0; u < GR_INFLIGHT; ++u) f[u] = pts[(q + u * step < q1) ? q + u * step : q];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < GR_INFLIGHT; ++u) {
                 const double d0 = f[u].x - p0, d1 = f[u].y - p1, d2 = f[u].z - p2;
                 const double s = (d0 * d0 + d1 * d1) + d2 * d2;
                 const int j = (int)__double_as_longlong(f[u].w);
