@@ -51,6 +51,36 @@ def test_workspace_queries_and_argument_errors(lib_path):
     assert lib.pm_icp(None, 5, None, 5, 1, None, None, None, None, 0, None) == -1
 
 
+def test_every_entry_point_rejects_bad_arguments_before_touching_the_device(lib_path):
+    """All pointers NULL and all sizes zero -> PM_ERR_INVALID_ARG from every int-returning entry point (nothing is enqueued,
+    so this runs without a GPU); a non-NULL call with a missing workspace -> PM_ERR_WORKSPACE; size queries answer 0."""
+    from platymatch_amd import _native
+    lib = _native.load()
+    skipped = {"pm_version", "pm_last_hip_error", "pm_error_string"}
+    for name, (restype, argtypes) in _native.SIGNATURES.items():
+        if name in skipped:
+            continue
+        args = [None if a is ctypes.c_void_p else (0.0 if a is ctypes.c_double else 0) for a in argtypes]
+        got = getattr(lib, name)(*args)
+        if restype is ctypes.c_size_t or name.endswith("_workspace"):
+            assert got == 0, name
+        else:
+            assert got == -1, (name, got)
+    fake = ctypes.c_void_p(0x1000)               # never dereferenced: the workspace check comes first
+    assert lib.pm_mean_distance(fake, 100, fake, None, 0, None) == -2
+    assert lib.pm_mean_distance_rows(fake, 100, 0, 1, fake, 0, None) == -2
+    assert lib.pm_icp(fake, 10, fake, 10, 3, fake, None, None, None, 0, None) == -2
+    assert lib.pm_icp_nn(fake, 10, fake, 10, fake, None, None, 0, None) == -2
+    assert lib.pm_icp_accumulate(fake, 10, fake, 10, None, fake, fake, None, 0, None) == -2
+    assert lib.pm_fit_affine(fake, 10, fake, 10, None, fake, None, 0, None) == -2
+    assert lib.pm_get_error(fake, fake, 10, fake, None, 0, None) == -2
+    assert lib.pm_shape_context(fake, 10, 8, 5, fake, fake, fake, 4, fake, None, None, None) == -1     # row block outside the cloud
+    assert lib.pm_shape_context(fake, 10, 0, 5, fake, fake, fake, 3, fake, None, None, None) == -1     # 3 frames do not exist
+    assert lib.pm_chi2_cost(fake, 4, fake, 4, fake, 3, None) == -1                                     # ld < columns
+    assert lib.pm_row_argmin(fake, 2, 4, 8, 8, 16, fake, None, None) == -1                             # overlapping matrices
+    assert lib.pm_mean_distance_rows(fake, 100, 2, 2, fake, 1 << 20, None) == -1                       # offset >= stride
+
+
 def test_product_refuses_to_run_without_a_gpu(lib_path):
     import torch
     if torch.cuda.is_available():
