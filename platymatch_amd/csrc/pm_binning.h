@@ -131,15 +131,41 @@ PM_HD void pm_phi_index4(double x, double y, int nframes, int p[4]) {
 }
 
 // Bins of one neighbour (frame coordinates x_, y_, z_) in frames 1..nframes: out[f] = bin or PM_DROP.
+//
+// The reference takes r_ = sqrt(s), s = (x_^2 + y_^2) + z_^2 (:29), compares r_/mean_dist with the ring edges and
+// c = z_/r_ (the argument of arccos, :31) with the theta steps: a square root and a division per neighbour, ~40 % of
+// this function's instructions.  Both comparisons are monotone and can be made on s instead:
+//     r_ >= rho   <=>  s >= rho^2                 c <= T  <=>  z_|z_| <= T|T| s      (u|u| is increasing, s = r_^2 > 0)
+// up to the roundings of sqrt, the division and the products (each < 2^-51 relative).  A decision is therefore taken on
+// s only if it is clear by 2^-40 (relative to s) of EVERY ring and theta step, and s is finite, normal and non-zero;
+// otherwise — one neighbour in ~1e9 for generic data — the reference's own expressions decide.
 PM_HD void pm_bin_index4(double x_, double y_, double z_, const double rho[4], int nframes, int out[4]) {
-    const double r_ = __builtin_sqrt((x_ * x_ + y_ * y_) + z_ * z_);   // :29
-    const double c = z_ / r_;                                          // :31 argument of arccos
-    if (!(__builtin_fabs(c) <= 1.0) || x_ != x_ || y_ != y_) {         // arccos / atan2 -> NaN: not counted
-        out[0] = out[1] = out[2] = out[3] = PM_DROP;
-        return;
+    const double s = (x_ * x_ + y_ * y_) + z_ * z_;
+    const double zz = z_ * __builtin_fabs(z_), m = s * 0x1p-40;
+    int safe = (s > 0x1p-900) & (s < 0x1p+900);           // also false for NaN coordinates
+    int th = 0, ring = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double dd = zz - (PM_CTH[k] * __builtin_fabs(PM_CTH[k])) * s;
+        safe &= (__builtin_fabs(dd) > m);
+        th += (dd <= 0.0);
     }
-    const int th = (c <= PM_CTH[0]) + (c <= PM_CTH[1]) + (c <= PM_CTH[2]) + (c <= PM_CTH[3]) + (c <= PM_CTH[4]) + (c <= PM_CTH[5]);
-    const int ring = (r_ >= rho[0]) + (r_ >= rho[1]) + (r_ >= rho[2]) + (r_ >= rho[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double dd = s - ((rho[k] < 0.0) ? -1.0 : rho[k] * rho[k]);      // rho < 0: every r_ passes (pm_ring_thresholds)
+        safe &= (__builtin_fabs(dd) > m);
+        ring += (dd >= 0.0);
+    }
+    if (!safe) {
+        const double r_ = __builtin_sqrt(s);                               // :29
+        const double c = z_ / r_;                                          // :31 argument of arccos
+        if (!(__builtin_fabs(c) <= 1.0) || x_ != x_ || y_ != y_) {         // arccos / atan2 -> NaN: not counted
+            out[0] = out[1] = out[2] = out[3] = PM_DROP;
+            return;
+        }
+        th = (c <= PM_CTH[0]) + (c <= PM_CTH[1]) + (c <= PM_CTH[2]) + (c <= PM_CTH[3]) + (c <= PM_CTH[4]) + (c <= PM_CTH[5]);
+        ring = (r_ >= rho[0]) + (r_ >= rho[1]) + (r_ >= rho[2]) + (r_ >= rho[3]);
+    }
     const int base = ring * 72 + th * 12;
     int p[4];
     pm_phi_index4(x_, y_, nframes, p);

@@ -171,3 +171,30 @@ def test_ring_thresholds_equal_the_division(host_lib):
     rho = np.zeros(4)
     host_lib.pmt_ring_thresholds(ctypes.c_double(float("inf")), rho.ctypes.data_as(ctypes.c_void_p))
     assert not (np.array([0.0, 1.0, 1e300])[:, None] >= rho[None, :]).any()      # r = 0 for every finite r_: ring 0
+
+
+def test_four_frame_step_ring_and_theta_decided_on_squares(host_lib, oracle):
+    """pm_bin_index4 decides the ring and the theta step on s = |v|^2 when s is clear of every step by 2^-40 and by the
+    reference's sqrt / division otherwise: neighbours at 0, a few ulps, 2^-41, 2^-40, 2^-39 and 1e-9 (relative) on both
+    sides of every ring edge and every theta step, for several mean distances, directions and magnitudes."""
+    rels = [0.0, 2.0 ** -52, -2.0 ** -52, 3 * 2.0 ** -52, -3 * 2.0 ** -52, 2.0 ** -45, -2.0 ** -45, 2.0 ** -41, -2.0 ** -41,
+            2.0 ** -40, -2.0 ** -40, 1.5 * 2.0 ** -40, -1.5 * 2.0 ** -40, 2.0 ** -39, -2.0 ** -39, 1e-9, -1e-9]
+    rng = np.random.default_rng(8)
+    for md in (1.0, 37.0, 114.13353403330422, 0.7, 1e-3, 12345.678):
+        tests = []
+        for edge in (0.125, 0.25000000000000006, 0.5000000000000001, 1.0, 2.0):
+            for rel in rels:
+                rad = edge * md * (1.0 + rel)
+                for _ in range(6):
+                    u = rng.normal(size=3)
+                    u /= np.linalg.norm(u)
+                    tests.append(tuple(rad * u))
+                tests += [(rad, 0.0, 0.0), (0.0, -rad, 0.0), (0.0, 0.0, rad), (0.0, 0.0, -rad)]
+        for k in range(0, 7):                         # theta steps at k * pi / 6
+            for rel in rels:
+                th = k * np.pi / 6 + rel * (1.0 if k else 0.0) + (abs(rel) if k == 0 else 0.0)
+                for rad in (0.3 * md, 1.7 * md, 1e-4 * md, 4e3 * md):
+                    for ph in (0.1, 2.0, 4.4, 6.0):
+                        tests.append((rad * np.sin(th) * np.cos(ph), rad * np.sin(th) * np.sin(ph), rad * np.cos(th)))
+        tests = np.array(tests)
+        assert np.array_equal(prod_bin4(host_lib, tests, md), oracle_bin4(oracle, tests, md)), md
