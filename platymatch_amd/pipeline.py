@@ -185,6 +185,8 @@ def build_descriptors(be, mov, fix, group=None):
     -> (sc_m [2, rows_g, 360], sc_f [4, M, 360] complete (or [1, M, 360], see gather_fixed_descriptors), moving row bounds)."""
     rank, world = _world(group)
     n, m = mov.shape[1], fix.shape[1]
+    if world > min(n, m):        # every rank sees the same clouds: all raise, before the first collective
+        raise ValueError("cannot shard %d x %d points over %d ranks: every rank needs at least one row of each cloud" % (n, m, world))
     cm, mdm, x0m = cloud_statistics(be, mov, group)
     cf, mdf, x0f = cloud_statistics(be, fix, group)
     bn, bm = shard_bounds(n, world), shard_bounds(m, world)
@@ -266,8 +268,22 @@ def assign(U_loc, bounds, group=None):
         if owner == rank:    # keep the assembled matrix on the host; solve after all gathers so ranks solve concurrently
             mine[h] = torch.cat([blocks[g][:bounds[g + 1] - bounds[g]] for g in range(world)], dim=0).cpu().numpy()
             del blocks
+    # A solver refusal (NaN / -inf costs from degenerate descriptors, infeasible matrix) on the owner of one hypothesis
+    # must not leave the other ranks waiting in the broadcasts below: collect a status word per hypothesis, agree on it,
+    # and raise the same exception everywhere.
+    status = torch.zeros(8, dtype=torch.int32, device=U_loc.device)
     for h in list(mine):
-        mine[h] = linear_sum_assignment(mine[h])
+        try:
+            mine[h] = linear_sum_assignment(mine[h])
+        except ValueError as e:
+            status[h] = 2 if "infeasible" in str(e) else 1
+            mine[h] = None
+    dist.all_reduce(status, op=dist.ReduceOp.MAX, group=group)
+    bad = status.cpu().numpy()
+    if bad.any():
+        h = int(np.flatnonzero(bad)[0])
+        raise ValueError("hypothesis %s: %s" % (HYPOTHESES[h], "cost matrix is infeasible" if bad[h] == 2
+                                                 else "matrix contains invalid numeric entries"))
     k = min(n, U_loc.shape[2])
     out = []
     for h in range(8):
@@ -443,29 +459,110 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     return A_sc.cpu().numpy(), (A_icp.cpu().numpy() if nat.is_torch(A_icp) else np.asarray(A_icp)), inliers
 
 
-def estimate_transform_batch(pairs, workers=4, seeds=None, **kwargs):
-    """Several independent registrations on one GPU (BASELINE config 5: "replicas only", no collective): each worker thread
-    drives its pairs on its own HIP stream, so the GPU stages of different pairs overlap, the Hungarian solves (GIL-free,
-    lsap.py) run concurrently on the host.  Seeded pairs draw their RANSAC index sets from a private RandomState(seed) (the
-    sets np.random.seed(seed) would give); unseeded pairs draw from NumPy's global generator one after the other.  pairs: iterable of (moving, fixed); seeds: optional per-pair RANSAC seeds.
-    -> list of (A_sc, A_icp, inliers) in input order, each identical to a stand-alone estimate_transform call."""
+def batch_costs(sizes):
+    """Relative cost of a registration of N x M nuclei, for sharing a batch out: the eight N x M cost matrices grow
+    with N*M, the eight Hungarian solves (the dominant host step) roughly with N*M*sqrt(min(N, M)) (measured at 2k-20k,
+    profiles/r02_batch64.json)."""
+    return [float(n) * float(m) * float(min(n, m)) ** 0.5 for n, m in sizes]
+
+
+def batch_assignment(sizes, world):
+    """Pairs -> ranks, largest first onto the least loaded rank (LPT): a pure function of the sizes, so every rank
+    computes the same table without talking.  -> list of rank indices, one per pair."""
+    cost = batch_costs(sizes)
+    load = [0.0] * world
+    owner = [0] * len(cost)
+    for k in sorted(range(len(cost)), key=lambda k: (-cost[k], k)):
+        g = min(range(world), key=lambda g: (load[g], g))
+        owner[k] = g
+        load[g] += cost[k]
+    return owner
+
+
+def _pair_size(pair):
+    return tuple(int(x.shape[1]) for x in pair[:2])
+
+
+def _run_local(pairs, ks, workers, seeds, kwargs):
+    """This process's share of a batch: pairs ks on `workers` host threads, one HIP stream each."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
-    pairs = list(pairs)
-    seeds = list(seeds) if seeds is not None else [None] * len(pairs)
-    if len(seeds) != len(pairs):
-        raise ValueError("one seed per pair")
-    dev = nat.device()
-    nat.load()
+    be = kwargs.get("backend")
+    on_gpu = be is None or getattr(be, "device", None) is None or torch.device(be.device).type == "cuda"
+    if on_gpu:
+        dev = nat.device(None if be is None else be.device)
+        nat.load()
 
     def one(k):
+        if not on_gpu:                       # a caller-supplied host backend (tests): no stream to set
+            return estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, **kwargs)
         stream = torch.cuda.Stream(device=dev)
         with torch.cuda.device(dev), torch.cuda.stream(stream):
             out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, **kwargs)
             stream.synchronize()
         return out
 
-    if workers <= 1 or len(pairs) <= 1:
-        return [one(k) for k in range(len(pairs))]
-    with ThreadPoolExecutor(max_workers=min(workers, len(pairs))) as ex:
-        return list(ex.map(one, range(len(pairs))))
+    # largest first: the long Hungarian solves start early and the short pairs fill the gaps at the end
+    cost = batch_costs([_pair_size(pairs[k]) for k in ks])
+    order = [ks[i] for i in sorted(range(len(ks)), key=lambda i: (-cost[i], ks[i]))]
+    if workers <= 1 or len(order) <= 1:
+        return {k: one(k) for k in order}
+    with ThreadPoolExecutor(max_workers=min(workers, len(order))) as ex:
+        return dict(zip(order, ex.map(one, order)))
+
+
+def estimate_transform_batch(pairs, workers=4, seeds=None, group=None, **kwargs):
+    """Several independent registrations (BASELINE config 5: "replicas only" — pairs never exchange data).
+
+    One GPU (group=None): each worker thread drives its pairs on its own HIP stream, so the GPU stages of different pairs
+    overlap and the Hungarian solves (GIL-free, lsap.py) run concurrently on the host.
+    Several GPUs (group = a torch.distributed group, one process per GPU): every rank holds the whole list; pairs are
+    dealt to ranks largest first (batch_assignment, no communication), each rank registers its share as above, and ONE
+    all-reduce of 40 doubles per pair (A_sc, A_icp, inlier counts; every entry is non-zero on its owner only, so the sum is
+    exact) hands every result to every rank.  A failure on any rank is raised on all of them.
+
+    Seeded pairs draw their RANSAC index sets from a private RandomState(seed) (the sets np.random.seed(seed) would
+    give); unseeded pairs draw from NumPy's global generator one after the other.
+    pairs: iterable of (moving, fixed); seeds: optional per-pair RANSAC seeds.
+    -> list of (A_sc, A_icp, inliers) in input order, each identical to a stand-alone estimate_transform call."""
+    import torch
+    pairs = list(pairs)
+    seeds = list(seeds) if seeds is not None else [None] * len(pairs)
+    if len(seeds) != len(pairs):
+        raise ValueError("one seed per pair")
+    if "details" in kwargs:
+        raise ValueError("details is per registration: call estimate_transform for the pair of interest")
+    rank, world = _world(group)
+    if world == 1:
+        res = _run_local(pairs, list(range(len(pairs))), workers, seeds, kwargs)
+        return [res[k] for k in range(len(pairs))]
+    dist = _dist()
+    owner = batch_assignment([_pair_size(p) for p in pairs], world)
+    mine = [k for k in range(len(pairs)) if owner[k] == rank]
+    failure = None
+    try:
+        res = _run_local(pairs, mine, workers, seeds, kwargs)
+    except Exception as e:                     # keep the collective below matched on every rank, then raise everywhere
+        failure, res = e, {}
+    be = kwargs.get("backend")
+    on_host = dist.get_backend(group) == "gloo"
+    dev = torch.device("cpu") if on_host else (nat.device(None if be is None else be.device))
+    table = torch.zeros((len(pairs) + 1, 40), dtype=torch.float64, device=dev)
+    table[len(pairs), 0] = 0.0 if failure is None else 1.0
+    for k, (A_sc, A_icp, inl) in res.items():
+        table[k, :16] = torch.as_tensor(np.asarray(A_sc.cpu() if nat.is_torch(A_sc) else A_sc, dtype=np.float64).reshape(16))
+        table[k, 16:32] = torch.as_tensor(np.asarray(A_icp.cpu() if nat.is_torch(A_icp) else A_icp, dtype=np.float64).reshape(16))
+        table[k, 32:] = torch.as_tensor(np.asarray(inl, dtype=np.float64))
+    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    if failure is not None:
+        raise failure
+    if float(table[len(pairs), 0]) != 0.0:
+        raise RuntimeError("estimate_transform_batch: a registration failed on another rank")
+    out = []
+    host = table.cpu().numpy()
+    for k, p in enumerate(pairs):
+        A_sc, A_icp, inl = host[k, :16].reshape(4, 4).copy(), host[k, 16:32].reshape(4, 4).copy(), host[k, 32:].astype(np.int64)
+        if nat.is_torch(p[0]):
+            A_sc, A_icp = torch.as_tensor(A_sc, device=p[0].device), torch.as_tensor(A_icp, device=p[0].device)
+        out.append((A_sc, A_icp, inl))
+    return out

@@ -90,8 +90,10 @@ class OracleBackend:
         return torch.as_tensor(np.argmin(U.numpy(), axis=-1).astype(np.int32))
 
     def draw_samples(self, n, min_samples, trials, rng=None):
-        assert rng is None
-        return self.o.draw_ransac_samples(n, min_samples, trials)
+        if rng is None:
+            return self.o.draw_ransac_samples(n, min_samples, trials)
+        # a batch run's private RandomState(seed): the draws np.random.seed(seed) + the global generator would give
+        return np.stack([rng.choice(n, min_samples, replace=False) for _ in range(trials)]).astype(np.int32)
 
     def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples, samples=None):
         A, k = self.o.do_ransac(mov.numpy()[:, rows], fix.numpy()[:, cols], min_samples=min_samples, trials=trials, error=error,
@@ -236,3 +238,113 @@ def _gather_worker(rank, world, port, out):
         np.save(out % rank, got.numpy())
     finally:
         dist.destroy_process_group()
+
+
+# ---- BASELINE config 5: a batch of independent pairs dealt to ranks (pipeline.estimate_transform_batch(group=...)) ----
+def _batch_pairs():
+    from conftest import synth_pair
+    sizes = [(40, 40), (64, 56), (33, 48), (72, 72), (50, 41)]
+    pairs = []
+    for k, (n, m) in enumerate(sizes):
+        mv, fx, _ = synth_pair(n, 300 + k, m=m)
+        pairs.append((mv, fx))
+    return pairs
+
+
+def _batch_worker(rank, world, port, out_path, poison):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from platymatch_amd import pipeline as P
+        pairs = _batch_pairs()
+        if poison:                                           # one pair cannot be registered: too few points for 4 samples
+            pairs[1] = (pairs[1][0][:, :3], pairs[1][1][:, :3])
+        owner = P.batch_assignment([(p[0].shape[1], p[1].shape[1]) for p in pairs], world)
+        try:
+            res = P.estimate_transform_batch(pairs, workers=2, seeds=[7 + k for k in range(len(pairs))], group=dist.group.WORLD,
+                                             backend=OracleBackend(), ransac_trials=60, ransac_error=16, icp_iterations=4)
+            np.savez(out_path % rank, owner=np.array(owner), A_sc=np.stack([r[0] for r in res]), A_icp=np.stack([r[1] for r in res]),
+                     inl=np.stack([r[2] for r in res]))
+        except Exception as e:                               # every rank must get here when one pair fails, none may hang
+            np.savez(out_path % rank, owner=np.array(owner), error=np.array(type(e).__name__))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_dealt_to_two_ranks_equals_stand_alone_calls(tmp_path, oracle):
+    from platymatch_amd import pipeline as P
+    out = str(tmp_path / "b%d.npz")
+    mp.spawn(_batch_worker, args=(2, _free_port(), out, False), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    for k in ("owner", "A_sc", "A_icp", "inl"):
+        assert np.array_equal(r0[k], r1[k]), k                      # all results on every rank
+    assert set(r0["owner"].tolist()) == {0, 1}                      # both ranks worked
+    pairs = _batch_pairs()
+    # largest first onto the least loaded rank
+    cost = P.batch_costs([(p[0].shape[1], p[1].shape[1]) for p in pairs])
+    assert r0["owner"][int(np.argmax(cost))] == 0
+    load = [sum(c for c, g in zip(cost, r0["owner"]) if g == r) for r in range(2)]
+    assert max(load) / sum(load) < 0.62
+    for k, (mv, fx) in enumerate(pairs):
+        A_sc, A_icp, inl = oracle.estimate_transform(mv, fx, ransac_trials=60, ransac_error=16, icp_iterations=4, seed=7 + k)
+        assert np.array_equal(r0["inl"][k], inl), k
+        assert np.array_equal(r0["A_sc"][k], A_sc) and np.array_equal(r0["A_icp"][k], A_icp), k
+
+
+def test_batch_failure_on_one_rank_is_raised_on_all(tmp_path, oracle):
+    out = str(tmp_path / "f%d.npz")
+    mp.spawn(_batch_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    assert "error" in r0.files and "error" in r1.files
+    owner = int(r0["owner"][1])
+    assert str([r0, r1][owner]["error"]) == "ValueError"            # the owner re-raises the original exception
+    assert str([r0, r1][1 - owner]["error"]) == "RuntimeError"
+
+
+def test_batch_assignment_is_balanced_and_deterministic():
+    from platymatch_amd import pipeline as P
+    rng = np.random.default_rng(5)
+    sizes = [(int(n), int(n)) for n in rng.integers(2000, 20001, size=64)]      # config 5
+    owner = P.batch_assignment(sizes, 8)
+    assert owner == P.batch_assignment(list(sizes), 8)
+    cost = P.batch_costs(sizes)
+    load = np.array([sum(c for c, g in zip(cost, owner) if g == r) for r in range(8)])
+    assert load.min() > 0 and load.max() / load.mean() < 1.1
+
+
+def _assign_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from platymatch_amd import pipeline as P
+        rng = np.random.default_rng(3)
+        U = rng.random((8, 9, 9))
+        U[5, 2, 3] = np.nan                                   # one hypothesis (owner: rank 1) cannot be solved
+        b = P.shard_bounds(9, world)
+        try:
+            P.assign(torch.as_tensor(U[:, b[rank]:b[rank + 1]].copy()), b, dist.group.WORLD)
+            msg = "no error"
+        except ValueError as e:
+            msg = str(e)
+        np.save(out_path % rank, np.array(msg))
+        # too many ranks for the clouds: refused on every rank before any collective
+        try:
+            P.build_descriptors(OracleBackend(), torch.zeros(3, 1, dtype=torch.float64), torch.zeros(3, 5, dtype=torch.float64),
+                                dist.group.WORLD)
+            raise AssertionError("expected ValueError")
+        except ValueError:
+            pass
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_assign_raises_on_every_rank_instead_of_hanging(tmp_path, oracle):
+    out = str(tmp_path / "a%d.npy")
+    mp.spawn(_assign_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    m0, m1 = str(np.load(out % 0)), str(np.load(out % 1))
+    assert m0 == m1 and "hypothesis 22" in m0 and "invalid numeric" in m0
