@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 1
+#define PM_ABI_VERSION 2
 #define PM_NBINS 360 /* 5 r x 6 theta x 12 phi: the only binning the reference uses (shape_context.py:10) */
 
 #define PM_OK 0
@@ -175,18 +175,23 @@ int pm_legacy_choice(uint32_t *key, int *pos, long n, int k, long trials, int32_
  * order, so a seeded run sees identical sets).  Matched clouds are given indirectly:
  * point k of the matched pair list is (mov[:, rows[k]], fix[:, cols[k]]) — the widget's
  * moving[:, row_indices], fixed[:, col_indices] (_dock_widget.py:622-675); rows/cols may be NULL
- * for the identity.  Per trial t: fit the affine through its `min_samples` (= 4) pairs
- * (get_affine_transform, find_transform.py:4-17), apply it to all n pairs and count
- * ||fixed - predicted|| <= error.
- *   samples   [trials][4] int32 indices into the matched list
- *   A_out     [trials][16] float64 row-major 4x4 (last row 0 0 0 1)
- *   inliers   [trials] int32 */
+ * for the identity.  Per trial t: fit the affine through its `min_samples` (>= 4) pairs
+ * (get_affine_transform, find_transform.py:4-17: the interpolating affine for four pairs, least squares for more),
+ * apply it to all n pairs and count ||fixed - predicted|| <= error.
+ *   samples     [trials][min_samples] int32 indices into the matched list
+ *   A_out       [trials][16] float64 row-major 4x4 (last row 0 0 0 1)
+ *   inliers     [trials] int32
+ *   degenerate  [trials] int32 (may be NULL): 1 where the sample is (nearly) rank deficient — coplanar or repeated
+ *               points.  The reference's pinv returns a minimum-norm answer there; such trials get A = NaN and 0 inliers
+ *               here and the caller refits them with pinv on the host and scores them with pm_ransac_score.
+ * min_samples < 4 (rank deficient by construction) returns PM_ERR_UNSUPPORTED: host pinv + pm_ransac_score. */
 int pm_ransac_affine(const double *mov, int n_mov, const double *fix, int n_fix, const int32_t *rows,
-                     const int32_t *cols, int n, const int32_t *samples, int trials, double error,
-                     double *A_out, int32_t *inliers, void *stream);
+                     const int32_t *cols, int n, const int32_t *samples, int min_samples, int trials, double error,
+                     double *A_out, int32_t *inliers, int32_t *degenerate, void *stream);
 
-/* Score caller-supplied transforms instead of fitting (used for transform='Similar', whose fit
- * stays on the host): A_in [trials][16]. */
+/* Score caller-supplied transforms instead of fitting (transform='Similar', whose 4x4 eigen-decomposition stays on
+ * the host, and the pinv refits of degenerate affine samples): A_in [trials][16]; only rows 0-2 are applied, as
+ * apply_affine_transform does (apply_transform.py:14-17). */
 int pm_ransac_score(const double *mov, int n_mov, const double *fix, int n_fix, const int32_t *rows,
                     const int32_t *cols, int n, const double *A_in, int trials, double error,
                     int32_t *inliers, void *stream);
@@ -200,10 +205,11 @@ int pm_apply_affine(const double *A16, const double *in, int n, double *out, voi
 /* get_affine_transform (find_transform.py:4-17) for full-rank input: least-squares 4x4 with
  * [fixed;1] ~ A [moving;1], solved as centred normal equations (3x3 SPD solve + translation).
  * If nn != NULL the pairing is (mov[:, i], fix[:, nn[i]]), i < n (ICP, perform_icp.py:18);
- * else (mov[:, i], fix[:, i]).  A_out[16]. */
+ * else (mov[:, i], fix[:, i]).  A_out[16].  status1[0] (may be NULL) = 1 if the moving points are (nearly) coplanar /
+ * fewer than four — the normal equations are singular where pinv is not, the caller must then use pinv — else 0. */
 size_t pm_fit_affine_workspace(int n);
 int pm_fit_affine(const double *mov, int n, const double *fix, int n_fix, const int32_t *nn,
-                  double *A_out16, void *ws, size_t ws_bytes, void *stream);
+                  double *A_out16, int32_t *status1, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- ICP ----------------------------------------------------------------------------------- */
 
@@ -239,11 +245,12 @@ int pm_icp_accumulate(const double *mov, int n, const double *fix, int m, const 
 /* From (globally summed) sums: A_est = least-squares affine (perform_icp.py:18), mov <- A_est.mov
  * in place (:23), A_icp <- A_est . A_icp (:25), residual1[0] += nothing; residual_parts receives
  * this block's sum of ||mov_new - fix[nn]|| and count so the caller can form get_error (:24,
- * utils.py:77-88) across ranks: residual_parts[2] = { sum, n }. */
+ * utils.py:77-88) across ranks: residual_parts[2] = { sum, n }.  status1 (may be NULL): set to 1 — never cleared, the
+ * caller zeroes it before a loop — if the moment matrix is (nearly) singular, i.e. the moving cloud is planar. */
 size_t pm_icp_update_workspace(int n);
 int pm_icp_update(const double *sums, const double *origin6, double *mov, int n, const double *fix,
                   int m, const int32_t *nn, double *A_icp16, double *A_est16, double *residual_parts2,
-                  void *ws, size_t ws_bytes, void *stream);
+                  int32_t *status1, void *ws, size_t ws_bytes, void *stream);
 
 /* Same as pm_icp_update with the 4x4 given by the caller instead of solved from sums (a step fitted elsewhere:
  * apply, residual and composition A_icp = A_est . A_icp of perform_icp.py:23-25 on the device). */
@@ -259,10 +266,13 @@ int pm_get_error(const double *a, const double *b, int n, double *out1, void *ws
  *   A_icp      16 doubles out (starts from identity)
  *   residuals  [iters] mean ||moving - fixed[:, nn]|| after each update (the value the reference prints); may be NULL
  *   nn_all     [iters][n] int32 NN indices of every iteration; may be NULL
+ *   status1    [1] int32, may be NULL: 0, or 1 if some iteration's moving cloud was (nearly) planar — the result is then
+ *              meaningless (the reference's pinv handles that case) and the caller must rerun with pinv fits
+ *              (pm_icp_grid_nn + host fit + pm_icp_apply per iteration)
  * iters == 0 returns the identity. */
 size_t pm_icp_workspace(int n, int m);
 int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_icp16,
-           double *residuals, int32_t *nn_all, void *ws, size_t ws_bytes, void *stream);
+           double *residuals, int32_t *nn_all, int32_t *status1, void *ws, size_t ws_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,17 @@ def _cloud(x, name="cloud"):
         raise ValueError("%s is empty" % name)
     if x.shape[1] >= 2 ** 31:
         raise ValueError("%s too large" % name)
+    _here(x, name)
     return x
+
+
+def _here(x, name):
+    """Kernels are enqueued on the current stream of the CURRENT device: operands must live there (a launch on another
+    GPU's stream against foreign memory faults).  Wrap the call in torch.cuda.device(x.device) to work on another GPU."""
+    cur = _t().cuda.current_device()
+    if x.device.index != cur:
+        raise ValueError("%s lives on cuda:%s but the current device is cuda:%d (use `with torch.cuda.device(%s):`)"
+                         % (name, x.device.index, cur, "tensor.device"))
 
 
 def _vec(x, n, name):
@@ -205,6 +215,7 @@ def _desc(x, name):
     if not (nat.is_torch(x) and x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.shape[1] == NBINS
             and x.is_contiguous() and x.shape[0] >= 1):
         raise ValueError("%s must be a contiguous float64 GPU tensor [N, 360]" % name)
+    _here(x, name)
     return x
 
 
@@ -297,18 +308,22 @@ def _pairs(mov, fix, rows, cols):
 
 
 def ransac_affine(mov, fix, rows, cols, samples, error):
-    """samples: [trials, 4] int32 GPU -> (A [trials, 4, 4] float64, inliers [trials] int32)."""
+    """samples: [trials, k] int32 GPU, k >= 4 -> (A [trials, 4, 4] float64, inliers [trials] int32, degenerate [trials] int32).
+    Trials whose sample is (nearly) rank deficient come back flagged, with A = NaN and 0 inliers: refit those with pinv."""
     torch = _t()
     mov, fix, rows, cols, n = _pairs(mov, fix, rows, cols)
-    if not (nat.is_torch(samples) and samples.dim() == 2 and samples.shape[1] == 4):
-        raise ValueError("samples must be [trials, 4] (min_samples = 4 is the only size the affine fit interpolates)")
-    trials = samples.shape[0]
-    samples = _idx(samples.reshape(-1), trials * 4, n, "samples")
+    if not (nat.is_torch(samples) and samples.dim() == 2 and samples.shape[1] >= 4):
+        raise ValueError("samples must be [trials, k] with k >= 4 (fewer pairs are rank deficient by construction: host pinv)")
+    trials, k = samples.shape
+    if k > n:
+        raise ValueError("more samples per trial than matched pairs")
+    samples = _idx(samples.reshape(-1), trials * k, n, "samples")
     A = torch.empty((trials, 4, 4), dtype=torch.float64, device=mov.device)
     inl = torch.empty(trials, dtype=torch.int32, device=mov.device)
+    deg = torch.empty(trials, dtype=torch.int32, device=mov.device)
     check(nat.load().pm_ransac_affine(ptr(mov), mov.shape[1], ptr(fix), fix.shape[1], ptr(rows), ptr(cols), n, ptr(samples),
-                                      trials, float(error), ptr(A), ptr(inl), nat.stream_ptr()))
-    return A, inl
+                                      k, trials, float(error), ptr(A), ptr(inl), ptr(deg), nat.stream_ptr()))
+    return A, inl, deg
 
 
 def ransac_score(mov, fix, rows, cols, A, error):
@@ -333,7 +348,9 @@ def apply_affine(A, xyz, out=None):
     return out
 
 
-def fit_affine(mov, fix, nn=None):
+def fit_affine(mov, fix, nn=None, status=None):
+    """-> A [4, 4].  status: optional int32 GPU tensor [1], set to 1 if the moving points are (nearly) coplanar (the
+    caller must then use pinv, as the reference does), else 0."""
     torch = _t()
     mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
     n = mov.shape[1]
@@ -345,8 +362,16 @@ def fit_affine(mov, fix, nn=None):
     lib = nat.load()
     ws = nat.workspace(lib.pm_fit_affine_workspace(n), mov.device)
     A = torch.empty((4, 4), dtype=torch.float64, device=mov.device)
-    check(lib.pm_fit_affine(ptr(mov), n, ptr(fix), fix.shape[1], ptr(nn), ptr(A), ptr(ws), ws.numel(), nat.stream_ptr()))
+    check(lib.pm_fit_affine(ptr(mov), n, ptr(fix), fix.shape[1], ptr(nn), ptr(A), ptr(_status(status)), ptr(ws), ws.numel(),
+                            nat.stream_ptr()))
     return A
+
+
+def _status(status):
+    torch = _t()
+    if status is not None and not (nat.is_torch(status) and status.is_cuda and status.dtype == torch.int32 and status.numel() == 1):
+        raise ValueError("status must be an int32 GPU tensor with one element")
+    return status
 
 
 def icp_grid(fix):
@@ -395,8 +420,9 @@ def icp_accumulate(mov, fix, nn, origin6, out=None, nn_trusted=False):
     return sums
 
 
-def icp_update(sums, origin6, mov, fix, nn, A_icp, parts_out=None, nn_trusted=False):
-    """In place: mov <- A_est mov, A_icp <- A_est A_icp.  -> (A_est [4,4], residual_parts [2] = (sum, n))."""
+def icp_update(sums, origin6, mov, fix, nn, A_icp, parts_out=None, nn_trusted=False, status=None):
+    """In place: mov <- A_est mov, A_icp <- A_est A_icp.  -> (A_est [4,4], residual_parts [2] = (sum, n)).
+    status: optional int32 GPU tensor [1], set to 1 (never cleared) when the moment matrix is (nearly) singular."""
     torch = _t()
     mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
     n = mov.shape[1]
@@ -408,15 +434,16 @@ def icp_update(sums, origin6, mov, fix, nn, A_icp, parts_out=None, nn_trusted=Fa
     A_est = torch.empty((4, 4), dtype=torch.float64, device=mov.device)
     parts = torch.empty(2, dtype=torch.float64, device=mov.device) if parts_out is None else _vec(parts_out, 2, "parts_out")
     check(lib.pm_icp_update(ptr(sums), ptr(origin6), ptr(mov), n, ptr(fix), fix.shape[1], ptr(nn), ptr(A_icp), ptr(A_est),
-                            ptr(parts), ptr(ws), ws.numel(), nat.stream_ptr()))
+                            ptr(parts), ptr(_status(status)), ptr(ws), ws.numel(), nat.stream_ptr()))
     return A_est, parts
 
 
-def icp_apply(A_est, mov, fix, nn, A_icp):
+def icp_apply(A_est, mov, fix, nn, A_icp, nn_trusted=False):
+    """A step fitted elsewhere: mov <- A_est mov (rows 0-2), A_icp <- A_est A_icp (all four rows) -> residual parts [2]."""
     torch = _t()
     mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
     n = mov.shape[1]
-    nn = None if nn is None else _idx(nn, n, fix.shape[1], "nn")
+    nn = None if nn is None else _idx(nn, n, fix.shape[1], "nn", trusted=nn_trusted)
     A_est, A_icp = _vec(A_est, 16, "A_est"), _vec(A_icp, 16, "A_icp")
     lib = nat.load()
     ws = nat.workspace(lib.pm_icp_update_workspace(n), mov.device)
@@ -437,9 +464,11 @@ def get_error(a, b):
     return out
 
 
-def icp(mov, fix, iters, want_nn=False, ws=None):
+def icp(mov, fix, iters, want_nn=False, ws=None, status=None):
     """Affine ICP loop on the device.  `mov` is updated IN PLACE.
-    -> (A_icp [4,4], residuals [iters], nn_all [iters, n] or None)."""
+    -> (A_icp [4,4], residuals [iters], nn_all [iters, n] or None).
+    status: optional int32 GPU tensor [1]: 0, or 1 if some iteration met a (nearly) planar moving cloud — the results are
+    then meaningless and the loop must be rerun with pinv fits (estimate_transform.perform_icp does)."""
     torch = _t()
     mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
     n, m = mov.shape[1], fix.shape[1]
@@ -452,5 +481,6 @@ def icp(mov, fix, iters, want_nn=False, ws=None):
     A = torch.empty((4, 4), dtype=torch.float64, device=mov.device)
     res = torch.empty(max(iters, 1), dtype=torch.float64, device=mov.device)
     nn_all = torch.empty((max(iters, 1), n), dtype=torch.int32, device=mov.device) if want_nn else None
-    check(lib.pm_icp(ptr(mov), n, ptr(fix), m, iters, ptr(A), ptr(res), ptr(nn_all), ptr(ws), ws.numel(), nat.stream_ptr()))
+    check(lib.pm_icp(ptr(mov), n, ptr(fix), m, iters, ptr(A), ptr(res), ptr(nn_all), ptr(_status(status)), ptr(ws), ws.numel(),
+                     nat.stream_ptr()))
     return A, res[:iters], (nn_all[:iters] if want_nn else None)

@@ -13,6 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libplatymatch_hip.so")
 NBINS = 360
+ABI_VERSION = 2
 ICP_NSUMS = 24
 _lib = None
 _lock = threading.Lock()
@@ -47,13 +48,13 @@ SIGNATURES = {
     "pm_chi2_symmetry_check": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
                                         _c_void_p, _c_void_p]),
     "pm_chi2_cost8_sym": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_size_t, _c_size_t, _c_void_p]),
-    "pm_ransac_affine": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int,
-                                  _c_double, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_ransac_affine": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int,
+                                  _c_double, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "pm_ransac_score": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int,
                                  _c_double, _c_void_p, _c_void_p]),
     "pm_apply_affine": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p]),
     "pm_fit_affine_workspace": (_c_size_t, [_c_int]),
-    "pm_fit_affine": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_fit_affine": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_icp_nn_workspace": (_c_size_t, [_c_int, _c_int]),
     "pm_icp_nn": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_icp_grid_workspace": (_c_size_t, [_c_int]),
@@ -66,13 +67,13 @@ SIGNATURES = {
                                    _c_size_t, _c_void_p]),
     "pm_icp_update_workspace": (_c_size_t, [_c_int]),
     "pm_icp_update": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
-                               _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+                               _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_icp_apply": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                               _c_size_t, _c_void_p]),
     "pm_get_error_workspace": (_c_size_t, [_c_int]),
     "pm_get_error": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_icp_workspace": (_c_size_t, [_c_int, _c_int]),
-    "pm_icp": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+    "pm_icp": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                         _c_size_t, _c_void_p]),
 }
 
@@ -101,8 +102,8 @@ def load():
                 fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
                 fn.restype = res
                 fn.argtypes = args
-            if lib.pm_version() != 1:
-                raise NativeError("libplatymatch_hip.so ABI version %d, expected 1" % lib.pm_version())
+            if lib.pm_version() != ABI_VERSION:
+                raise NativeError("libplatymatch_hip.so ABI version %d, expected %d" % (lib.pm_version(), ABI_VERSION))
             _lib = lib
     return _lib
 
@@ -135,8 +136,13 @@ def device(dev=None):
     return torch.device(dev)
 
 
-def stream_ptr():
-    return torch_mod().cuda.current_stream().cuda_stream
+def stream_ptr(t=None):
+    """hipStream_t of torch's current stream — on the device of tensor `t` if given (kernels must be enqueued on a stream
+    of the device that owns their operands), else on the current device."""
+    cuda = torch_mod().cuda
+    if t is not None and t.is_cuda:
+        return cuda.current_stream(t.device).cuda_stream
+    return cuda.current_stream().cuda_stream
 
 
 def is_torch(x):

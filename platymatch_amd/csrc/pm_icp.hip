@@ -17,7 +17,7 @@ namespace pm {
 
 // moment sums + solve + apply + residual of one iteration (pm_transform.hip)
 int refit_apply(double *mov, int n, const double *fix, int m, const int32_t *nn, const double *origin6, double *A_icp16,
-                double *acc_ws, double *res_ring, int it, hipStream_t s);
+                double *acc_ws, double *res_ring, int it, int32_t *status, hipStream_t s);
 int residual_rows(const double *res_ring, int n, int count, double *mean_out, hipStream_t s);
 size_t residual_ring_bytes(int n);
 constexpr int ICP_RES_RING = 64;               // = TF_RES_RING (pm_transform.hip)
@@ -172,8 +172,10 @@ int nn_search(const double *mov, int n, const double *fix, int m, int32_t *nn, d
     return launch_status();
 }
 
-__global__ void icp_init_kernel(const double *__restrict__ fix, int m, double *__restrict__ origin6, double *__restrict__ A16) {
+__global__ void icp_init_kernel(const double *__restrict__ fix, int m, double *__restrict__ origin6, double *__restrict__ A16,
+                                int32_t *__restrict__ status) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (status) status[0] = 0;
         for (int c = 0; c < 3; ++c) { origin6[c] = fix[(size_t)c * m]; origin6[3 + c] = fix[(size_t)c * m]; }
         for (int k = 0; k < 16; ++k) A16[k] = (k % 5 == 0) ? 1.0 : 0.0;
     }
@@ -237,7 +239,7 @@ int pm_icp_nn(const double *mov, int n, const double *fix, int m, int32_t *nn, d
 size_t pm_icp_workspace(int n, int m) { return (n > 0 && m > 0) ? pm::icp_layout(n, m).total : 0; }
 
 int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_icp16, double *residuals, int32_t *nn_all,
-           void *ws, size_t ws_bytes, void *stream) {
+           int32_t *status1, void *ws, size_t ws_bytes, void *stream) {
     if (!mov || !fix || !A_icp16 || n <= 0 || m <= 0 || iters < 0) return PM_ERR_INVALID_ARG;
     if (!ws || ws_bytes < pm_icp_workspace(n, m)) return PM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -247,7 +249,7 @@ int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_ic
     double *acc_ws = (double *)(base + L.acc_ws);
     double *res_ring = (double *)(base + L.res_ring);
     double *origin = (double *)(base + L.origin);
-    pm::icp_init_kernel<<<1, 64, 0, s>>>(fix, m, origin, A_icp16);
+    pm::icp_init_kernel<<<1, 64, 0, s>>>(fix, m, origin, A_icp16, status1);
     if (iters > 0) {                                   // the fixed cloud never changes: bin it once
         int rc = pm::grid_build(fix, m, base + L.nn_ws, s);
         if (rc != PM_OK) return rc;
@@ -256,7 +258,7 @@ int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_ic
         int32_t *nn = nn_all ? nn_all + (size_t)it * n : nn_buf;
         int rc = pm::grid_query(mov, n, m, base + L.nn_ws, nn, nullptr, s);
         if (rc != PM_OK) return rc;
-        rc = pm::refit_apply(mov, n, fix, m, nn, origin, A_icp16, acc_ws, res_ring, it, s);
+        rc = pm::refit_apply(mov, n, fix, m, nn, origin, A_icp16, acc_ws, res_ring, it, status1, s);
         if (rc != PM_OK) return rc;
         const int filled = it % pm::ICP_RES_RING + 1;  // residual partials waiting in the ring
         if (residuals && (filled == pm::ICP_RES_RING || it + 1 == iters)) {

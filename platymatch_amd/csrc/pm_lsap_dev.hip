@@ -1,0 +1,128 @@
+// pm_lsap_dev.hip — DEVICE side of the assignment solve: everything that touches the dense N x M cost matrix.
+// Reference call sites: scipy.optimize.linear_sum_assignment(U_h) for the eight matrices, _dock_widget.py:604-611.
+// The matrices (up to 8 x 3.2 GB at 20 000 nuclei) stay in HBM; the host solves a sparse core (pm_lsap_core.cpp) and these
+// two kernels connect it with the dense problem, one streaming pass each (HBM-read bound: 8 B per entry, read once):
+//   row_select_kernel   per row, a handful of entries with the smallest cost - v[col]: the core's initial edges (v = 0)
+//                       and, with the solver's column duals, the PRICING step (which entries violate dual feasibility);
+//   certificate_kernel  the optimality certificate of a finished solve against every entry of the matrix, plus the list of
+//                       entries within eps of tight that decides uniqueness (pm_lsap_unique).
+#include "pm_common.h"
+
+namespace pm {
+
+constexpr int LS_THREADS = 256;
+
+// One workgroup per row.  Thread t keeps the entry minimising red = cost - v[col] over its columns t, t + 256, ... (first
+// one on ties); the 256 thread minima are ranked by (red, col) and the k best written in rank order.  The row's overall
+// minimum is always among them (rank 0); the rest are a cheap, deterministic sample of the row's small entries — pricing
+// repairs whatever the sample missed, so it need not be the exact k smallest.  Slots beyond the row's width get col = -1.
+template <bool HAS_V>
+__global__ __launch_bounds__(LS_THREADS) void row_select_kernel(const double *__restrict__ U, int nc, size_t ld,
+                                                                const double *__restrict__ v, int k, int32_t *__restrict__ out_col,
+                                                                double *__restrict__ out_cost, int32_t *__restrict__ nonfinite) {
+    __shared__ double s_red[LS_THREADS];
+    __shared__ int s_col[LS_THREADS];
+    const int tid = threadIdx.x;
+    const double *row = U + (size_t)blockIdx.x * ld;
+    double best = INFINITY, best_cost = INFINITY;
+    int best_col = 0x7fffffff;
+    bool bad = false;
+    for (int j = tid; j < nc; j += LS_THREADS) {
+        const double c = row[j];
+        bad |= !(fabs(c) < INFINITY);                       // NaN or +-inf: the caller takes SciPy's own path for such matrices
+        const double red = HAS_V ? c - v[j] : c;
+        if (red < best) { best = red; best_cost = c; best_col = j; }
+    }
+    s_red[tid] = best;
+    s_col[tid] = best_col;
+    __syncthreads();
+    int rank = 0;
+    for (int t = 0; t < LS_THREADS; ++t) {
+        const double r = s_red[t];                          // same address in every lane: an LDS broadcast
+        const int c = s_col[t];
+        rank += (r < best || (r == best && c < best_col)) ? 1 : 0;
+    }
+    if (rank < k) {
+        out_col[(size_t)blockIdx.x * k + rank] = (best_col == 0x7fffffff) ? -1 : best_col;
+        out_cost[(size_t)blockIdx.x * k + rank] = best_cost;
+    }
+    if (bad) nonfinite[0] = 1;
+}
+
+// Optimality certificate of (u, v, col4row) for the nr x nc matrix U — the conditions of LP duality, entry by entry:
+//   dual feasibility          (U[i][j] - v[j]) - u[i] >= -delta          for every entry            -> summary[0] counts failures
+//   complementary slackness   |(U[i][j] - v[j]) - u[i]| <= delta         for j = col4row[i]          -> summary[2] counts failures
+// and the non-matching entries with reduced cost <= eps (the "tight" edges uniqueness is decided on): appended to
+// tight[cap][2] in arbitrary order, summary[1] = their number (may exceed cap: then the list is incomplete).
+// stats[0] = largest |reduced cost| on a matched entry, stats[1] = largest violation (positive number), as float64 bit
+// patterns (non-negative doubles order like their bit patterns, so an integer atomic max does it).
+__global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *__restrict__ U, int nc, size_t ld,
+                                                                 const double *__restrict__ u, const double *__restrict__ v,
+                                                                 const int32_t *__restrict__ col4row, double delta, double eps,
+                                                                 int32_t *__restrict__ summary, unsigned long long *__restrict__ stats,
+                                                                 int32_t *__restrict__ tight, int cap) {
+    __shared__ int s_cnt[2];
+    __shared__ unsigned long long s_max[2];
+    const int tid = threadIdx.x, i = blockIdx.x;
+    if (tid < 2) { s_cnt[tid] = 0; s_max[tid] = 0ull; }
+    __syncthreads();
+    const double *row = U + (size_t)i * ld;
+    const double ui = u[i];
+    const int jm = col4row[i];
+    int viol = 0, loose = 0;
+    double worst = 0.0, slack = 0.0;
+    for (int j = tid; j < nc; j += LS_THREADS) {
+        const double red = (row[j] - v[j]) - ui;
+        if (j == jm) {
+            if (!(fabs(red) <= delta)) ++loose;
+            slack = fmax(slack, fabs(red));                  // fmax drops NaN; `loose` has counted it
+        } else if (!(red >= -delta)) {
+            ++viol;
+            worst = fmax(worst, -red);
+        } else if (red <= eps) {
+            const int at = atomicAdd(&summary[1], 1);
+            if (at < cap) { tight[2 * (size_t)at] = i; tight[2 * (size_t)at + 1] = j; }
+        }
+    }
+    if (viol) atomicAdd(&s_cnt[0], viol);
+    if (loose) atomicAdd(&s_cnt[1], loose);
+    if (slack > 0.0) atomicMax(&s_max[0], (unsigned long long)__double_as_longlong(slack));
+    if (worst > 0.0) atomicMax(&s_max[1], (unsigned long long)__double_as_longlong(worst));
+    __syncthreads();
+    if (tid == 0) {
+        if (s_cnt[0]) atomicAdd(&summary[0], s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&summary[2], s_cnt[1]);
+        if (s_max[0]) atomicMax(&stats[0], s_max[0]);
+        if (s_max[1]) atomicMax(&stats[1], s_max[1]);
+    }
+}
+
+}  // namespace pm
+
+extern "C" {
+
+int pm_lsap_row_select(const double *U, int nr, int nc, size_t ld, const double *v, int k, int32_t *out_col, double *out_cost,
+                       int32_t *nonfinite1, void *stream) {
+    if (!U || !out_col || !out_cost || !nonfinite1 || nr <= 0 || nc <= 0 || ld < (size_t)nc || k <= 0 || k > pm::LS_THREADS)
+        return PM_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(nonfinite1, 0, sizeof(int32_t), s) != hipSuccess) return pm::launch_status();
+    if (v) pm::row_select_kernel<true><<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, v, k, out_col, out_cost, nonfinite1);
+    else pm::row_select_kernel<false><<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, nullptr, k, out_col, out_cost, nonfinite1);
+    return pm::launch_status();
+}
+
+int pm_lsap_certificate(const double *U, int nr, int nc, size_t ld, const double *u, const double *v, const int32_t *col4row,
+                        double delta, double eps, int32_t *summary4, double *stats2, int32_t *tight, int cap, void *stream) {
+    if (!U || !u || !v || !col4row || !summary4 || !stats2 || !tight || nr <= 0 || nc < nr || ld < (size_t)nc || cap <= 0 ||
+        !(delta >= 0.0) || !(eps >= 0.0))
+        return PM_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(summary4, 0, 4 * sizeof(int32_t), s) != hipSuccess) return pm::launch_status();
+    if (hipMemsetAsync(stats2, 0, 2 * sizeof(double), s) != hipSuccess) return pm::launch_status();
+    pm::certificate_kernel<<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, u, v, col4row, delta, eps, summary4, (unsigned long long *)stats2,
+                                                          tight, cap);
+    return pm::launch_status();
+}
+
+}  // extern "C"

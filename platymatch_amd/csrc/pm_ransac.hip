@@ -7,8 +7,10 @@
 // RNG calls, same order) and one launch evaluates them all: lane <-> trial (its 4x4 stays in
 // registers), the matched pairs stream through LDS as wave-uniform broadcasts, the four waves of a
 // workgroup split each staged chunk and their counts are added at the end.
-// The 4-pair fit is the exact interpolating affine (find_transform.py:4-17 on a square, full-rank
-// system), obtained like every other fit here from centred moments (pm_solve.h).
+// The fit of a trial's min_samples pairs (find_transform.py:4-17): four pairs -> the interpolating affine from the
+// sample's edge matrices; more -> least squares from moments centred on the sample means (pm_solve.h).  Samples that
+// are (nearly) rank deficient — coplanar or repeated points, where the reference's pinv returns a minimum-norm
+// answer — are flagged, score zero here, and are refitted by the host mirror with the reference's own expression.
 #include "pm_common.h"
 #include "pm_solve.h"
 
@@ -23,9 +25,10 @@ template <bool FIT>
 __global__ __launch_bounds__(RS_THREADS) void ransac_kernel(const double *__restrict__ mov, int n_mov,
                                                             const double *__restrict__ fix, int n_fix,
                                                             const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
-                                                            int n, const int32_t *__restrict__ samples,
+                                                            int n, const int32_t *__restrict__ samples, int k,
                                                             const double *__restrict__ A_in, int trials, double error,
-                                                            double *__restrict__ A_out, int32_t *__restrict__ inliers) {
+                                                            double *__restrict__ A_out, int32_t *__restrict__ inliers,
+                                                            int32_t *__restrict__ degenerate) {
     __shared__ double Pm[3][RS_CHUNK];
     __shared__ double Pf[3][RS_CHUNK];
     __shared__ int cnt_s[RS_WAVES][64];
@@ -35,39 +38,58 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kernel(const double *__rest
     const int tc = min(t, trials - 1);
 
     double A[16];
+    bool flagged = false;
     if (FIT) {
-        // moments of the four sampled pairs about the first of them
-        double sums[PM_ICP_NSUMS], origin[6];
-#pragma unroll
-        for (int k = 0; k < PM_ICP_NSUMS; ++k) sums[k] = 0.0;
-        sums[0] = 4.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = samples[(size_t)tc * 4 + q];
-            const int im = rows ? rows[k] : k, jf = cols ? cols[k] : k;
-            double a[3], f[3];
+        auto pair_of = [&](int q, double a[3], double f[3]) {
+            const int s = samples[(size_t)tc * k + q];
+            const int im = rows ? rows[s] : s, jf = cols ? cols[s] : s;
 #pragma unroll
             for (int c = 0; c < 3; ++c) { a[c] = mov[(size_t)c * n_mov + im]; f[c] = fix[(size_t)c * n_fix + jf]; }
-            if (q == 0) {
+        };
+        if (k == 4) {
+            // four pairs: the interpolating affine from the edge matrices (conditioned like the sample itself)
+            double m4[4][3], f4[4][3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { origin[c] = a[c]; origin[3 + c] = f[c]; }
+            for (int q = 0; q < 4; ++q) pair_of(q, m4[q], f4[q]);
+            const double had = affine_from_4(m4, f4, A);
+            flagged = !(had > PM_DEGENERATE_SIMPLEX);                      // also true for NaN
+        } else {
+            // k > 4 pairs: least squares from moments centred on the sample means (two passes over the k pairs)
+            double mb[3] = {0.0, 0.0, 0.0}, fb[3] = {0.0, 0.0, 0.0};
+            for (int q = 0; q < k; ++q) {
+                double a[3], f[3];
+                pair_of(q, a, f);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { mb[c] += a[c]; fb[c] += f[c]; }
             }
+            const double rk = 1.0 / (double)k;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { a[c] -= origin[c]; f[c] -= origin[3 + c]; }
-            sums[1] += a[0]; sums[2] += a[1]; sums[3] += a[2];
-            sums[4] += f[0]; sums[5] += f[1]; sums[6] += f[2];
-            sums[7] += a[0] * a[0]; sums[8] += a[0] * a[1]; sums[9] += a[0] * a[2];
-            sums[10] += a[1] * a[1]; sums[11] += a[1] * a[2]; sums[12] += a[2] * a[2];
+            for (int c = 0; c < 3; ++c) { mb[c] *= rk; fb[c] *= rk; }
+            double cmm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, cfm[9];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 9; ++c) cfm[c] = 0.0;
+            for (int q = 0; q < k; ++q) {
+                double a[3], f[3];
+                pair_of(q, a, f);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) sums[13 + 3 * r + c] += f[r] * a[c];
-            sums[22] += (f[0] * f[0] + f[1] * f[1]) + f[2] * f[2];
+                for (int c = 0; c < 3; ++c) { a[c] -= mb[c]; f[c] -= fb[c]; }
+                cmm[0] += a[0] * a[0]; cmm[1] += a[0] * a[1]; cmm[2] += a[0] * a[2];
+                cmm[3] += a[1] * a[1]; cmm[4] += a[1] * a[2]; cmm[5] += a[2] * a[2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) cfm[3 * r + c] += f[r] * a[c];
+            }
+            const double ratio = affine_from_centred(cmm, cfm, mb, fb, A);
+            flagged = !(ratio > PM_DEGENERATE_MOMENTS_SAMPLE);
         }
-        affine_from_sums(sums, origin, A);
+        if (flagged) {                  // never an inlier below; the host refits such trials with the reference's pinv
+#pragma unroll
+            for (int q = 0; q < 16; ++q) A[q] = NAN;
+        }
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) A[k] = A_in[(size_t)tc * 16 + k];
+        for (int q = 0; q < 16; ++q) A[q] = A_in[(size_t)tc * 16 + q];
     }
 
     int cnt = 0;
@@ -100,6 +122,7 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kernel(const double *__rest
     __syncthreads();
     if (wave == 0 && t < trials) {
         inliers[t] = cnt_s[0][lane] + cnt_s[1][lane] + cnt_s[2][lane] + cnt_s[3][lane];
+        if (FIT && degenerate) degenerate[t] = flagged ? 1 : 0;
         if (FIT && A_out) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) A_out[(size_t)t * 16 + k] = A[k];
@@ -112,11 +135,13 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kernel(const double *__rest
 extern "C" {
 
 int pm_ransac_affine(const double *mov, int n_mov, const double *fix, int n_fix, const int32_t *rows, const int32_t *cols,
-                     int n, const int32_t *samples, int trials, double error, double *A_out, int32_t *inliers,
-                     void *stream) {
+                     int n, const int32_t *samples, int min_samples, int trials, double error, double *A_out, int32_t *inliers,
+                     int32_t *degenerate, void *stream) {
     if (!mov || !fix || !samples || !inliers || n_mov <= 0 || n_fix <= 0 || n <= 0 || trials <= 0) return PM_ERR_INVALID_ARG;
+    if (min_samples < 4) return PM_ERR_UNSUPPORTED;      // fewer than four pairs: rank deficient by construction (host pinv)
+    if (min_samples > n) return PM_ERR_INVALID_ARG;
     pm::ransac_kernel<true><<<(trials + 63) / 64, pm::RS_THREADS, 0, (hipStream_t)stream>>>(
-        mov, n_mov, fix, n_fix, rows, cols, n, samples, nullptr, trials, error, A_out, inliers);
+        mov, n_mov, fix, n_fix, rows, cols, n, samples, min_samples, nullptr, trials, error, A_out, inliers, degenerate);
     return pm::launch_status();
 }
 
@@ -124,7 +149,7 @@ int pm_ransac_score(const double *mov, int n_mov, const double *fix, int n_fix, 
                     int n, const double *A_in, int trials, double error, int32_t *inliers, void *stream) {
     if (!mov || !fix || !A_in || !inliers || n_mov <= 0 || n_fix <= 0 || n <= 0 || trials <= 0) return PM_ERR_INVALID_ARG;
     pm::ransac_kernel<false><<<(trials + 63) / 64, pm::RS_THREADS, 0, (hipStream_t)stream>>>(
-        mov, n_mov, fix, n_fix, rows, cols, n, nullptr, A_in, trials, error, nullptr, inliers);
+        mov, n_mov, fix, n_fix, rows, cols, n, nullptr, 0, A_in, trials, error, nullptr, inliers, nullptr);
     return pm::launch_status();
 }
 

@@ -7,9 +7,19 @@
 
 namespace pm {
 
+// Conditioning thresholds below which a fit is reported as degenerate (callers then refit with the reference's own
+// pinv on the host, which returns the minimum-norm answer for rank-deficient input: find_transform.py:17).
+//   PM_DEGENERATE_MOMENTS: det(Cmm) / (trace(Cmm)/3)^3 of the centred 3x3 moment matrix (1 for an isotropic cloud, 0 for a
+//                          planar one); the normal-equation solve loses about eps / ratio relative accuracy.
+//   PM_DEGENERATE_SIMPLEX: |det D| / (|d1| |d2| |d3|) of the edge matrix of a 4-point sample (Hadamard ratio).
+#define PM_DEGENERATE_MOMENTS 1e-8
+#define PM_DEGENERATE_MOMENTS_SAMPLE 1e-6
+#define PM_DEGENERATE_SIMPLEX 1e-6
+
 // L (3x3 row-major) = Cfm . inverse(Cmm), Cmm symmetric given as {00,01,02,11,12,22}.
-// Cofactor inverse; a singular Cmm (coplanar points) yields inf/NaN, which callers treat as "no fit".
-__device__ __forceinline__ void solve_sym3(const double cmm[6], const double cfm[9], double L[9]) {
+// Cofactor inverse; a singular Cmm (coplanar points) yields inf/NaN.  Returns det / (trace/3)^3 (NaN-propagating), the
+// conditioning measure callers compare with PM_DEGENERATE_MOMENTS.
+__device__ __forceinline__ double solve_sym3(const double cmm[6], const double cfm[9], double L[9]) {
     const double a = cmm[0], b = cmm[1], c = cmm[2], d = cmm[3], e = cmm[4], f = cmm[5];
     const double i00 = d * f - e * e, i01 = c * e - b * f, i02 = b * e - c * d;
     const double i11 = a * f - c * c, i12 = b * c - a * e, i22 = a * d - b * b;
@@ -21,10 +31,62 @@ __device__ __forceinline__ void solve_sym3(const double cmm[6], const double cfm
 #pragma unroll
         for (int q = 0; q < 3; ++q)
             L[3 * r + q] = (cfm[3 * r] * inv[q] + cfm[3 * r + 1] * inv[3 + q]) + cfm[3 * r + 2] * inv[6 + q];
+    const double tr3 = ((a + d) + f) * (1.0 / 3.0);
+    return det / ((tr3 * tr3) * tr3);
+}
+
+// The affine through exactly four pairs (get_affine_transform on a square system, find_transform.py:4-17): with edge
+// matrices Dm = [m1-m0, m2-m0, m3-m0], Df likewise (columns), L = Df Dm^-1 and t = f0 - L m0.  Conditioned like Dm
+// itself (the moment form squares it).  m, f: [4][3].  Returns the Hadamard ratio of Dm (0 for coplanar samples).
+__device__ __forceinline__ double affine_from_4(const double m[4][3], const double f[4][3], double A[16]) {
+    double dm[3][3], df[3][3];          // [edge][coordinate]
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { dm[e][c] = m[e + 1][c] - m[0][c]; df[e][c] = f[e + 1][c] - f[0][c]; }
+    // cross products = rows of det * Dm^-1 (Dm has the edges as columns: Dm[c][e] = dm[e][c])
+    const double c0[3] = {dm[1][1] * dm[2][2] - dm[1][2] * dm[2][1], dm[1][2] * dm[2][0] - dm[1][0] * dm[2][2], dm[1][0] * dm[2][1] - dm[1][1] * dm[2][0]};
+    const double c1[3] = {dm[2][1] * dm[0][2] - dm[2][2] * dm[0][1], dm[2][2] * dm[0][0] - dm[2][0] * dm[0][2], dm[2][0] * dm[0][1] - dm[2][1] * dm[0][0]};
+    const double c2[3] = {dm[0][1] * dm[1][2] - dm[0][2] * dm[1][1], dm[0][2] * dm[1][0] - dm[0][0] * dm[1][2], dm[0][0] * dm[1][1] - dm[0][1] * dm[1][0]};
+    const double det = (dm[0][0] * c0[0] + dm[0][1] * c0[1]) + dm[0][2] * c0[2];
+    const double rdet = 1.0 / det;
+    // inverse rows: inv[e][c] = cross_e[c] / det  (inv . Dm = I: row e dotted with edge e' is delta)
+    double L[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            L[3 * r + c] = ((df[0][r] * c0[c] + df[1][r] * c1[c]) + df[2][r] * c2[c]) * rdet;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        A[4 * r] = L[3 * r]; A[4 * r + 1] = L[3 * r + 1]; A[4 * r + 2] = L[3 * r + 2];
+        A[4 * r + 3] = f[0][r] - ((L[3 * r] * m[0][0] + L[3 * r + 1] * m[0][1]) + L[3 * r + 2] * m[0][2]);
+    }
+    A[12] = 0.0; A[13] = 0.0; A[14] = 0.0; A[15] = 1.0;
+    const double n0 = (dm[0][0] * dm[0][0] + dm[0][1] * dm[0][1]) + dm[0][2] * dm[0][2];
+    const double n1 = (dm[1][0] * dm[1][0] + dm[1][1] * dm[1][1]) + dm[1][2] * dm[1][2];
+    const double n2 = (dm[2][0] * dm[2][0] + dm[2][1] * dm[2][1]) + dm[2][2] * dm[2][2];
+    return fabs(det) / __builtin_sqrt((n0 * n1) * n2);
+}
+
+// Least-squares affine from CENTRED moments (cmm, cfm about the means mb, fb; absolute coordinates): L = Cfm Cmm^-1,
+// t = fb - L mb.  Returns the conditioning ratio of solve_sym3.
+__device__ __forceinline__ double affine_from_centred(const double cmm[6], const double cfm[9], const double mb[3], const double fb[3],
+                                                      double A[16]) {
+    double L[9];
+    const double ratio = solve_sym3(cmm, cfm, L);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        A[4 * r] = L[3 * r]; A[4 * r + 1] = L[3 * r + 1]; A[4 * r + 2] = L[3 * r + 2];
+        A[4 * r + 3] = fb[r] - ((L[3 * r] * mb[0] + L[3 * r + 1] * mb[1]) + L[3 * r + 2] * mb[2]);
+    }
+    A[12] = 0.0; A[13] = 0.0; A[14] = 0.0; A[15] = 1.0;
+    return ratio;
 }
 
 // sums: PM_ICP_NSUMS layout about origin6 = {origin_m(3), origin_f(3)} -> A (4x4 row-major).
-__device__ __forceinline__ void affine_from_sums(const double *sums, const double *origin6, double A[16]) {
+// Returns the conditioning ratio of solve_sym3 (compare with PM_DEGENERATE_MOMENTS).
+__device__ __forceinline__ double affine_from_sums(const double *sums, const double *origin6, double A[16]) {
     const double n = sums[0], rn = 1.0 / n;
     const double mb[3] = {sums[1] * rn, sums[2] * rn, sums[3] * rn};
     const double fb[3] = {sums[4] * rn, sums[5] * rn, sums[6] * rn};
@@ -40,7 +102,7 @@ __device__ __forceinline__ void affine_from_sums(const double *sums, const doubl
 #pragma unroll
         for (int q = 0; q < 3; ++q) cfm[3 * r + q] = sums[13 + 3 * r + q] - n * fb[r] * mb[q];
     double L[9];
-    solve_sym3(cmm, cfm, L);
+    const double ratio = solve_sym3(cmm, cfm, L);
     const double ma[3] = {mb[0] + origin6[0], mb[1] + origin6[1], mb[2] + origin6[2]};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -48,6 +110,7 @@ __device__ __forceinline__ void affine_from_sums(const double *sums, const doubl
         A[4 * r + 3] = (fb[r] + origin6[3 + r]) - ((L[3 * r] * ma[0] + L[3 * r + 1] * ma[1]) + L[3 * r + 2] * ma[2]);
     }
     A[12] = 0.0; A[13] = 0.0; A[14] = 0.0; A[15] = 1.0;
+    return ratio;
 }
 
 }  // namespace pm

@@ -120,11 +120,13 @@ __global__ __launch_bounds__(64) void accumulate_final(const double *__restrict_
     if (k == NS) sums[1 + NS] = 0.0;
 }
 
-__global__ void solve_kernel(const double *__restrict__ sums, const double *__restrict__ origin6, double *__restrict__ A16) {
+__global__ void solve_kernel(const double *__restrict__ sums, const double *__restrict__ origin6, double *__restrict__ A16,
+                             int32_t *__restrict__ status) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         double A[16];
-        affine_from_sums(sums, origin6, A);
+        const double ratio = affine_from_sums(sums, origin6, A);
         for (int k = 0; k < 16; ++k) A16[k] = A[k];
+        if (status) status[0] = (ratio > PM_DEGENERATE_MOMENTS) ? 0 : 1;
     }
 }
 
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(TF_THREADS) void update_kernel(const double *__rest
                                                             const double *__restrict__ origin6,
                                                             const double *__restrict__ A_given, double *mov, int n, const double *__restrict__ fix, int m,
                                                             const int32_t *__restrict__ nn, double *A_icp16, double *A_est16,
-                                                            double *__restrict__ partial) {
+                                                            double *__restrict__ partial, int32_t *status) {
     __shared__ double scratch[TF_THREADS / 64];
     __shared__ double As[16];
     __shared__ double sums_s[PM_ICP_NSUMS];
@@ -146,13 +148,17 @@ __global__ __launch_bounds__(TF_THREADS) void update_kernel(const double *__rest
     }
     if (threadIdx.x == 0) {
         double A[16];
+        double ratio = 1.0;
         if (A_given) {
             for (int k = 0; k < 16; ++k) A[k] = A_given[k];
         } else {
-            affine_from_sums(acc_partial ? sums_s : sums, origin6, A);   // identical operations in every block -> identical A_est
+            ratio = affine_from_sums(acc_partial ? sums_s : sums, origin6, A);   // identical operations in every block -> identical A_est
         }
         for (int k = 0; k < 16; ++k) As[k] = A[k];
         if (blockIdx.x == 0) {
+            // a (nearly) planar moving cloud: the normal equations are singular where the reference's pinv is not; sticky flag,
+            // the host mirror then reruns the refinement with pinv fits (perform_icp.py:18, find_transform.py:17)
+            if (status && !(ratio > PM_DEGENERATE_MOMENTS)) status[0] = 1;
             if (A_est16)
                 for (int k = 0; k < 16; ++k) A_est16[k] = A[k];
             if (A_icp16) {                   // perform_icp.py:25, np.matmul(A_est, A_icp)
@@ -233,9 +239,10 @@ int accumulate(const double *mov, int n, const double *fix, int m, const int32_t
 }
 
 int update(const double *sums, const double *origin6, const double *A_given, double *mov, int n, const double *fix, int m,
-           const int32_t *nn, double *A_icp16, double *A_est16, double *parts2, double *mean_out, double *ws, hipStream_t s) {
+           const int32_t *nn, double *A_icp16, double *A_est16, double *parts2, double *mean_out, double *ws, int32_t *status,
+           hipStream_t s) {
     const int nb = tf_blocks(n);
-    update_kernel<<<nb, TF_THREADS, 0, s>>>(sums, nullptr, origin6, A_given, mov, n, fix, m, nn, A_icp16, A_est16, ws);
+    update_kernel<<<nb, TF_THREADS, 0, s>>>(sums, nullptr, origin6, A_given, mov, n, fix, m, nn, A_icp16, A_est16, ws, status);
     residual_final<<<1, 64, 0, s>>>(ws, nb, n, parts2, mean_out);
     return launch_status();
 }
@@ -245,11 +252,11 @@ int update(const double *sums, const double *origin6, const double *A_given, dou
 // hence the same bits.  The residual partials of iteration `it` go to row it % TF_RES_RING of res_ring; the caller
 // turns the rows into mean residuals with residual_rows().  acc_ws: tf_blocks(n) * NS doubles.
 int refit_apply(double *mov, int n, const double *fix, int m, const int32_t *nn, const double *origin6, double *A_icp16,
-                double *acc_ws, double *res_ring, int it, hipStream_t s) {
+                double *acc_ws, double *res_ring, int it, int32_t *status, hipStream_t s) {
     const int nb = tf_blocks(n);
     accumulate_kernel<<<nb, TF_THREADS, 0, s>>>(mov, n, fix, m, nn, origin6, acc_ws);
     update_kernel<<<nb, TF_THREADS, 0, s>>>(nullptr, acc_ws, origin6, nullptr, mov, n, fix, m, nn, A_icp16, nullptr,
-                                            res_ring + (size_t)(it % TF_RES_RING) * nb);
+                                            res_ring + (size_t)(it % TF_RES_RING) * nb, status);
     return launch_status();
 }
 
@@ -292,12 +299,12 @@ int pm_icp_accumulate(const double *mov, int n, const double *fix, int m, const 
 size_t pm_icp_update_workspace(int n) { return n > 0 ? (size_t)pm::tf_blocks(n) * sizeof(double) : 0; }
 
 int pm_icp_update(const double *sums, const double *origin6, double *mov, int n, const double *fix, int m,
-                  const int32_t *nn, double *A_icp16, double *A_est16, double *residual_parts2, void *ws,
+                  const int32_t *nn, double *A_icp16, double *A_est16, double *residual_parts2, int32_t *status1, void *ws,
                   size_t ws_bytes, void *stream) {
     if (!sums || !origin6 || !mov || !fix || n <= 0 || m <= 0) return PM_ERR_INVALID_ARG;
     if (!ws || ws_bytes < pm_icp_update_workspace(n)) return PM_ERR_WORKSPACE;
     return pm::update(sums, origin6, nullptr, mov, n, fix, m, nn, A_icp16, A_est16, residual_parts2, nullptr, (double *)ws,
-                      (hipStream_t)stream);
+                      status1, (hipStream_t)stream);
 }
 
 int pm_icp_apply(const double *A_est16, double *mov, int n, const double *fix, int m, const int32_t *nn, double *A_icp16,
@@ -305,7 +312,7 @@ int pm_icp_apply(const double *A_est16, double *mov, int n, const double *fix, i
     if (!A_est16 || !mov || !fix || n <= 0 || m <= 0) return PM_ERR_INVALID_ARG;
     if (!ws || ws_bytes < pm_icp_update_workspace(n)) return PM_ERR_WORKSPACE;
     return pm::update(nullptr, nullptr, A_est16, mov, n, fix, m, nn, A_icp16, nullptr, residual_parts2, nullptr, (double *)ws,
-                      (hipStream_t)stream);
+                      nullptr, (hipStream_t)stream);
 }
 
 size_t pm_get_error_workspace(int n) { return pm_icp_update_workspace(n); }
@@ -323,8 +330,8 @@ size_t pm_fit_affine_workspace(int n) {
     return n > 0 ? pm::align_up(pm_icp_accumulate_workspace(n), 256) + 256 + 256 : 0;  // partials | sums[22] | origin[6]
 }
 
-int pm_fit_affine(const double *mov, int n, const double *fix, int n_fix, const int32_t *nn, double *A_out16, void *ws,
-                  size_t ws_bytes, void *stream) {
+int pm_fit_affine(const double *mov, int n, const double *fix, int n_fix, const int32_t *nn, double *A_out16, int32_t *status1,
+                  void *ws, size_t ws_bytes, void *stream) {
     if (!mov || !fix || !A_out16 || n <= 0 || n_fix <= 0) return PM_ERR_INVALID_ARG;
     if (!nn && n_fix < n) return PM_ERR_INVALID_ARG;
     if (!ws || ws_bytes < pm_fit_affine_workspace(n)) return PM_ERR_WORKSPACE;
@@ -336,7 +343,7 @@ int pm_fit_affine(const double *mov, int n, const double *fix, int n_fix, const 
     pm::origin_kernel<<<1, 64, 0, s>>>(mov, n, fix, n_fix, origin);
     int rc = pm::accumulate(mov, n, fix, n_fix, nn, origin, sums, partial, s);
     if (rc != PM_OK) return rc;
-    pm::solve_kernel<<<1, 64, 0, s>>>(sums, origin, A_out16);
+    pm::solve_kernel<<<1, 64, 0, s>>>(sums, origin, A_out16, status1);
     return pm::launch_status();
 }
 

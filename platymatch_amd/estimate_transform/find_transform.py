@@ -15,19 +15,39 @@ def _pair(moving, fixed, drop_ones):
     return m[:3, :].contiguous(), f[:3, :].contiguous()
 
 
+def affine_pinv_host(moving, fixed):
+    """find_transform.py:11-17 on host arrays, the reference's own expression: [fixed; 1] . pinv([moving; 1]).
+    The device path solves centred normal equations, which equal this for full-rank input; for rank-deficient input
+    (fewer than four points, coplanar or repeated points) pinv returns the minimum-norm least-squares answer — whose last
+    row is not 0 0 0 1 — and only this expression reproduces it."""
+    moving, fixed = np.asarray(moving, dtype=np.float64), np.asarray(fixed, dtype=np.float64)
+    one = np.ones((1, moving.shape[1]))
+    return np.matmul(np.vstack((fixed[:3], one)), np.linalg.pinv(np.vstack((moving[:3], one))))
+
+
+def affine_pinv_host_batch(P, Y):
+    """The same for T small samples at once: P, Y [T, 3, k] -> [T, 4, 4] (np.linalg.pinv works on stacks)."""
+    P, Y = np.asarray(P, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+    one = np.ones((P.shape[0], 1, P.shape[2]))
+    return np.matmul(np.concatenate((Y, one), axis=1), np.linalg.pinv(np.concatenate((P, one), axis=1)))
+
+
 def get_affine_transform(moving, fixed, with_ones=False):
     """find_transform.py:4-17: least-squares 4 x 4 with [fixed;1] = A [moving;1].
 
-    The reference forms fixed . pinv(moving); for a full-rank cloud (>= 4 points, not coplanar)
-    that is the least-squares solution, computed here on the device from centred moments
-    (last row exactly 0 0 0 1, the reference's is 0 0 0 1 to ~1e-17).  Rank-deficient input,
-    where pinv returns a minimum-norm answer, is not supported and raises ValueError."""
+    The reference forms fixed . pinv(moving).  For a full-rank cloud (>= 4 points, not coplanar) that is the
+    least-squares solution, computed here on the device from centred moments (last row exactly 0 0 0 1, the reference's
+    is 0 0 0 1 to ~1e-17).  For rank-deficient input the kernel reports it (pm_fit_affine's status word) and the
+    reference's own expression runs on the host (affine_pinv_host): same minimum-norm answer as the reference."""
+    torch = nat.torch_mod()
     m, f = _pair(moving, fixed, with_ones)
-    if m.shape[1] < 4:
-        raise ValueError("get_affine_transform needs at least 4 point pairs on the device path")
-    A = K.fit_affine(m, f)
-    if not bool(nat.torch_mod().isfinite(A).all()):
-        raise ValueError("degenerate (coplanar or repeated) points: affine fit is rank deficient")
+    degenerate = m.shape[1] < 4
+    if not degenerate:
+        status = torch.zeros(1, dtype=torch.int32, device=m.device)
+        A = K.fit_affine(m, f, status=status)
+        degenerate = int(status.item()) != 0 or not bool(torch.isfinite(A).all())
+    if degenerate:
+        A = torch.as_tensor(affine_pinv_host(m.cpu().numpy(), f.cpu().numpy()), device=m.device)
     return nat.like_input(A, moving)
 
 

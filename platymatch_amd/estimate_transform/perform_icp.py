@@ -3,16 +3,35 @@ import numpy as np
 
 from .. import _kernels as K
 from .. import _native as nat
-from .find_transform import apply_affine_host, similar_transform_host
+from .find_transform import affine_pinv_host, apply_affine_host, similar_transform_host
 
 VERBOSE = True   # the reference prints one residual line per iteration (perform_icp.py:24)
+
+
+def _icp_with_host_fits(m, f, iters, want_nn):
+    """perform_icp.py:14-25 with get_affine_transform's pinv on the host: m (3 x N, GPU) is updated in place."""
+    torch = nat.torch_mod()
+    A_icp = torch.eye(4, dtype=torch.float64, device=m.device).reshape(16).contiguous()
+    fh = f.cpu().numpy()
+    grid = K.icp_grid(f) if iters else None
+    res_l, nn_l = [], []
+    for _ in range(iters):
+        nn = K.icp_nn(m, f, want_dist=False, grid=grid)[0]                       # :15-16
+        A_est = affine_pinv_host(m.cpu().numpy(), fh[:, nn.cpu().numpy()])      # :18
+        parts = K.icp_apply(nat.to_dev(A_est, dev=m.device).reshape(16), m, f, nn, A_icp, nn_trusted=True)   # :23-25
+        res_l.append(parts[0] / parts[1])
+        nn_l.append(nn)
+    res = torch.stack(res_l) if res_l else torch.empty(0, dtype=torch.float64, device=m.device)
+    return A_icp.reshape(4, 4), res, (torch.stack(nn_l) if (want_nn and nn_l) else None)
 
 
 def perform_icp(moving, fixed, icp_iterations=50, transform='Affine', log=None):
     """perform_icp.py:7-26 -> A_icp (4 x 4).
 
     'Affine': the whole loop (nearest neighbours, refit, apply, compose) is enqueued on the
-    device in one call with no host synchronisation until the result is read.
+    device in one call with no host synchronisation until the result is read; if the moving cloud turns out
+    (nearly) planar — where the reference's pinv gives a minimum-norm fit the normal equations cannot — the loop is
+    rerun with pinv fits on the host (_icp_with_host_fits).
     'Similar': the nearest-neighbour search of every iteration runs on the device; the fit, the application and the
     composition are the reference's own NumPy calls on the host (find_transform.similar_transform_host explains why
     this mode can only be reproduced that way).
@@ -26,7 +45,15 @@ def perform_icp(moving, fixed, icp_iterations=50, transform='Affine', log=None):
     iters = int(icp_iterations)
     want_nn = log is not None
     if transform == 'Affine':
-        A, res, nn_all = K.icp(m, f, iters, want_nn=want_nn)
+        start = m.clone()
+        status = torch.zeros(1, dtype=torch.int32, device=m.device)
+        A, res, nn_all = K.icp(m, f, iters, want_nn=want_nn, status=status)
+        if int(status.item()) != 0 or not bool(torch.isfinite(A).all()):
+            # a (nearly) planar moving cloud: the device's normal equations are singular where the reference's pinv
+            # (find_transform.py:17) returns the minimum-norm fit.  Rerun with the search and the application on the
+            # device and the reference's own expression for the 4 x 4 on the host, one small round trip per iteration.
+            m = start
+            A, res, nn_all = _icp_with_host_fits(m, f, iters, want_nn)
     elif transform == 'Similar':
         # host copies in the layout the caller gave (np.mean's summation order follows the memory layout)
         mh = moving.detach().cpu().numpy() if nat.is_torch(moving) else np.asarray(moving, dtype=np.float64)

@@ -13,6 +13,74 @@ from .find_transform import get_affine_transform, get_similar_transform  # noqa:
 
 HYPOTHESES = ("11", "12", "13", "14", "21", "22", "23", "24")   # widget order, _dock_widget.py:547-611
 
+# ---- descriptors that remember where they came from ---------------------------------------------------------------
+# The widget never asks for a cost matrix: it calls get_unary_distance(unary_11[i], unary_21[j]) inside eight Python
+# double loops (_dock_widget.py:547-602).  For that UNCHANGED code to be fast, the arrays get_unary returns for NumPy
+# input are ndarrays of a subclass whose row views unary[i] remember (descriptor set, frame, row).  The first
+# get_unary_distance between rows of two descriptor sets builds the whole N x M matrix (all eight at once for a
+# moving x fixed combination: one chi2_cost8 launch) and keeps it on the host; every later call is a table lookup.
+# Anything else — copies, slices, arithmetic results, foreign arrays, torch tensors — takes the per-pair launch as before.
+MATRIX_CACHE_BYTES = 4 << 30          # all matrices of a combination are built at once below this, one at a time above
+
+
+class _DescriptorSet:
+    """What one get_unary call produced: the device histograms [F, N, 360], their host copy, and the cost matrices
+    already built against other sets."""
+    __slots__ = ("hist", "host", "tables", "lock", "__weakref__")
+
+    def __init__(self, hist, host):
+        import threading
+        import weakref
+        self.hist, self.host = hist, host
+        self.tables = weakref.WeakKeyDictionary()        # other set -> {(frame_a, frame_b): N x M ndarray}  (or False: do not cache)
+        self.lock = threading.Lock()
+
+
+class UnaryArray(np.ndarray):
+    """(N, 360) float64 descriptors as get_unary returns them — an ordinary ndarray in every respect; `a[i]` with an
+    integer i additionally carries (set, frame, row) so that get_unary_distance can look the pair up."""
+
+    def __array_finalize__(self, obj):
+        self._pm_set = None          # never inherited: only __getitem__(int) and get_unary tag an array
+        self._pm_frame = -1
+        self._pm_row = -1
+
+    def __getitem__(self, idx):
+        out = super().__getitem__(idx)
+        if self._pm_set is not None and self._pm_row < 0 and self.ndim == 2 and isinstance(idx, (int, np.integer)):
+            out._pm_set, out._pm_frame = self._pm_set, self._pm_frame
+            out._pm_row = int(idx) + (self.shape[0] if idx < 0 else 0)
+        return out
+
+    def __reduce__(self):            # pickling / copying yields plain data
+        return np.asarray(self).__reduce__()
+
+
+def _cost_table(sa, sb, fa, fb):
+    """The N x M chi-square matrix between frame fa of descriptor set sa and frame fb of set sb, built on first use.
+    -> ndarray, or None if the sets may not be cached (their host arrays were modified after get_unary returned them)."""
+    with sa.lock:
+        tabs = sa.tables.get(sb)
+        if tabs is None:
+            # the host arrays are writable like the reference's: trust the device copy only if they still agree bit for bit
+            same = all(np.array_equal(x.host.view(np.uint64), x.hist.cpu().numpy().view(np.uint64)) for x in (sa, sb))
+            tabs = sa.tables[sb] = {} if same else False
+        if tabs is False:
+            return None
+        t = tabs.get((fa, fb))
+        if t is None:
+            na, nb = sa.hist.shape[1], sb.hist.shape[1]
+            if sa.hist.shape[0] == 2 and sb.hist.shape[0] == 4 and 64 * na * nb <= MATRIX_CACHE_BYTES:
+                U = K.chi2_cost8(sa.hist, sb.hist).cpu().numpy()                 # the widget's eight matrices in one launch
+                for h, name in enumerate(HYPOTHESES):
+                    tabs[(int(name[0]) - 1, int(name[1]) - 1)] = U[h]
+            else:
+                if 8 * na * nb * (len(tabs) + 1) > MATRIX_CACHE_BYTES:           # large clouds: the widget fills one matrix at a time
+                    tabs.clear()
+                tabs[(fa, fb)] = K.chi2_cost(sa.hist[fa], sb.hist[fb]).cpu().numpy()
+            t = tabs[(fa, fb)]
+        return t
+
 
 def get_Y(z, x):
     """shape_context.py:6-8: unit(z x x).  Three-vector helper; the per-point frames of get_unary are
@@ -66,8 +134,15 @@ def transform(detection, x_vector, y_vector, z_vector, neighbors):
 
 
 def get_unary_distance(sc1, sc2):
-    """shape_context.py:88-99 for one pair of descriptors (kept for the widget's per-pair loops;
-    use unary_distance_matrix / unary_distance_matrices for whole clouds)."""
+    """shape_context.py:88-99 for one pair of descriptors.  Rows of the arrays get_unary returned (the widget's
+    unary_11[i], unary_21[j]) are answered from the cost matrix of their two descriptor sets, built on the device at
+    the first call (see UnaryArray); any other input is one launch per pair.  Whole clouds: unary_distance_matrix /
+    unary_distance_matrices."""
+    sa, sb = getattr(sc1, "_pm_set", None), getattr(sc2, "_pm_set", None)
+    if sa is not None and sb is not None and sc1._pm_row >= 0 and sc2._pm_row >= 0:
+        t = _cost_table(sa, sb, sc1._pm_frame, sc2._pm_frame)
+        if t is not None:
+            return t[sc1._pm_row, sc2._pm_row]          # np.float64, as the reference's 0.5 * dist
     a, b = nat.to_dev(sc1).reshape(1, -1), nat.to_dev(sc2).reshape(1, -1)
     d = K.chi2_cost(a.contiguous(), b.contiguous())
     return d[0, 0] if nat.is_torch(sc1) else float(d.item())
@@ -122,7 +197,9 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
     """shape_context.py:103-139 -> (A_best 4 x 4, inliers_best).
 
     The host draws the index sets (same RNG calls as the reference); one kernel launch fits and
-    scores every trial.  The first trial with strictly more inliers than all before it wins;
+    scores every trial (any min_samples >= 4; samples that are rank deficient — and every sample when
+    min_samples < 4 — get the reference's pinv fit on the host and are scored on the device).
+    The first trial with strictly more inliers than all before it wins;
     with no inliers at all A_best stays np.ones((4, 4)), as in the reference (:119-120, 136-138).
     `rows`/`cols` (optional) select matched pairs without gathering on the host:
     pairs are (moving_all[:, rows[k]], fixed_all[:, cols[k]]).  `samples` (optional, [trials, min_samples] int32):
@@ -151,10 +228,47 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
         if samples.shape != (trials, int(min_samples)):
             raise ValueError("samples must be [trials, min_samples]")
     if transform == 'Affine':
-        if int(min_samples) != 4:
-            raise ValueError("the device path fits the affine through exactly 4 pairs (the widget's default, "
-                             "_dock_widget.py:327); got min_samples=%d" % min_samples)
-        A, inl = K.ransac_affine(m, f, rows, cols, nat.to_dev(samples, dtype=torch.int32, dev=m.device), float(error))
+        from .find_transform import affine_pinv_host, affine_pinv_host_batch
+        k = int(min_samples)
+        hosts = {}
+
+        def host_pairs():                 # matched clouds on the host, fetched only if some trial needs a pinv fit
+            if not hosts:
+                mh, fh = m.cpu().numpy(), f.cpu().numpy()
+                if rows is not None:
+                    mh, fh = mh[:, rows.cpu().numpy()], fh[:, cols.cpu().numpy()]
+                hosts["m"], hosts["f"] = mh, fh
+            return hosts["m"], hosts["f"]
+
+        if k >= 4:
+            A, inl, deg = K.ransac_affine(m, f, rows, cols, nat.to_dev(samples, dtype=torch.int32, dev=m.device), float(error))
+            redo = np.flatnonzero(deg.cpu().numpy())
+        else:                             # fewer than four pairs: rank deficient by construction, every fit is pinv's
+            A = torch.empty((trials, 4, 4), dtype=torch.float64, device=m.device)
+            inl = torch.zeros(trials, dtype=torch.int32, device=m.device)
+            redo = np.arange(trials)
+        if redo.size:
+            # (nearly) coplanar / repeated sample points: the reference's pinv answer (find_transform.py:17), fitted on the
+            # host for just those trials and scored on the device like the others
+            mh, fh = host_pairs()
+            sel = samples[redo]
+            A_h = affine_pinv_host_batch(np.moveaxis(mh[:, sel], 0, 1), np.moveaxis(fh[:, sel], 0, 1))
+            A_d = nat.to_dev(A_h, dev=m.device)
+            idx = torch.as_tensor(redo, device=m.device)
+            A[idx] = A_d
+            inl[idx] = K.ransac_score(m, f, rows, cols, A_d, float(error))
+        inl_h = inl.cpu().numpy()
+        best = int(np.argmax(inl_h))          # first maximum == first strictly-better trial
+        if inl_h[best] <= 0:
+            return (torch.as_tensor(ones, device=m.device) if nat.is_torch(moving_all) else ones), 0
+        if redo.size and best in set(redo.tolist()):
+            # the winner came from the host: refit it by the literal per-sample expression (the batched call may differ in
+            # the last bits)
+            mh, fh = host_pairs()
+            A_best = torch.as_tensor(affine_pinv_host(mh[:, samples[best]], fh[:, samples[best]]), device=m.device)
+        else:
+            A_best = A[best]
+        return (A_best if nat.is_torch(moving_all) else A_best.cpu().numpy()), int(inl_h[best])
     elif transform == 'Similar':
         mh, fh = m.cpu().numpy(), f.cpu().numpy()
         if rows is not None:
@@ -174,12 +288,6 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
         return (torch.as_tensor(A_best, device=m.device) if nat.is_torch(moving_all) else A_best), int(inl_h[best])
     else:
         raise ValueError("transform must be 'Affine' or 'Similar'")
-    inl_h = inl.cpu().numpy()
-    best = int(np.argmax(inl_h))          # first maximum == first strictly-better trial
-    if inl_h[best] <= 0:
-        return (torch.as_tensor(ones, device=m.device) if nat.is_torch(moving_all) else ones), 0
-    A_best = A[best]
-    return (A_best if nat.is_torch(moving_all) else A_best.cpu().numpy()), int(inl_h[best])
 
 
 def get_unary(centroid, mean_distance, detections, type, transposed=False, x0=None):
@@ -203,7 +311,16 @@ def get_unary(centroid, mean_distance, detections, type, transposed=False, x0=No
     axis = K.pca_axis(xyz) if x0 is None else nat.to_dev(x0, dev=xyz.device).reshape(3).contiguous()
     nf = 4 if type == 'fixed' else 2
     hist = K.shape_context(xyz, c, axis, md, nf)["hist"]
-    outs = [nat.like_input(hist[k], detections) for k in range(nf)]
+    if nat.is_torch(detections):
+        outs = [hist[k] for k in range(nf)]
+    else:
+        host = hist.cpu().numpy()
+        dset = _DescriptorSet(hist, host)
+        outs = []
+        for k in range(nf):
+            a = host[k].view(UnaryArray)
+            a._pm_set, a._pm_frame = dset, k
+            outs.append(a)
     if nf == 2:
         empty = torch.empty(0, dtype=torch.float64, device=xyz.device) if nat.is_torch(detections) else np.array([])
         outs += [empty, empty]

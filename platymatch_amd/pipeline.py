@@ -88,18 +88,19 @@ class GpuBackend:
         from .estimate_transform.perform_icp import perform_icp
         return perform_icp(mov, fix, iters, transform, log=log)
 
-    def icp_nn(self, mov, fix):
-        # the fixed cloud is constant across the iterations of one ICP run: bin it once per (tensor, stream of calls)
-        key = (fix.data_ptr(), fix.shape[1])
-        if getattr(self, "_grid_key", None) != key:
-            self._grid, self._grid_key = self.K.icp_grid(fix), key
-        return self.K.icp_nn(mov, fix, want_dist=False, grid=self._grid)[0]
+    def icp_grid(self, fix):
+        """Bin the fixed cloud once per ICP run; the run owns the grid and hands it to icp_nn (no hidden backend state:
+        a backend may be shared between threads and the allocator reuses addresses)."""
+        return self.K.icp_grid(fix)
+
+    def icp_nn(self, mov, fix, grid=None):
+        return self.K.icp_nn(mov, fix, want_dist=False, grid=grid)[0]
 
     def icp_accumulate(self, mov, fix, nn, origin, out=None):
         return self.K.icp_accumulate(mov, fix, nn, origin, out=out, nn_trusted=True)     # nn is icp_nn's own output
 
-    def icp_update(self, sums, origin, mov, fix, nn, A_icp, parts_out=None):
-        return self.K.icp_update(sums, origin, mov, fix, nn, A_icp, parts_out=parts_out, nn_trusted=True)
+    def icp_update(self, sums, origin, mov, fix, nn, A_icp, parts_out=None, status=None):
+        return self.K.icp_update(sums, origin, mov, fix, nn, A_icp, parts_out=parts_out, nn_trusted=True, status=status)
 
 
 def shard_bounds(n, world):
@@ -309,8 +310,7 @@ def icp_sharded(be, moved, fix, iters, group=None):
     dist = _dist() if world > 1 else None
     bn = shard_bounds(moved.shape[1], world)
     loc = moved[:, bn[rank]:bn[rank + 1]].contiguous().clone()
-    if hasattr(be, "_grid_key"):
-        be._grid_key = None            # a new run may reuse the address of an old fixed cloud: never trust a stale grid
+    grid = be.icp_grid(fix) if (iters and hasattr(be, "icp_grid")) else None     # owned by this run
     A_icp = torch.eye(4, dtype=torch.float64, device=moved.device).reshape(16).contiguous()
     origin = torch.cat([fix[:, 0], fix[:, 0]]).contiguous()
     # One collective per iteration: the 24 moment sums of this iteration travel together with the residual
@@ -320,10 +320,11 @@ def icp_sharded(be, moved, fix, iters, group=None):
     sums_view, rp_view = mine[:24], mine[24:]
     gathered = [torch.empty_like(mine) for _ in range(world)] if world > 1 else None
     res_buf = torch.zeros((max(iters, 1), 2), dtype=torch.float64, device=moved.device)
+    status = torch.zeros(1, dtype=torch.int32, device=moved.device) if moved.is_cuda else None
     for it in range(iters + (1 if world > 1 and iters else 0)):
         last = it == iters
         if not last:
-            nn = be.icp_nn(loc, fix)
+            nn = be.icp_nn(loc, fix, grid) if grid is not None else be.icp_nn(loc, fix)
             be.icp_accumulate(loc, fix, nn, origin, out=sums_view)
         if world > 1:
             dist.all_gather(gathered, mine, group=group)
@@ -334,9 +335,12 @@ def icp_sharded(be, moved, fix, iters, group=None):
         else:
             sums = sums_view
         if not last:
-            be.icp_update(sums, origin, loc, fix, nn, A_icp, parts_out=rp_view)
+            be.icp_update(sums, origin, loc, fix, nn, A_icp, parts_out=rp_view, status=status)
             if world == 1:
                 res_buf[it].copy_(rp_view)
+    if status is not None and int(status.item()) != 0:       # identical sums on every rank: all ranks raise together
+        raise ValueError("sharded ICP met a (nearly) planar moving cloud: the reference's pinv fit is needed there; run the "
+                         "refinement unsharded (icp_shard_min_points above the cloud size)")
     residuals = list((res_buf[:iters, 0] / res_buf[:iters, 1]).unbind(0)) if iters else []
     res = torch.stack(residuals) if residuals else torch.empty(0, dtype=torch.float64, device=moved.device)
     return A_icp.reshape(4, 4), res
@@ -365,9 +369,17 @@ class _SampleDraws:
 
     def __init__(self, be, n_pairs, min_samples, trials, seed, private=False):
         import threading
-        self.sets, self.error = None, None
+        self.sets, self.error, self.seconds = None, None, 0.0
 
         def work():
+            import time
+            t0 = time.perf_counter()
+            try:
+                _work()
+            finally:
+                self.seconds = time.perf_counter() - t0
+
+        def _work():
             try:
                 if trials <= 0:
                     self.sets = [None] * 8
@@ -410,19 +422,35 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     icp_shard_min_points  moving-cloud size from which ICP is sharded too (below it every rank runs it whole)
     details         optional dict filled with intermediate results (lsa, ransac_A, residuals)
     """
+    import time
     import torch
     be = backend or GpuBackend()
     mov, fix = be.cloud(moving), be.cloud(fixed)
     inliers = np.zeros(8, dtype=np.int64)
     rank, world = _world(group)
+    timing = {} if (details is not None and details.get("timing")) else None     # details={"timing": True}: wall-clock split
+
+    def mark(name, t0):
+        if timing is not None:
+            if mov.is_cuda:
+                torch.cuda.current_stream(mov.device).synchronize()
+            timing[name] = timing.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
+    t0 = time.perf_counter()
     if mode == 'unsupervised':
         U, bn = build_costs(be, mov, fix, group)
+        t0 = mark("gpu_descriptors_costs", t0)
         draws = _SampleDraws(be, min(mov.shape[1], fix.shape[1]), int(ransac_samples), int(ransac_trials), seed, private_rng)
         try:
             lsa = assign(U, bn, group)
         finally:
             del U
+            t0 = mark("host_assignment", t0)
             sets = draws.result()                    # every rank draws the same 8 x trials: same RNG stream everywhere
+            t0 = mark("host_draws_exposed", t0)
+            if timing is not None:
+                timing["host_draws_thread"] = draws.seconds
         A_h = []
         for h, (r, c) in enumerate(lsa):
             A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
@@ -430,6 +458,7 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             A_h.append(nat.to_dev(A, dev=mov.device))
             inliers[h] = k
         A_sc = A_h[int(np.argmax(inliers))]          # first maximum (_dock_widget.py:683-703)
+        t0 = mark("gpu_ransac", t0)
         if details is not None:
             details.update(lsa=lsa, ransac_A=torch.stack(A_h).cpu().numpy())
     elif mode == 'supervised':
@@ -454,6 +483,9 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         A_icp = be.icp(moved, fix, int(icp_iterations), transform, log)             # :715-717
         if details is not None:
             details.update(residuals=log['residuals'], nn=log['nn'])
+    t0 = mark("gpu_icp", t0)
+    if timing is not None:
+        details["timing"] = timing
     if nat.is_torch(moving):
         return A_sc, nat.to_dev(A_icp, dev=mov.device), inliers
     return A_sc.cpu().numpy(), (A_icp.cpu().numpy() if nat.is_torch(A_icp) else np.asarray(A_icp)), inliers
@@ -483,7 +515,7 @@ def _pair_size(pair):
     return tuple(int(x.shape[1]) for x in pair[:2])
 
 
-def _run_local(pairs, ks, workers, seeds, kwargs):
+def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
     """This process's share of a batch: pairs ks on `workers` host threads, one HIP stream each."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
@@ -494,12 +526,16 @@ def _run_local(pairs, ks, workers, seeds, kwargs):
         nat.load()
 
     def one(k):
+        det = {"timing": True} if timings is not None else None
         if not on_gpu:                       # a caller-supplied host backend (tests): no stream to set
-            return estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, **kwargs)
-        stream = torch.cuda.Stream(device=dev)
-        with torch.cuda.device(dev), torch.cuda.stream(stream):
-            out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, **kwargs)
-            stream.synchronize()
+            out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, details=det, **kwargs)
+        else:
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, details=det, **kwargs)
+                stream.synchronize()
+        if timings is not None:
+            timings[k] = det["timing"]
         return out
 
     # largest first: the long Hungarian solves start early and the short pairs fill the gaps at the end
@@ -511,7 +547,7 @@ def _run_local(pairs, ks, workers, seeds, kwargs):
         return dict(zip(order, ex.map(one, order)))
 
 
-def estimate_transform_batch(pairs, workers=4, seeds=None, group=None, **kwargs):
+def estimate_transform_batch(pairs, workers=4, seeds=None, group=None, timings=None, **kwargs):
     """Several independent registrations (BASELINE config 5: "replicas only" — pairs never exchange data).
 
     One GPU (group=None): each worker thread drives its pairs on its own HIP stream, so the GPU stages of different pairs
@@ -523,7 +559,8 @@ def estimate_transform_batch(pairs, workers=4, seeds=None, group=None, **kwargs)
 
     Seeded pairs draw their RANSAC index sets from a private RandomState(seed) (the sets np.random.seed(seed) would
     give); unseeded pairs draw from NumPy's global generator one after the other.
-    pairs: iterable of (moving, fixed); seeds: optional per-pair RANSAC seeds.
+    pairs: iterable of (moving, fixed); seeds: optional per-pair RANSAC seeds; timings: optional dict, filled with
+    {pair index: wall-clock split of its stages} for the pairs this process registered (adds stream synchronisations).
     -> list of (A_sc, A_icp, inliers) in input order, each identical to a stand-alone estimate_transform call."""
     import torch
     pairs = list(pairs)
@@ -534,14 +571,14 @@ def estimate_transform_batch(pairs, workers=4, seeds=None, group=None, **kwargs)
         raise ValueError("details is per registration: call estimate_transform for the pair of interest")
     rank, world = _world(group)
     if world == 1:
-        res = _run_local(pairs, list(range(len(pairs))), workers, seeds, kwargs)
+        res = _run_local(pairs, list(range(len(pairs))), workers, seeds, kwargs, timings)
         return [res[k] for k in range(len(pairs))]
     dist = _dist()
     owner = batch_assignment([_pair_size(p) for p in pairs], world)
     mine = [k for k in range(len(pairs)) if owner[k] == rank]
     failure = None
     try:
-        res = _run_local(pairs, mine, workers, seeds, kwargs)
+        res = _run_local(pairs, mine, workers, seeds, kwargs, timings)
     except Exception as e:                     # keep the collective below matched on every rank, then raise everywhere
         failure, res = e, {}
     be = kwargs.get("backend")

@@ -397,7 +397,93 @@ def similar_mode(ref):
     return out
 
 
-ALL = ["next_rows", "micro", "similar_mode", "synth128", "synth96x128", "insitu02_identity", "insitu02_affine", "insitu04_affine"]
+def ransac_k(ref):
+    """do_ransac with min_samples != 4 (the widget exposes the field, _dock_widget.py:327), get_affine_transform on
+    rank-deficient input (pinv's minimum-norm answer, find_transform.py:17), a planar cloud through RANSAC and ICP, and
+    shape_context.transform() on its own (shape_context.py:61-84)."""
+    sc_mod, ft, at, icp_mod, utils = ref
+    import contextlib
+    import io
+    rng = np.random.default_rng(33)
+    n = 160
+    mv = rng.normal(size=(3, n)) * np.array([[60.0], [40.0], [25.0]]) + 200.0
+    fx = at.apply_affine_transform(mv, A_GT) + rng.normal(scale=0.8, size=(3, n))
+    out = {"moving": mv, "fixed": fx}
+    for k in (1, 2, 3, 5, 8, 13):
+        np.random.seed(200 + k)
+        sets = np.stack([np.random.choice(n, k, replace=False) for _ in range(80)])
+        out["samples_k%d" % k] = sets.astype(np.int32)
+        out["fits_k%d" % k] = np.stack([ft.get_affine_transform(mv[:, s], fx[:, s]) for s in sets])
+    for k, trials, err in ((3, 300, 6.0), (5, 300, 3.0), (8, 200, 3.0)):
+        np.random.seed(9)
+        A, inl = sc_mod.do_ransac(mv, fx, min_samples=k, trials=trials, error=err, transform='Affine')
+        out["ransac_A_k%d" % k], out["ransac_inliers_k%d" % k] = np.asarray(A, dtype=np.float64), np.int64(inl)
+        out["ransac_args_k%d" % k] = np.array([k, trials, err, 9], dtype=np.float64)
+    # planar moving cloud (one coordinate constant: 2-D data embedded in 3-D), non-planar and planar targets
+    pl = mv.copy()
+    pl[0, :] = 37.5
+    T = A_GT.copy()
+    T[3] = [0, 0, 0, 1]
+    pf = at.apply_affine_transform(pl, T) + rng.normal(scale=0.5, size=(3, n))
+    out["planar_moving"], out["planar_fixed"] = pl, pf
+    out["planar_fit"] = ft.get_affine_transform(pl, pf)
+    out["planar_fit_4"] = ft.get_affine_transform(pl[:, :4], pf[:, :4])
+    out["planar_fit_3"] = ft.get_affine_transform(pl[:, :3], pf[:, :3])
+    np.random.seed(4)
+    A, inl = sc_mod.do_ransac(pl, pf, min_samples=4, trials=200, error=3.0, transform='Affine')
+    out["planar_ransac_A"], out["planar_ransac_inliers"] = np.asarray(A, dtype=np.float64), np.int64(inl)
+    start = at.apply_affine_transform(pl, A)
+    nn_log = []
+    real_dm = icp_mod.distance_matrix
+
+    def dm_spy(a, b):
+        d = real_dm(a, b)
+        nn_log.append(np.argmin(d, 1).astype(np.int32))
+        return d
+
+    icp_mod.distance_matrix = dm_spy
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            out["planar_icp_A"] = icp_mod.perform_icp(start, pf.copy(), 6, 'Affine')
+    finally:
+        icp_mod.distance_matrix = real_dm
+    out["planar_icp_start"] = start
+    out["planar_icp_nn"] = np.stack(nn_log)
+    # half of the points on a plane: many 4-samples are coplanar
+    hp = mv.copy()
+    hp[2, : n // 2] = 150.0
+    hf = at.apply_affine_transform(hp, T) + rng.normal(scale=0.5, size=(3, n))
+    out["halfplane_moving"], out["halfplane_fixed"] = hp, hf
+    np.random.seed(12)
+    sets = np.stack([np.random.choice(n // 2, 4, replace=False) for _ in range(40)])          # all coplanar
+    out["halfplane_samples"] = sets.astype(np.int32)
+    out["halfplane_fits"] = np.stack([ft.get_affine_transform(hp[:, s], hf[:, s]) for s in sets])
+    np.random.seed(13)
+    A, inl = sc_mod.do_ransac(hp, hf, min_samples=4, trials=300, error=3.0, transform='Affine')
+    out["halfplane_ransac_A"], out["halfplane_ransac_inliers"] = np.asarray(A, dtype=np.float64), np.int64(inl)
+    # repeated points in a sample cannot happen (replace=False) but repeated COORDINATES can: duplicate nuclei
+    dup = mv[:, :12].copy()
+    dup[:, 1] = dup[:, 0]
+    dupf = fx[:, :12].copy()
+    out["dup_moving"], out["dup_fixed"] = dup, dupf
+    out["dup_fit_4"] = ft.get_affine_transform(dup[:, :4], dupf[:, :4])
+    # transform() by itself: the frame of one point as get_unary builds it (shape_context.py:169-177)
+    det = mv[:, 5]
+    c = utils.get_centroid(mv, transposed=False)[:, 0]
+    z = (det - c) / np.linalg.norm(det - c)
+    x0 = np.array([0.3, -0.5, 0.81])
+    x = x0 - z * np.dot(x0, z)
+    x = x / np.linalg.norm(x)
+    y = sc_mod.get_Y(z, x)
+    nb = np.delete(mv.T, 5, 0)
+    out["tf_detection"], out["tf_x"], out["tf_y"], out["tf_z"], out["tf_neighbors"] = det, x, y, z, nb
+    out["tf_out"] = sc_mod.transform(det[None, :], x[None, :], y[None, :], z[None, :], nb)
+    out["tf_out_1d"] = sc_mod.transform(det, x, y, z, nb)
+    out["get_Y"] = y
+    return out
+
+
+ALL = ["next_rows", "micro", "similar_mode", "ransac_k", "synth128", "synth96x128", "insitu02_identity", "insitu02_affine", "insitu04_affine"]
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or ALL
@@ -413,6 +499,8 @@ if __name__ == "__main__":
             res = next_rows(ref)
         elif name == "similar_mode":
             res = similar_mode(ref)
+        elif name == "ransac_k":
+            res = ransac_k(ref)
         else:
             res, a_gt = scenario(ref, name)
             res["A_gt"] = a_gt

@@ -34,7 +34,7 @@ def test_python_binding_covers_the_header(lib_path):
     from platymatch_amd import _native
     assert sorted(_native.SIGNATURES) == declared_symbols()
     lib = _native.load()
-    assert lib.pm_version() == 1
+    assert lib.pm_version() == 2
     assert b"workspace" in lib.pm_error_string(-2)
 
 
@@ -48,7 +48,7 @@ def test_workspace_queries_and_argument_errors(lib_path):
     assert lib.pm_centroid(None, 10, None, None, 0, None) == -1
     assert lib.pm_chi2_cost(None, 1, None, 1, None, 1, None) == -1
     assert lib.pm_shape_context(None, 0, 0, 0, None, None, None, 3, None, None, None, None) == -1
-    assert lib.pm_icp(None, 5, None, 5, 1, None, None, None, None, 0, None) == -1
+    assert lib.pm_icp(None, 5, None, 5, 1, None, None, None, None, None, 0, None) == -1
 
 
 def test_every_entry_point_rejects_bad_arguments_before_touching_the_device(lib_path):
@@ -69,10 +69,11 @@ def test_every_entry_point_rejects_bad_arguments_before_touching_the_device(lib_
     fake = ctypes.c_void_p(0x1000)               # never dereferenced: the workspace check comes first
     assert lib.pm_mean_distance(fake, 100, fake, None, 0, None) == -2
     assert lib.pm_mean_distance_rows(fake, 100, 0, 1, fake, 0, None) == -2
-    assert lib.pm_icp(fake, 10, fake, 10, 3, fake, None, None, None, 0, None) == -2
+    assert lib.pm_icp(fake, 10, fake, 10, 3, fake, None, None, None, None, 0, None) == -2
     assert lib.pm_icp_nn(fake, 10, fake, 10, fake, None, None, 0, None) == -2
     assert lib.pm_icp_accumulate(fake, 10, fake, 10, None, fake, fake, None, 0, None) == -2
-    assert lib.pm_fit_affine(fake, 10, fake, 10, None, fake, None, 0, None) == -2
+    assert lib.pm_fit_affine(fake, 10, fake, 10, None, fake, None, None, 0, None) == -2
+    assert lib.pm_ransac_affine(fake, 10, fake, 10, None, None, 10, fake, 3, 5, 1.0, fake, fake, None, None) == -4      # < 4 pairs: host pinv
     assert lib.pm_get_error(fake, fake, 10, fake, None, 0, None) == -2
     assert lib.pm_shape_context(fake, 10, 8, 5, fake, fake, fake, 4, fake, None, None, None) == -1     # row block outside the cloud
     assert lib.pm_shape_context(fake, 10, 0, 5, fake, fake, fake, 3, fake, None, None, None) == -1     # 3 frames do not exist

@@ -1,6 +1,8 @@
-"""BASELINE-size checks (N = M = 50 000) through properties that need no CPU reference: the oracle cannot follow at this
-size, so the HIP path is checked against itself along independent routes (general vs half-cost chi-square kernel,
-grid vs brute-force correspondence search, fused ICP loop vs step-by-step loop) and against invariants of the data."""
+"""BASELINE-size checks (N = M = 50 000).  Where one CPU core can follow in seconds the oracle is the checker at full size:
+the nearest-neighbour step of the first ICP iterations (all 50 000 x 50 000 pairs, ~4 s per pass: perform_icp.py:15-16) and
+complete rows of all eight cost matrices for sampled moving points (shape_context.py:88-99).  Everything else at this size is
+checked along independent routes of the HIP path (general vs half-cost chi-square kernel, grid vs brute-force correspondence
+search, fused ICP loop vs step-by-step loop) and against invariants of the data."""
 import numpy as np
 import pytest
 
@@ -91,6 +93,52 @@ def test_fused_icp_loop_equals_stepwise_loop(big):
         assert float(parts[0] / parts[1]) == float(res[it])
     assert t.equal(A.reshape(16), A2) and t.equal(work, loc)
     assert float(res[-1]) < float(res[0])
+
+
+def test_config3_icp_correspondences_equal_oracle_at_50k(big, oracle):
+    """BASELINE config 3 pinned to the CPU oracle at its full size: for the first three iterations of the 50k ICP, the
+    nearest fixed point of EVERY moving point (and its distance) equals the oracle's scan of all 2.5e9 pairs
+    (perform_icp.py:15-16: distance_matrix + argmin, first index on ties) — indices and float64 distances exactly."""
+    K, t = big["K"], big["t"]
+    iters = 3
+    work = big["start"].clone()
+    A, res, nn_all = K.icp(work, big["fix"], iters, want_nn=True)          # the fused loop, as perform_icp runs it
+    fix_h = big["fix"].cpu().numpy()
+    loc = big["start"].clone()
+    A2 = t.eye(4, dtype=t.float64, device=loc.device).reshape(16).contiguous()
+    origin = t.cat([big["fix"][:, 0], big["fix"][:, 0]]).contiguous()
+    for it in range(iters):
+        o_nn, o_d = oracle.nn_argmin(loc.cpu().numpy(), fix_h)
+        g_nn, g_d = K.icp_nn(loc, big["fix"])
+        assert np.array_equal(nn_all[it].cpu().numpy(), o_nn), it
+        assert np.array_equal(g_nn.cpu().numpy(), o_nn) and np.array_equal(g_d.cpu().numpy(), o_d), it
+        sums = K.icp_accumulate(loc, big["fix"], g_nn, origin, nn_trusted=True)
+        K.icp_update(sums, origin, loc, big["fix"], g_nn, A2, nn_trusted=True)
+    assert t.equal(work, loc)
+    # the residual the reference prints (utils.py:77-88) after the last update, from the oracle's own norm
+    moved = loc.cpu().numpy()
+    want = oracle.get_error(moved, fix_h[:, nn_all[iters - 1].cpu().numpy()])
+    assert abs(float(res[-1]) - want) <= 1e-12 * want
+
+
+def test_config3_sampled_cost_rows_equal_oracle_at_50k(big, oracle):
+    """Four sampled moving rows x all eight matrices x all 50 000 columns of the 50k build against oracle.unary_distance_matrix
+    (float64 bit patterns), with the descriptors of the sampled rows checked as integer histograms first."""
+    K, t = big["K"], big["t"]
+    rows = np.array([0, 12345, 31999, N - 1])
+    hm_all = K.shape_context(big["mov"], *big["mov_stats"], 2, want_counts=True)
+    hf = K.shape_context(big["fix"], *big["fix_stats"], 4)["hist"]
+    sel = t.as_tensor(rows, device=hf.device)
+    hm = hm_all["hist"][:, sel].contiguous()
+    cm, x0m, mdm = (x.cpu().numpy() for x in big["mov_stats"])
+    cnt, tot = oracle.shape_context_counts_rows(cm, float(mdm[0]), big["mov"].cpu().numpy(), "moving", rows, x0m)
+    assert np.array_equal(cnt, hm_all["counts"][:, sel].cpu().numpy()) and np.array_equal(tot, hm_all["totals"][:, sel].cpu().numpy())
+    assert np.array_equal(oracle.normalise_counts(cnt, tot), hm.cpu().numpy())
+    U = K.chi2_cost8(hm, hf)                                                  # [8, 4, 50000]
+    hf_h, hm_h = hf.cpu().numpy(), hm.cpu().numpy()
+    for h, name in enumerate(oracle.HYPOTHESES):
+        want = oracle.unary_distance_matrix(hm_h[int(name[0]) - 1], hf_h[int(name[1]) - 1])
+        assert np.array_equal(want.view(np.uint64), U[h].cpu().numpy().view(np.uint64)), name
 
 
 def test_config4_rank_slice_row_argmins_equal_cpu():

@@ -378,12 +378,11 @@ def test_fit_and_apply(gpu, oracle, micro):
     A_gt = load_golden("synth128")["A_gt"]
     assert relerr(apply_affine_transform(P, A_gt), micro["apply_affine"]) < 1e-15
     assert relerr(apply_similar_transform(P, 1.3, A_gt[:3, :3], A_gt[:3, 3:4]), micro["apply_similar"]) < 1e-15
-    with pytest.raises(ValueError):
-        get_affine_transform(P[:, :3], Q[:, :3])
+    # rank-deficient input: the reference's pinv minimum-norm answer (find_transform.py:17), not a refusal
+    assert relerr(get_affine_transform(P[:, :3], Q[:, :3]), oracle.get_affine_transform(P[:, :3], Q[:, :3])) < 1e-10
     flat = P.copy()
-    flat[2] = 1.0                                                           # coplanar: pinv territory, refused
-    with pytest.raises(ValueError):
-        get_affine_transform(flat, Q)
+    flat[2] = 1.0                                                           # coplanar cloud
+    assert relerr(get_affine_transform(flat, Q), oracle.get_affine_transform(flat, Q)) < 1e-10
 
 
 def test_utils_mirror(gpu, oracle, micro):
@@ -421,15 +420,16 @@ def test_ransac_scores_exact_vs_oracle(gpu, oracle):
     perm = rng.permutation(3000).astype(np.int32)
     rows, cols = perm[:2500], perm[::-1][:2500].copy()
     samples = np.stack([rng.choice(2500, 4, replace=False) for _ in range(700)]).astype(np.int32)
-    A, inl = gpu.K.ransac_affine(gpu.d(mv), gpu.d(fx), gpu.d(rows, gpu.t.int32), gpu.d(cols, gpu.t.int32),
-                                 gpu.d(samples, gpu.t.int32), 16.0)
+    A, inl, deg = gpu.K.ransac_affine(gpu.d(mv), gpu.d(fx), gpu.d(rows, gpu.t.int32), gpu.d(cols, gpu.t.int32),
+                                      gpu.d(samples, gpu.t.int32), 16.0)
+    assert int(deg.sum()) == 0                                              # generic samples: none flagged rank deficient
     A_h = A.cpu().numpy()
     ref = oracle.ransac_score(mv[:, rows], fx[:, cols], A_h, 16.0)        # same transforms, scoring restated on the CPU
     assert np.array_equal(inl.cpu().numpy(), ref)
     for t in range(0, 700, 37):                                             # the fit itself vs fixed . pinv(moving)
         s = samples[t]
         ref_A = oracle.get_affine_transform(mv[:, rows[s]], fx[:, cols[s]])
-        assert relerr(A_h[t], ref_A) < 1e-7
+        assert relerr(A_h[t], ref_A) < 1e-9
     inl2 = gpu.K.ransac_score(gpu.d(mv), gpu.d(fx), gpu.d(rows, gpu.t.int32), gpu.d(cols, gpu.t.int32), A, 16.0)
     assert gpu.t.equal(inl, inl2)
     with pytest.raises(IndexError):

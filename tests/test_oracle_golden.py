@@ -3,6 +3,8 @@ produced by running the reference itself (gen_golden.py).  CPU only."""
 import numpy as np
 from scipy.optimize import linear_sum_assignment
 
+from conftest import load_golden
+
 
 def test_micro_binning_known_answers(oracle, micro):
     # get_bin_index on 500 random neighbours and get_shape_context on the integer lattice (exact ring,
@@ -122,3 +124,27 @@ def test_similar_mode_matches_reference(oracle):
         assert np.array_equal(A, d["ransac_A_k%d" % k]) and inl == int(d["ransac_inliers_k%d" % k])
     A_icp = oracle.perform_icp(oracle.apply_affine_transform(mv, d["ransac_A_k4"]), fx, 12, "Similar")
     assert np.array_equal(A_icp, d["icp_A"])
+
+
+def test_oracle_reproduces_ransac_k_fixture(oracle):
+    """min_samples != 4, rank-deficient fits (pinv's minimum-norm answer), planar cloud through RANSAC and ICP:
+    the oracle against what the reference produced (tests/golden/ransac_k.npz), bit for bit."""
+    d = load_golden("ransac_k")
+    for k in (1, 2, 3, 5, 8, 13):
+        fits = np.stack([oracle.get_affine_transform(d["moving"][:, s], d["fixed"][:, s]) for s in d["samples_k%d" % k]])
+        assert np.array_equal(fits, d["fits_k%d" % k]), k
+    for k in (3, 5, 8):
+        kk, trials, err, seed = d["ransac_args_k%d" % k]
+        np.random.seed(int(seed))
+        A, inl = oracle.do_ransac(d["moving"], d["fixed"], min_samples=int(kk), trials=int(trials), error=float(err))
+        assert inl == int(d["ransac_inliers_k%d" % k]) and np.array_equal(A, d["ransac_A_k%d" % k])
+    assert np.array_equal(oracle.get_affine_transform(d["planar_moving"], d["planar_fixed"]), d["planar_fit"])
+    np.random.seed(4)
+    A, inl = oracle.do_ransac(d["planar_moving"], d["planar_fixed"], 4, 200, 3.0)
+    assert inl == int(d["planar_ransac_inliers"]) and np.array_equal(A, d["planar_ransac_A"])
+    log = {}
+    A = oracle.perform_icp(d["planar_icp_start"], d["planar_fixed"], 6, "Affine", log=log)
+    assert np.array_equal(A, d["planar_icp_A"]) and np.array_equal(log["nn"], d["planar_icp_nn"])
+    np.random.seed(13)
+    A, inl = oracle.do_ransac(d["halfplane_moving"], d["halfplane_fixed"], 4, 300, 3.0)
+    assert inl == int(d["halfplane_ransac_inliers"]) and np.array_equal(A, d["halfplane_ransac_A"])

@@ -128,7 +128,7 @@ class OracleBackend:
             return out
         return torch.as_tensor(s)
 
-    def icp_update(self, sums, origin, mov, fix, nn, A_icp, parts_out=None):
+    def icp_update(self, sums, origin, mov, fix, nn, A_icp, parts_out=None, status=None):
         s, o = sums.numpy(), origin.numpy()
         n = s[0]
         mb, fb = s[1:4] / n, s[4:7] / n

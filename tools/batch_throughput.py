@@ -1,8 +1,15 @@
 #!/usr/bin/env python3
-"""Aggregate registrations/s of a batch of independent pairs on ONE GPU (BASELINE config 5 is this, times 8 GPUs, at
-2k-20k points; "replicas only" -- no collective).  Each pair is a complete unsupervised registration: descriptors, eight
-cost matrices, eight Hungarian solves, 8 x 8000 RANSAC trials, 50 ICP iterations.
-Usage: python tools/batch_throughput.py [workers] [size size ...]"""
+"""Aggregate registrations/s of a batch of independent specimen pairs (BASELINE config 5: 64 pairs of mixed 2k-20k nuclei,
+"replicas only" -- pairs never exchange data).  Each pair is a complete unsupervised registration as the widget runs it
+(_dock_widget.py:526-718): statistics, descriptors, eight cost matrices, eight Hungarian solves, 8 x 8000 RANSAC trials,
+50 ICP iterations.
+
+One GPU:     python tools/batch_throughput.py [--pairs 64] [--workers 4] [--json profiles/r02_batch64.json]
+Several:     python -m torch.distributed.run --nproc-per-node G ... tools/batch_throughput.py ...   (pairs dealt to ranks
+             largest first, pipeline.estimate_transform_batch(group=...); one rank per GPU over RCCL)
+Sizes: rng.integers(2000, 20001) per pair, default_rng(5); --max-points caps them for a short run."""
+import argparse
+import json
 import os
 import sys
 import time
@@ -17,22 +24,79 @@ from conftest import synth_pair  # noqa: E402
 from platymatch_amd import pipeline as P  # noqa: E402
 from platymatch_amd.estimate_transform import perform_icp as pi  # noqa: E402
 
-pi.VERBOSE = False
-workers = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-sizes = [int(x) for x in sys.argv[2:]] or [2000, 3000, 2500, 4000, 2000, 5000, 3500, 3000]
-pairs, truth = [], []
-for k, n in enumerate(sizes):
-    mv, fx, A = synth_pair(n, 100 + k)
-    pairs.append((mv, fx))
-    truth.append(A)
-P.estimate_transform(pairs[0][0][:, :300], pairs[0][1][:, :300], ransac_trials=100, icp_iterations=2)      # warm-up
-for w in sorted({1, workers}):
-    torch.cuda.synchronize()
-    t = time.perf_counter()
-    out = P.estimate_transform_batch(pairs, workers=w, seeds=list(range(len(pairs))), ransac_trials=8000, ransac_error=16,
-                                     icp_iterations=50)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t
-    err = max(np.linalg.norm(o[1] @ o[0] - A) / np.linalg.norm(A) for o, A in zip(out, truth))
-    print("workers=%d: %d pairs (sizes %s) in %.2f s -> %.3f registrations/s; worst rel. error vs ground truth %.1e"
-          % (w, len(pairs), sizes, dt, len(pairs) / dt, err), flush=True)
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=64)
+    ap.add_argument("--workers", type=int, default=4)
+    ap.add_argument("--min-points", type=int, default=2000)
+    ap.add_argument("--max-points", type=int, default=20000)
+    ap.add_argument("--trials", type=int, default=8000)
+    ap.add_argument("--icp", type=int, default=50)
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--sequential-too", action="store_true", help="also time workers=1 (one GPU only)")
+    args = ap.parse_args()
+    pi.VERBOSE = False
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("PM_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        group = dist.group.WORLD
+    sizes = [int(x) for x in np.random.default_rng(5).integers(args.min_points, args.max_points + 1, size=args.pairs)]
+    pairs, truth = [], []
+    for k, n in enumerate(sizes):
+        mv, fx, A = synth_pair(n, 100 + k)
+        pairs.append((mv, fx))
+        truth.append(A)
+    P.estimate_transform(pairs[0][0][:, :300], pairs[0][1][:, :300], ransac_trials=100, icp_iterations=2)      # warm-up
+    runs = []
+    import threading
+    t_start = time.perf_counter()
+    stop = threading.Event()
+
+    def heartbeat():                 # a long batch must show signs of life (the GPU box kills silent commands)
+        while not stop.wait(60.0):
+            print("[rank %d] %.0f s elapsed" % (rank, time.perf_counter() - t_start), flush=True)
+
+    threading.Thread(target=heartbeat, daemon=True).start()
+    for w in ([1] if (args.sequential_too and world == 1) else []) + [args.workers]:
+        torch.cuda.synchronize()
+        timings = {}
+        t = time.perf_counter()
+        out = P.estimate_transform_batch(pairs, workers=w, seeds=list(range(len(pairs))), group=group, timings=timings,
+                                         ransac_trials=args.trials, ransac_error=16, icp_iterations=args.icp)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        err = max(np.linalg.norm(np.asarray(o[1]) @ np.asarray(o[0]) - A) / np.linalg.norm(A) for o, A in zip(out, truth))
+        split = {}
+        for tm in timings.values():
+            for name, v in tm.items():
+                split[name] = split.get(name, 0.0) + v
+        run = {"workers_per_gpu": w, "n_gpus": world, "pairs": len(pairs), "seconds": dt, "registrations_per_s": len(pairs) / dt,
+               "worst_rel_error_vs_ground_truth": err,
+               "stage_seconds_summed_over_this_ranks_pairs": split,
+               "per_pair": [{"pair": k, "n": sizes[k], **{a: round(b, 4) for a, b in timings[k].items()}} for k in sorted(timings)]}
+        runs.append(run)
+        if rank == 0:
+            print("gpus=%d workers=%d: %d pairs (%d..%d points) in %.2f s -> %.3f registrations/s; worst rel. error vs ground truth %.1e; "
+                  "stage seconds (this rank) %s" % (world, w, len(pairs), min(sizes), max(sizes), dt, len(pairs) / dt, err,
+                                                    {a: round(b, 2) for a, b in split.items()}), flush=True)
+    stop.set()
+    if rank == 0 and args.json:
+        with open(args.json, "w") as f:
+            json.dump({"workload": "BASELINE configs[4]: %d pairs, sizes default_rng(5).integers(%d, %d), complete unsupervised "
+                                   "registration each (8 x %d RANSAC trials, %d ICP iterations)"
+                                   % (args.pairs, args.min_points, args.max_points + 1, args.trials, args.icp),
+                       "sizes": sizes, "host_cores": os.cpu_count(), "runs": runs}, f, indent=1)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
