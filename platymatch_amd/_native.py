@@ -36,6 +36,16 @@ SIGNATURES = {
     "pm_label_moments": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "pm_legacy_choice": (_c_int, [_c_void_p, _c_void_p, ctypes.c_long, _c_int, ctypes.c_long, _c_void_p]),
     "pm_lsap_solve": (_c_int, [_c_void_p, ctypes.c_long, ctypes.c_long, _c_void_p, _c_void_p]),
+    "pm_lsap_row_select": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_lsap_certificate": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_void_p, _c_void_p, _c_double, _c_double,
+                                     _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p]),
+    "pm_lsap_core_create": (_c_void_p, [_c_int, _c_int]),
+    "pm_lsap_core_destroy": (None, [_c_void_p]),
+    "pm_lsap_core_add": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
+    "pm_lsap_core_solve": (_c_int, [_c_void_p]),
+    "pm_lsap_core_reprice": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_double, _c_void_p]),
+    "pm_lsap_core_get": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_lsap_unique": (_c_int, [_c_int, _c_int, _c_void_p, _c_void_p, _c_double, _c_double, _c_void_p, _c_int]),
     "pm_mean_distance_rows": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "pm_mean_distance_finish": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
     "pm_row_argmin": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_size_t, _c_size_t, _c_void_p, _c_void_p, _c_void_p]),

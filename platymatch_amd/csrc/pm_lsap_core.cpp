@@ -251,17 +251,12 @@ int pm_lsap_core_reprice(void *h, int k, const int32_t *cand_col, const double *
     return PM_OK;
 }
 
-int pm_lsap_core_get(void *h, double *u, double *v, int32_t *col4row, double *dummy_u_max, long *stats4) {
+int pm_lsap_core_get(void *h, double *u, double *v, int32_t *col4row, long *stats4) {
     Core *c = static_cast<Core *>(h);
     if (!c || !u || !v || !col4row) return PM_ERR_INVALID_ARG;
     std::memcpy(u, c->u.data(), sizeof(double) * c->nr);
     std::memcpy(v, c->v.data(), sizeof(double) * c->nc);
     std::memcpy(col4row, c->col4row.data(), sizeof(int32_t) * c->nr);
-    if (dummy_u_max) {
-        double m = -std::numeric_limits<double>::infinity();
-        for (int r = c->nr; r < c->nc; ++r) m = std::max(m, c->u[r]);
-        *dummy_u_max = m;
-    }
     if (stats4) { stats4[0] = c->edges; stats4[1] = c->steps; stats4[2] = c->augmentations; stats4[3] = c->dummy_scans; }
     return PM_OK;
 }
@@ -270,9 +265,9 @@ int pm_lsap_core_get(void *h, double *u, double *v, int32_t *col4row, double *du
 // cost is within eps of zero (pm_lsap_certificate).  An alternative optimum within eps per edge exists only if those edges
 // close an alternating cycle — or, for nr < nc, an alternating path that ends on a column no real row holds.  Digraph on
 // the real rows plus one node F for "the free columns / dummy rows": i -> owner(col) for a tight (i, col), i -> F if col is
-// free, F -> owner(col) if a dummy row is tight on col (v[col] >= v_free_level - eps).  Returns 1 if acyclic (unique), 0 if
-// a cycle exists, < 0 on error.
-int pm_lsap_unique(int nr, int nc, const int32_t *col4row, const double *v, double dummy_u_max, double eps, const int32_t *tight,
+// free, F -> owner(col) if a dummy row is tight on col (v[col] >= v_free_level - eps, v_free_level = the dual the free
+// columns carry).  Returns 1 if acyclic (unique), 0 if a cycle exists, < 0 on error.
+int pm_lsap_unique(int nr, int nc, const int32_t *col4row, const double *v, double v_free_level, double eps, const int32_t *tight,
                    int n_tight) {
     if (nr <= 0 || nc < nr || !col4row || !v || n_tight < 0 || (n_tight > 0 && !tight)) return PM_ERR_INVALID_ARG;
     try {
@@ -291,9 +286,9 @@ int pm_lsap_unique(int nr, int nc, const int32_t *col4row, const double *v, doub
             if (owner[j] == i) continue;
             link(i, owner[j] >= 0 ? owner[j] : F);
         }
-        if (nc > nr)                       // a dummy row (dual dummy_u_max, cost 0) is tight on column j if -u_d - v[j] <= eps
+        if (nc > nr)                       // a dummy row (dual -v_free_level, cost 0) is tight on column j if v_free_level - v[j] <= eps
             for (int j = 0; j < nc; ++j)
-                if (owner[j] >= 0 && -dummy_u_max - v[j] <= eps) link(F, owner[j]);
+                if (owner[j] >= 0 && v_free_level - v[j] <= eps) link(F, owner[j]);
         std::vector<int32_t> stack;
         for (int a = 0; a < nodes; ++a)
             if (indeg[a] == 0) stack.push_back(a);

@@ -47,3 +47,251 @@ def solve_many(cost_matrices, threads=None):
         return [one(m) for m in mats]
     with ThreadPoolExecutor(max_workers=threads) as ex:
         return list(ex.map(one, mats))
+
+
+# ---- the same solve with the matrix resident on the GPU ---------------------------------------------------------------
+# include/platymatch_hip.h ("assignment with the matrix resident on the device") explains the scheme; csrc/pm_lsap_core.cpp
+# is the sparse host solver, csrc/pm_lsap_dev.hip the two kernels that read the dense matrix.
+CORE_EDGES_PER_ROW = 48          # initial core: up to this many cheap entries per row
+PRICE_EDGES_PER_ROW = 8          # offenders a row may hand back per pricing round
+MAX_PRICING_ROUNDS = 200
+REL_DELTA = 1e-13                # dual feasibility / tightness tolerance, relative to the largest dual or core cost
+REL_EPS = 1e-7                   # uniqueness margin: must exceed 2 * n * delta (n <= 2.5e5 here) and SciPy's own rounding
+DEVICE_MIN_ROWS = 1024           # below this the dense host solver is quicker than the round trips of the device scheme
+# The eight matrices hold four distinct sets of terms: U11/U22, U12/U21, U13/U24, U14/U23 differ only in
+# summation order (<= 6e-16 per entry), so one solve serves both — the twin is CERTIFIED on its own entries, not assumed.
+TWINS = {5: 0, 4: 1, 7: 2, 6: 3}
+
+
+class _Core:
+    def __init__(self, nr, nc):
+        self.lib = nat.load()
+        self.h = self.lib.pm_lsap_core_create(nr, nc)
+        if not self.h:
+            raise MemoryError("pm_lsap_core_create failed")
+        self.nr, self.nc = nr, nc
+
+    def close(self):
+        if self.h:
+            self.lib.pm_lsap_core_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def add(self, cols, costs):
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        costs = np.ascontiguousarray(costs, dtype=np.float64)
+        nat.check(self.lib.pm_lsap_core_add(self.h, cols.shape[1], cols.ctypes.data, costs.ctypes.data))
+
+    def solve(self):
+        rc = self.lib.pm_lsap_core_solve(self.h)
+        if rc == -4:
+            raise ValueError("cost matrix is infeasible")
+        nat.check(rc)
+
+    def reprice(self, cols, costs, delta):
+        import ctypes
+        n = ctypes.c_int(0)
+        nat.check(self.lib.pm_lsap_core_reprice(self.h, cols.shape[1], cols.ctypes.data, costs.ctypes.data, float(delta), ctypes.byref(n)))
+        return n.value
+
+    def get(self):
+        import ctypes
+        u, v = np.empty(self.nr), np.empty(self.nc)
+        c4r = np.empty(self.nr, dtype=np.int32)
+        stats = (ctypes.c_long * 4)()
+        nat.check(self.lib.pm_lsap_core_get(self.h, u.ctypes.data, v.ctypes.data, c4r.ctypes.data, stats))
+        return u, v, c4r, list(stats)
+
+
+class DeviceMatrix:
+    """The dense matrix as the solver sees it: three queries, each one streaming pass of a HIP kernel over HBM.
+    (tests/test_lsap_core.py substitutes a NumPy double to exercise the host solver without a GPU.)"""
+
+    def __init__(self, U):
+        self.U = U
+        self.shape = tuple(U.shape)
+
+    def row_select(self, v, k):
+        """-> (cols [nr, k] int32, costs [nr, k] float64, nonfinite flag): pm_lsap_row_select."""
+        torch = nat.torch_mod()
+        U = self.U
+        nr, nc = U.shape
+        cols = torch.empty((nr, k), dtype=torch.int32, device=U.device)
+        costs = torch.empty((nr, k), dtype=torch.float64, device=U.device)
+        flag = torch.empty(1, dtype=torch.int32, device=U.device)
+        v_dev = None if v is None else nat.to_dev(v, dev=U.device)
+        nat.check(nat.load().pm_lsap_row_select(nat.ptr(U), nr, nc, U.stride(0), nat.ptr(v_dev), k, nat.ptr(cols), nat.ptr(costs),
+                                                nat.ptr(flag), nat.stream_ptr(U)))
+        return cols.cpu().numpy(), costs.cpu().numpy(), int(flag.item())
+
+    def diagonal(self, n):
+        torch = nat.torch_mod()
+        d = torch.arange(n, device=self.U.device)
+        return self.U[d, d].cpu().numpy()
+
+    def certificate(self, u, v, col4row, delta, eps, cap):
+        """-> (violations, loose matched entries, tight edges [t, 2] int32 or None if more than cap, (max slack, max violation))."""
+        torch = nat.torch_mod()
+        U = self.U
+        nr, nc = U.shape
+        u_d, v_d = nat.to_dev(u, dev=U.device), nat.to_dev(v, dev=U.device)
+        c_d = nat.to_dev(col4row, dtype=torch.int32, dev=U.device)
+        summary = torch.empty(4, dtype=torch.int32, device=U.device)
+        stats = torch.empty(2, dtype=torch.float64, device=U.device)
+        tight = torch.empty((cap, 2), dtype=torch.int32, device=U.device)
+        nat.check(nat.load().pm_lsap_certificate(nat.ptr(U), nr, nc, U.stride(0), nat.ptr(u_d), nat.ptr(v_d), nat.ptr(c_d), float(delta),
+                                                 float(eps), nat.ptr(summary), nat.ptr(stats), nat.ptr(tight), cap, nat.stream_ptr(U)))
+        viol, n_tight, loose, _ = summary.cpu().tolist()
+        st = stats.cpu().tolist()
+        return viol, loose, (tight[:n_tight].cpu().numpy() if n_tight <= cap else None), (st[0], st[1])
+
+
+def certify(M, u, v, col4row, info=None):
+    """Is (u, v, col4row) a certified UNIQUE optimum of the matrix M (nr <= nc)?  Dual feasibility and complementary
+    slackness on every entry (pm_lsap_certificate), the free columns carrying the largest column dual (nr < nc), and no
+    alternating cycle among the entries within eps of tight (pm_lsap_unique)."""
+    lib = nat.load()
+    nr, nc = M.shape
+    scale = max(float(np.abs(u).max()), float(np.abs(v).max()), 1e-300)
+    delta, eps = REL_DELTA * scale, REL_EPS * scale
+    cap = 8 * nc + 1024
+    viol, loose, tight, (slack, worst) = M.certificate(u, v, col4row, delta, eps, cap)
+    if info is not None:
+        info.update(violations=viol, loose=loose, tight=None if tight is None else len(tight), max_matched_slack=slack,
+                    max_violation=worst, delta=delta, eps=eps)
+    if viol or loose or tight is None:
+        return False
+    v_free = 0.0
+    if nc > nr:
+        free = np.ones(nc, dtype=bool)
+        free[col4row] = False
+        v_free = float(v[free].min())
+        if float(v.max()) - v_free > delta:           # a matched column priced above a free one: not optimal for nr < nc
+            return False
+    t = np.ascontiguousarray(tight, dtype=np.int32)
+    c4r = np.ascontiguousarray(col4row, dtype=np.int32)
+    vv = np.ascontiguousarray(v, dtype=np.float64)
+    rc = lib.pm_lsap_unique(nr, nc, c4r.ctypes.data, vv.ctypes.data, v_free, eps, t.ctypes.data, int(len(t)))
+    if rc < 0:
+        nat.check(rc)
+    if info is not None:
+        info["unique"] = rc == 1
+    return rc == 1
+
+
+def solve_core(M, info=None):
+    """The sparse-core solve of one matrix M [nr, nc], nr <= nc, finite entries -> (u, v, col4row) with no entry of M
+    violating dual feasibility beyond delta, or None if M holds non-finite entries / pricing did not converge."""
+    nr, nc = M.shape
+    k = min(CORE_EDGES_PER_ROW, 256)
+    cols, costs, bad = M.row_select(None, k)
+    if bad:
+        return None
+    safety = M.diagonal(nr)                              # row i -> column i: the core always holds a perfect matching
+    scale = max(float(np.abs(costs[cols >= 0]).max()), float(np.abs(safety).max()), 1e-300)
+    delta = REL_DELTA * scale
+    kp = min(PRICE_EDGES_PER_ROW, 256)
+    with _Core(nr, nc) as core:
+        core.add(cols, costs)
+        core.add(np.arange(nr, dtype=np.int32)[:, None], safety[:, None])
+        rounds = 0
+        while True:
+            core.solve()
+            u, v, c4r, stats = core.get()
+            pc, pcost, _ = M.row_select(v, kp)
+            violated = core.reprice(pc, pcost, delta)
+            rounds += 1
+            if info is not None:
+                info.setdefault("violated_per_round", []).append(violated)
+            if violated == 0:
+                break
+            if rounds >= MAX_PRICING_ROUNDS:
+                return None
+        if info is not None:
+            info.update(rounds=rounds, edges=stats[0], steps=stats[1], augmentations=stats[2], dummy_scans=stats[3])
+    return u, v, c4r
+
+
+def solve_on_device(U, info=None, force=False):
+    """scipy.optimize.linear_sum_assignment(U) for a float64 GPU matrix, without moving it to the host when the sparse-core
+    scheme can certify its answer; otherwise (small matrix, non-finite entries, ties) the dense host solver, SciPy's
+    algorithm itself.  -> (row_ind, col_ind) int64, rows ascending.  info (dict): which route was taken and its counters."""
+    torch = nat.torch_mod()
+    if not (nat.is_torch(U) and U.is_cuda and U.dtype == torch.float64 and U.dim() == 2 and U.stride(1) == 1):
+        raise ValueError("U must be a float64 GPU matrix with unit column stride")
+    info = {} if info is None else info
+    n0, m0 = U.shape
+    if min(n0, m0) >= (1 if force else DEVICE_MIN_ROWS):
+        W = DeviceMatrix(U if n0 <= m0 else U.t().contiguous())      # rows are the short side (SciPy transposes likewise)
+        with torch.cuda.device(U.device):
+            sol = solve_core(W, info)
+            if sol is not None and certify(W, *sol, info=info):
+                info["route"] = "device"
+                return _answer(sol[2], n0, m0)
+    info["route"] = "host"
+    return linear_sum_assignment(U.cpu().numpy())
+
+
+def solve_eight_on_device(U8, info=None):
+    """The widget's eight assignments (_dock_widget.py:604-611) for U8 [8, N, M] on the GPU: hypotheses 11, 12, 13, 14 are
+    solved (four host threads drive their core solves and kernels concurrently); each twin (22, 21, 24, 23: the same terms
+    summed in another order) first tries its sibling's duals — accepted only if they are a certified unique optimum of the
+    twin's OWN matrix — and is solved on its own otherwise.  -> list of eight (row_ind, col_ind)."""
+    torch = nat.torch_mod()
+    n, m = U8.shape[1], U8.shape[2]
+    out = [None] * 8
+    infos = [dict() for _ in range(8)]
+    small = min(n, m) < DEVICE_MIN_ROWS
+
+    def pair(h):
+        stream = torch.cuda.Stream(device=U8.device)
+        with torch.cuda.device(U8.device), torch.cuda.stream(stream):
+            twin = [t for t, s in TWINS.items() if s == h][0]
+            W = DeviceMatrix(U8[h] if n <= m else U8[h].t().contiguous())
+            sol = None if small else solve_core(W, infos[h])
+            ok = sol is not None and certify(W, *sol, info=infos[h])
+            if ok:
+                infos[h]["route"] = "device"
+                out[h] = _answer(sol[2], n, m)
+                Wt = DeviceMatrix(U8[twin] if n <= m else U8[twin].t().contiguous())
+                if certify(Wt, *sol, info=infos[twin]):
+                    infos[twin]["route"] = "device (sibling's duals certified)"
+                    out[twin] = out[h]
+                else:
+                    out[twin] = solve_on_device(U8[twin], infos[twin])
+            else:
+                infos[h]["route"] = "host"
+                out[h] = linear_sum_assignment(U8[h].cpu().numpy())
+                out[twin] = solve_on_device(U8[twin], infos[twin]) if not small else linear_sum_assignment(U8[twin].cpu().numpy())
+            stream.synchronize()
+
+    if small:       # eight dense host solves on eight threads, each fetching its own matrix (the round-1 path)
+        stream = torch.cuda.current_stream(U8.device)
+
+        def fetch(h):
+            with torch.cuda.stream(stream):
+                return U8[h].cpu().numpy()
+        res = solve_many([lambda h=h: fetch(h) for h in range(8)])
+        if info is not None:
+            info["routes"] = ["host"] * 8
+        return res
+    torch.cuda.current_stream(U8.device).synchronize()      # U8 was produced on the caller's stream
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(pair, range(4)))
+    if info is not None:
+        info["routes"] = [i.get("route") for i in infos]
+        info["details"] = infos
+    return out
+
+
+def _answer(c4r, n, m):
+    """col4row of the (possibly transposed) problem -> SciPy's (row_ind ascending, col_ind) for the n x m matrix."""
+    if n <= m:
+        return np.arange(n, dtype=np.int64), c4r.astype(np.int64)
+    order = np.argsort(c4r, kind="stable")
+    return c4r[order].astype(np.int64), order.astype(np.int64)

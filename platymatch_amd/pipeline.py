@@ -238,24 +238,21 @@ def cost_row_argmins(be, mov, fix, rows_per_block=None, group=None):
     return all_gather_rows(idx, bn, 1, group)
 
 
-def assign(U_loc, bounds, group=None):
+def assign(U_loc, bounds, group=None, info=None):
     """linear_sum_assignment on each of the eight matrices (_dock_widget.py:604-611) -> list of
-    (row_ind, col_ind) int64 arrays, identical on every rank.  The solver is SciPy's algorithm restated in
-    C++ (lsap.py: identical indices, callable from threads): one GPU solves the eight hypotheses on eight host
-    threads; sharded, hypothesis h is assembled and solved on rank h mod G."""
+    (row_ind, col_ind) int64 arrays, identical on every rank.  On a GPU the matrices never leave HBM: a sparse core
+    of each is solved on the host and certified against every entry on the device (lsap.solve_on_device; tied or small
+    matrices fall back to SciPy's algorithm restated in C++, lsap.linear_sum_assignment: identical indices either way).
+    Sharded, hypothesis h is assembled and solved on rank h mod G.  info (dict): which route each hypothesis took."""
     import torch
+    from .lsap import solve_eight_on_device, solve_on_device
     rank, world = _world(group)
     if world == 1:
-        # eight host threads, GIL released in the copy and in the solver: thread h fetches its matrix and starts solving
-        # while the later matrices are still crossing PCIe
-        stream = torch.cuda.current_stream(U_loc.device) if U_loc.is_cuda else None
-
-        def fetch(h):
-            if stream is None:
-                return U_loc[h].numpy()
-            with torch.cuda.stream(stream):
-                return U_loc[h].cpu().numpy()
-        return solve_many([lambda h=h: fetch(h) for h in range(8)])
+        if U_loc.is_cuda:
+            # matrices stay in HBM: sparse-core solves driven from four host threads, certified on the device against every
+            # entry (lsap.solve_eight_on_device); small or tied matrices take the dense host solver, SciPy's algorithm itself
+            return solve_eight_on_device(U_loc, info=info)
+        return solve_many([U_loc[h].numpy() for h in range(8)])
     dist = _dist()
     n = bounds[-1]
     biggest = max(bounds[g + 1] - bounds[g] for g in range(world))
@@ -266,8 +263,8 @@ def assign(U_loc, bounds, group=None):
         padded[:U_loc.shape[1]].copy_(U_loc[h])
         blocks = [torch.empty_like(padded) for _ in range(world)] if owner == rank else None
         dist.gather(padded, blocks, dst=_global_rank(group, owner), group=group)   # row blocks -> the owner only
-        if owner == rank:    # keep the assembled matrix on the host; solve after all gathers so ranks solve concurrently
-            mine[h] = torch.cat([blocks[g][:bounds[g + 1] - bounds[g]] for g in range(world)], dim=0).cpu().numpy()
+        if owner == rank:    # keep the assembled matrix (on the device if that is where it is); solve after all gathers so ranks solve concurrently
+            mine[h] = torch.cat([blocks[g][:bounds[g + 1] - bounds[g]] for g in range(world)], dim=0)
             del blocks
     # A solver refusal (NaN / -inf costs from degenerate descriptors, infeasible matrix) on the owner of one hypothesis
     # must not leave the other ranks waiting in the broadcasts below: collect a status word per hypothesis, agree on it,
@@ -275,7 +272,7 @@ def assign(U_loc, bounds, group=None):
     status = torch.zeros(8, dtype=torch.int32, device=U_loc.device)
     for h in list(mine):
         try:
-            mine[h] = linear_sum_assignment(mine[h])
+            mine[h] = solve_on_device(mine[h]) if mine[h].is_cuda else linear_sum_assignment(mine[h].numpy())
         except ValueError as e:
             status[h] = 2 if "infeasible" in str(e) else 1
             mine[h] = None
@@ -443,7 +440,7 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         t0 = mark("gpu_descriptors_costs", t0)
         draws = _SampleDraws(be, min(mov.shape[1], fix.shape[1]), int(ransac_samples), int(ransac_trials), seed, private_rng)
         try:
-            lsa = assign(U, bn, group)
+            lsa = assign(U, bn, group, info=None if details is None else details.setdefault("assignment", {}))
         finally:
             del U
             t0 = mark("host_assignment", t0)

@@ -1,0 +1,123 @@
+"""The device-resident assignment solve (platymatch_amd/lsap.py) on the GPU: the two kernels that read the dense matrix
+against their NumPy restatement, and solve_on_device / solve_eight_on_device against scipy.optimize.linear_sum_assignment —
+the call the widget makes (_dock_widget.py:604-611) — on random, rectangular, tied and reference matrices."""
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment as scipy_lsa
+
+from conftest import load_golden, synth_pair
+from test_lsap_core import HostMatrix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    from platymatch_amd import _native as nat
+    from platymatch_amd.build import build_native
+    build_native()
+    nat.load()
+    assert torch.cuda.is_available()
+    return lambda x, dtype=None: nat.to_dev(x, dtype=dtype or torch.float64)
+
+
+@pytest.mark.parametrize("shape", [(7, 5), (300, 300), (257, 1000), (1000, 257), (1500, 1600)])
+def test_kernels_equal_their_numpy_restatement(dev, shape):
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(sum(shape))
+    U = rng.random(shape)
+    n, m = shape
+    W = U if n <= m else np.ascontiguousarray(U.T)
+    D, H = L.DeviceMatrix(dev(W)), HostMatrix(W)
+    v = -rng.random(W.shape[1]) * 0.1
+    for vv, k in ((None, 48), (v, 8), (v, 256)):
+        dc, dcost, dflag = D.row_select(vv, k)
+        hc, hcost, hflag = H.row_select(vv, k)
+        assert dflag == hflag == 0 and np.array_equal(dc, hc) and np.array_equal(dcost, hcost)
+    sol = L.solve_core(D)
+    assert sol is not None
+    u, v2, c4r = sol
+    scale = max(abs(u).max(), abs(v2).max())
+    for du, dv, dc4 in ((u, v2, c4r), (u + 1e-6, v2, c4r), (u, v2, np.roll(c4r, 1))):
+        cap = 8 * W.shape[1] + 1024
+        d = D.certificate(du, dv, dc4, 1e-13 * scale, 1e-7 * scale, cap)
+        h = H.certificate(du, dv, dc4, 1e-13 * scale, 1e-7 * scale, cap)
+        assert d[0] == h[0] and d[1] == h[1]
+        if h[2] is not None:
+            assert sorted(map(tuple, d[2])) == sorted(map(tuple, h[2]))
+        assert d[3] == h[3]
+    Wn = W.copy()
+    Wn[W.shape[0] // 2, 3] = np.nan
+    assert L.DeviceMatrix(dev(Wn)).row_select(None, 8)[2] == 1
+
+
+@pytest.mark.parametrize("shape", [(40, 40), (64, 900), (700, 90), (1200, 1200), (1100, 1300), (1, 5), (5, 1)])
+def test_solve_on_device_equals_scipy(dev, shape):
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(sum(shape) + 1)
+    for trial in range(3):
+        U = rng.random(shape) if trial else rng.random(shape) * rng.random((1, shape[1])) + 0.3 * rng.random((shape[0], 1))
+        info = {}
+        r, c = L.solve_on_device(dev(U), info=info, force=True)
+        rs, cs = scipy_lsa(U)
+        assert np.array_equal(r, rs) and np.array_equal(c, cs), info
+        assert info["route"] == "device", info
+    # a strided view (row block of a larger allocation) is accepted as it is
+    big = dev(rng.random((shape[0], shape[1] + 5)))
+    r, c = L.solve_on_device(big[:, :shape[1]], force=True)
+    rs, cs = scipy_lsa(big[:, :shape[1]].cpu().numpy())
+    assert np.array_equal(r, rs) and np.array_equal(c, cs)
+
+
+def test_tied_and_invalid_matrices_take_scipys_own_algorithm(dev):
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(0)
+    for trial in range(25):
+        n, m = int(rng.integers(2, 60)), int(rng.integers(2, 60))
+        U = rng.integers(0, 4, size=(n, m)).astype(np.float64)
+        info = {}
+        r, c = L.solve_on_device(dev(U), info=info, force=True)
+        rs, cs = scipy_lsa(U)
+        assert np.array_equal(r, rs) and np.array_equal(c, cs), (trial, info)         # identical indices, ties included
+    U = rng.random((40, 40))
+    U[7] = U[3]                                                                       # duplicate nuclei: identical rows
+    info = {}
+    r, c = L.solve_on_device(dev(U), info=info, force=True)
+    assert info["route"] == "host" and np.array_equal(c, scipy_lsa(U)[1])
+    U[2, 2] = np.nan
+    with pytest.raises(ValueError):
+        L.solve_on_device(dev(U), force=True)
+    U[2, 2] = np.inf                                                                  # forbidden edge: SciPy accepts it
+    r, c = L.solve_on_device(dev(U), info=info, force=True)
+    assert info["route"] == "host" and np.array_equal(c, scipy_lsa(U)[1])
+
+
+@pytest.mark.parametrize("name", ["insitu02_affine", "insitu04_affine", "synth96x128", "synth128"])
+def test_reference_scenarios_through_the_device_route(dev, name):
+    """Every hypothesis of a reference scenario, forced through the device route: the assignment vectors the reference's
+    SciPy calls produced."""
+    from platymatch_amd import lsap as L, pipeline as P
+    d = load_golden(name)
+    be = P.GpuBackend()
+    U, _ = P.build_costs(be, be.cloud(d["moving"]), be.cloud(d["fixed"]))
+    for h in range(8):
+        info = {}
+        r, c = L.solve_on_device(U[h], info=info, force=True)
+        assert info["route"] == "device", (h, info)
+        assert np.array_equal(r, d["lsa_rows"][h]) and np.array_equal(c, d["lsa_cols"][h]), h
+
+
+def test_eight_assignments_of_a_3000_point_pair_equal_scipy(dev):
+    from platymatch_amd import lsap as L, pipeline as P
+    mv, fx, _ = synth_pair(3000, 77)
+    be = P.GpuBackend()
+    U, _ = P.build_costs(be, be.cloud(mv), be.cloud(fx[:, :2900]))
+    info = {}
+    got = L.solve_eight_on_device(U, info=info)
+    assert all(r.startswith("device") for r in info["routes"]), info["routes"]
+    assert sum("sibling" in r for r in info["routes"]) == 4                            # four solves served eight hypotheses
+    for h in range(8):
+        rs, cs = scipy_lsa(U[h].cpu().numpy())
+        assert np.array_equal(got[h][0], rs) and np.array_equal(got[h][1], cs), h
+    print({k: info["details"][0].get(k) for k in ("rounds", "edges", "steps", "violated_per_round", "max_matched_slack", "tight")})

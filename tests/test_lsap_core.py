@@ -1,0 +1,171 @@
+"""The sparse-core assignment solve (platymatch_amd/lsap.py: solve_core + certify, csrc/pm_lsap_core.cpp) against
+scipy.optimize.linear_sum_assignment — the widget's call (_dock_widget.py:604-611) — on the CPU: the two device kernels
+that read the dense matrix are replaced by a NumPy double with the same contract (tests/test_gpu_lsap.py runs the real
+kernels), so what is exercised here is the host solver, the pricing loop, the rectangular (dummy row) handling and the
+uniqueness certificate: whenever the certificate says "unique", the indices must be SciPy's; tied matrices must be
+refused (they go to pm_lsap_solve, SciPy's algorithm step for step)."""
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment as scipy_lsa
+
+from conftest import load_golden
+
+
+class HostMatrix:
+    """NumPy restatement of DeviceMatrix's contract (pm_lsap_row_select / pm_lsap_certificate)."""
+
+    def __init__(self, U):
+        self.U = np.ascontiguousarray(U, dtype=np.float64)
+        self.shape = self.U.shape
+        self.passes = 0
+
+    def row_select(self, v, k):
+        self.passes += 1
+        nr, nc = self.U.shape
+        red = self.U if v is None else self.U - v[None, :]
+        cols = np.full((nr, k), -1, dtype=np.int32)
+        costs = np.full((nr, k), np.inf)
+        pad = (-nc) % 256
+        R = np.concatenate([red, np.full((nr, pad), np.inf)], axis=1).reshape(nr, -1, 256)      # [nr, chunk, class]
+        first = R.argmin(axis=1)                                                                 # first minimum per class
+        cand_col = first * 256 + np.arange(256)[None, :]
+        cand_red = np.take_along_axis(R, first[:, None, :], axis=1)[:, 0, :]
+        cand_col = np.where(np.isfinite(cand_red), cand_col, np.iinfo(np.int32).max)
+        order = np.lexsort((cand_col, cand_red), axis=1)[:, :k]
+        kk = order.shape[1]
+        sel = np.take_along_axis(cand_col, order, axis=1)
+        ok = sel < nc
+        cols[:, :kk] = np.where(ok, sel, -1)
+        costs[:, :kk] = np.where(ok, self.U[np.arange(nr)[:, None], np.minimum(sel, nc - 1)], np.inf)
+        return cols, costs, int(not np.isfinite(self.U).all())
+
+    def diagonal(self, n):
+        return self.U[np.arange(n), np.arange(n)].copy()
+
+    def certificate(self, u, v, col4row, delta, eps, cap):
+        self.passes += 1
+        red = (self.U - v[None, :]) - u[:, None]
+        nr = self.U.shape[0]
+        matched = np.zeros(self.U.shape, dtype=bool)
+        matched[np.arange(nr), col4row] = True
+        viol = int((~(red >= -delta) & ~matched).sum())
+        loose = int((~(np.abs(red) <= delta) & matched).sum())
+        t = np.argwhere((red <= eps) & (red >= -delta) & ~matched).astype(np.int32)
+        slack = float(np.abs(red[matched]).max())
+        return viol, loose, (t if len(t) <= cap else None), (slack, float(max(0.0, -(red[~matched]).min())))
+
+
+def run(U, force_k=None):
+    from platymatch_amd import lsap as L
+    n, m = U.shape
+    M = HostMatrix(U if n <= m else U.T)
+    info = {}
+    sol = L.solve_core(M, info)
+    if sol is None:
+        return None, info
+    ok = L.certify(M, *sol, info=info)
+    return (L._answer(sol[2], n, m) if ok else None), info
+
+
+@pytest.mark.parametrize("shape", [(40, 40), (300, 300), (257, 300), (300, 257), (64, 900), (700, 90), (1, 5), (5, 1), (600, 640)])
+def test_generic_matrices_are_certified_and_equal_scipy(shape):
+    rng = np.random.default_rng(sum(shape))
+    for trial in range(4):
+        U = rng.random(shape) if trial % 2 == 0 else rng.random(shape) * rng.random((1, shape[1])) + 0.3 * rng.random((shape[0], 1))
+        got, info = run(U)
+        assert got is not None, info
+        r, c = scipy_lsa(U)
+        assert np.array_equal(got[0], r) and np.array_equal(got[1], c), info
+
+
+def test_structured_costs_need_pricing_rounds_and_still_equal_scipy():
+    """A matrix whose optimum avoids most rows' cheapest entries: decoy columns that are cheap for every row."""
+    rng = np.random.default_rng(3)
+    n = 700
+    U = rng.random((n, n)) + 1.0
+    U[:, :6] = rng.random((n, 6)) * 1e-3                    # six columns everybody wants
+    U[np.arange(n), rng.permutation(n)] -= 0.9              # the hidden good matching
+    got, info = run(U)
+    assert got is not None and info["rounds"] >= 2, info
+    r, c = scipy_lsa(U)
+    assert np.array_equal(got[1], c)
+
+
+@pytest.mark.parametrize("name", ["insitu02_affine", "insitu04_affine", "synth96x128", "synth1000"])
+def test_reference_cost_matrices(oracle, name):
+    """The eight matrices of a reference scenario (rebuilt by the oracle from the fixture's histograms): certified, equal to the
+    assignment vectors the reference's own SciPy calls produced, and each twin accepts its sibling's duals."""
+    from platymatch_amd import lsap as L
+    d = load_golden(name)
+    um = [d["counts_m%d" % k].astype(np.float64) / d["total_m%d" % k][:, None] for k in (1, 2)]
+    uf = [d["counts_f%d" % k].astype(np.float64) / d["total_f%d" % k][:, None] for k in (1, 2, 3, 4)]
+    if name == "synth1000":
+        um, uf = [a[:400] for a in um], [b[:450] for b in uf]
+    Us = [oracle.unary_distance_matrix(um[int(h[0]) - 1], uf[int(h[1]) - 1]) for h in oracle.HYPOTHESES]
+    sols = {}
+    for h in range(8):
+        n, m = Us[h].shape
+        M = HostMatrix(Us[h] if n <= m else Us[h].T)
+        sol = L.solve_core(M)
+        assert sol is not None and L.certify(M, *sol)
+        sols[h] = sol
+        r, c = scipy_lsa(Us[h])
+        got = L._answer(sol[2], n, m)
+        assert np.array_equal(got[0], r) and np.array_equal(got[1], c), h
+        if name != "synth1000":
+            assert np.array_equal(c, d["lsa_cols"][h])
+    for twin, h in L.TWINS.items():
+        n, m = Us[twin].shape
+        M = HostMatrix(Us[twin] if n <= m else Us[twin].T)
+        assert L.certify(M, *sols[h])                        # one solve serves both, proven on the twin's own entries
+        assert np.array_equal(sols[h][2], sols[twin][2])
+
+
+def test_tied_matrices_are_refused_not_guessed():
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(0)
+    refused = 0
+    for trial in range(40):
+        n, m = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+        U = rng.integers(0, 4, size=(n, m)).astype(np.float64)          # few distinct values: many optimal assignments
+        got, info = run(U)
+        if got is None:
+            refused += 1
+        else:                                                            # certified unique: then it must be SciPy's answer
+            r, c = scipy_lsa(U)
+            assert np.array_equal(got[1], c), (trial, info)
+    assert refused >= 30
+    # duplicate rows (duplicate nuclei give identical descriptor rows): two optimal assignments -> refused
+    U = rng.random((30, 30))
+    U[7] = U[3]
+    assert run(U)[0] is None
+    # constant matrix, and a duplicate COLUMN in a wide matrix
+    assert run(np.ones((6, 6)))[0] is None
+    W = rng.random((10, 14))
+    r, c = scipy_lsa(W)
+    W2 = np.concatenate([W, W[:, c[:1]]], axis=1)                       # a free column identical to a used one
+    assert run(W2)[0] is None
+
+
+def test_non_finite_entries_are_left_to_the_dense_solver():
+    U = np.random.default_rng(1).random((20, 20))
+    U[3, 4] = np.nan
+    assert run(U)[0] is None
+    U[3, 4] = np.inf
+    assert run(U)[0] is None
+
+
+def test_certificate_rejects_a_wrong_assignment_and_perturbed_duals():
+    from platymatch_amd import lsap as L
+    U = np.random.default_rng(5).random((50, 60))
+    M = HostMatrix(U)
+    u, v, c4r = L.solve_core(M)
+    assert L.certify(M, u, v, c4r)
+    bad = c4r.copy()
+    bad[[0, 1]] = bad[[1, 0]]
+    assert not L.certify(M, u, v, bad)
+    assert not L.certify(M, u + 1e-6, v, c4r)
+    v2 = v.copy()
+    free = np.setdiff1d(np.arange(60), c4r)
+    v2[free[0]] -= 0.5                                    # a free column priced below the matched ones: not a rectangular optimum
+    assert not L.certify(M, u, v2, c4r)
