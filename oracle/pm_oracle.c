@@ -22,6 +22,7 @@
  * Their published algorithms are restated where used.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -86,17 +87,31 @@ int pmo_bin_index(const double *nb, int n, double mean_dist, double *idx_out) {
     return 0;
 }
 
+/* Threads for the row loops below (rows are independent: every output element is produced by one thread, so results do
+ * not depend on the count).  Default 1; bench.py's cpu_baseline leg raises it to the host's cores for its all-cores figure. */
+static int g_threads = 1;
+int pmo_set_threads(int t) {
+    g_threads = t > 0 ? t : 1;
+    return g_threads;
+}
+int pmo_max_threads(void) { return omp_get_num_procs(); }
+
 /* get_mean_distance (utils/utils.py:58-75): mean of ||p_i - p_j|| over i<j.
  * The reference averages a Python list with np.average (pairwise summation);
  * this restatement sums per row then over rows — equal to ~1e-14 relative. */
 int pmo_mean_distance(const double *xyz, int n, double *out) {
     const double *X = xyz, *Y = xyz + n, *Z = xyz + 2 * (size_t)n;
-    double total = 0.0;
+    double *rows = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    if (!rows) return -1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
     for (int i = 0; i < n; ++i) {
         double row = 0.0;
         for (int j = i + 1; j < n; ++j) row += norm3(X[i] - X[j], Y[i] - Y[j], Z[i] - Z[j]);
-        total += row;
+        rows[i] = row;
     }
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) total += rows[i];       /* row sums added in row order: the same value for any thread count */
+    free(rows);
     *out = total / (0.5 * (double)n * (double)(n - 1));
     return 0;
 }
@@ -145,6 +160,7 @@ int pmo_shape_context_counts(const double *xyz, int n, const double *centroid, c
                              double mean_dist, int n_frames, int32_t *counts, int32_t *totals) {
     memset(counts, 0, sizeof(int32_t) * (size_t)n_frames * n * PM_NBINS);
     memset(totals, 0, sizeof(int32_t) * (size_t)n_frames * n);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(g_threads)
     for (int i = 0; i < n; ++i)
         sc_one_point(xyz, n, i, centroid, x0, mean_dist, n_frames, counts + (size_t)i * PM_NBINS, totals + i,
                      (size_t)n * PM_NBINS, (size_t)n);
@@ -157,8 +173,10 @@ int pmo_shape_context_rows(const double *xyz, int n, const int32_t *rows, int n_
                            double mean_dist, int n_frames, int32_t *counts, int32_t *totals) {
     memset(counts, 0, sizeof(int32_t) * (size_t)n_frames * n_rows * PM_NBINS);
     memset(totals, 0, sizeof(int32_t) * (size_t)n_frames * n_rows);
-    for (int r = 0; r < n_rows; ++r) {
+    for (int r = 0; r < n_rows; ++r)
         if (rows[r] < 0 || rows[r] >= n) return -1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+    for (int r = 0; r < n_rows; ++r) {
         sc_one_point(xyz, n, rows[r], centroid, x0, mean_dist, n_frames, counts + (size_t)r * PM_NBINS, totals + r,
                      (size_t)n_rows * PM_NBINS, (size_t)n_rows);
     }
@@ -169,6 +187,7 @@ int pmo_shape_context_rows(const double *xyz, int n, const int32_t *rows, int n_
  * N x M double loops (_dock_widget.py:547-602).  Sequential sum over the 360
  * bins in index order, bins with a == b skipped. */
 int pmo_chi2(const double *a, int n, const double *b, int m, double *out) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
     for (int i = 0; i < n; ++i) {
         const double *ai = a + (size_t)i * PM_NBINS;
         for (int j = 0; j < m; ++j) {
@@ -190,6 +209,7 @@ int pmo_chi2(const double *a, int n, const double *b, int m, double *out) {
  * scipy.spatial.distance_matrix = sum(|x-y|**2, axis=-1)**0.5 (scipy/spatial/_kdtree.py
  * minkowski_distance, p=2), then np.argmin(axis=1) — first index on ties. */
 int pmo_nn_argmin(const double *mov, int n, const double *fix, int m, int32_t *idx, double *dist) {
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
     for (int i = 0; i < n; ++i) {
         double best = INFINITY;
         int bj = 0;
@@ -209,6 +229,7 @@ int pmo_nn_argmin(const double *mov, int n, const double *fix, int m, int32_t *i
  * inliers = #{ ||fixed - predicted|| <= error }. */
 int pmo_ransac_score(const double *mov, const double *fix, int n, const double *A, int trials,
                      double error, int32_t *inliers) {
+#pragma omp parallel for schedule(dynamic, 8) num_threads(g_threads)
     for (int t = 0; t < trials; ++t) {
         const double *a = A + 16 * (size_t)t;
         int cnt = 0;

@@ -40,6 +40,19 @@ def lib():
     return _lib
 
 
+def set_threads(t):
+    """Threads for the oracle's row loops (results do not depend on it). -> the count now in force."""
+    return int(lib().pmo_set_threads(ctypes.c_int(int(t))))
+
+
+def host_threads():
+    """Cores this process may run on (its affinity mask, not the machine's socket count)."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(LS_THREADS) void row_select_kernel(const double *__
     for (int t = 0; t < LS_THREADS; ++t) {
         const double r = s_red[t];                          // same address in every lane: an LDS broadcast
         const int c = s_col[t];
-        rank += (r < best || (r == best && c < best_col)) ? 1 : 0;
+        rank += (r < best || (r == best && (c < best_col || (c == best_col && t < tid)))) ? 1 : 0;   // empty threads tie: thread order
     }
     if (rank < k) {
         out_col[(size_t)blockIdx.x * k + rank] = (best_col == 0x7fffffff) ? -1 : best_col;

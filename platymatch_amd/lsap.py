@@ -115,6 +115,7 @@ class DeviceMatrix:
     def __init__(self, U):
         self.U = U
         self.shape = tuple(U.shape)
+        self.ld = U.stride(0) if U.shape[0] > 1 else U.shape[1]      # a one-row tensor's row stride is arbitrary
 
     def row_select(self, v, k):
         """-> (cols [nr, k] int32, costs [nr, k] float64, nonfinite flag): pm_lsap_row_select."""
@@ -125,7 +126,7 @@ class DeviceMatrix:
         costs = torch.empty((nr, k), dtype=torch.float64, device=U.device)
         flag = torch.empty(1, dtype=torch.int32, device=U.device)
         v_dev = None if v is None else nat.to_dev(v, dev=U.device)
-        nat.check(nat.load().pm_lsap_row_select(nat.ptr(U), nr, nc, U.stride(0), nat.ptr(v_dev), k, nat.ptr(cols), nat.ptr(costs),
+        nat.check(nat.load().pm_lsap_row_select(nat.ptr(U), nr, nc, self.ld, nat.ptr(v_dev), k, nat.ptr(cols), nat.ptr(costs),
                                                 nat.ptr(flag), nat.stream_ptr(U)))
         return cols.cpu().numpy(), costs.cpu().numpy(), int(flag.item())
 
@@ -144,7 +145,7 @@ class DeviceMatrix:
         summary = torch.empty(4, dtype=torch.int32, device=U.device)
         stats = torch.empty(2, dtype=torch.float64, device=U.device)
         tight = torch.empty((cap, 2), dtype=torch.int32, device=U.device)
-        nat.check(nat.load().pm_lsap_certificate(nat.ptr(U), nr, nc, U.stride(0), nat.ptr(u_d), nat.ptr(v_d), nat.ptr(c_d), float(delta),
+        nat.check(nat.load().pm_lsap_certificate(nat.ptr(U), nr, nc, self.ld, nat.ptr(u_d), nat.ptr(v_d), nat.ptr(c_d), float(delta),
                                                  float(eps), nat.ptr(summary), nat.ptr(stats), nat.ptr(tight), cap, nat.stream_ptr(U)))
         viol, n_tight, loose, _ = summary.cpu().tolist()
         st = stats.cpu().tolist()
