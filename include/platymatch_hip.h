@@ -182,11 +182,12 @@ int pm_lsap_row_select(const double *U, int nr, int nc, size_t ld, const double 
 
 /* DEVICE: certificate of (u[nr], v[nc], col4row[nr]) against every entry of U.  summary4 = { entries with reduced cost
  * (U[i][j] - v[j]) - u[i] < -delta; non-matching entries with reduced cost <= eps, appended to tight[cap][2] as (row, col)
- * — if the count exceeds cap the list is incomplete; matched entries with |reduced cost| > delta; 0 }.  stats2 = { largest
- * |reduced cost| on a matched entry, largest violation }. */
+ * with their reduced costs in tight_red[cap] — if the count exceeds cap the list is incomplete; matched entries with
+ * |reduced cost| > delta; 0 }.  stats2 = { largest |reduced cost| on a matched entry, largest violation }: the caller
+ * derives from them how small an eps still separates the optimum from every alternative, and filters the list by it. */
 int pm_lsap_certificate(const double *U, int nr, int nc, size_t ld, const double *u, const double *v,
                         const int32_t *col4row, double delta, double eps, int32_t *summary4, double *stats2,
-                        int32_t *tight, int cap, void *stream);
+                        int32_t *tight, double *tight_red, int cap, void *stream);
 
 /* HOST: the sparse core solver, one instance per matrix (nr <= nc; nc - nr implicit zero-cost dummy rows square the
  * problem).  add: k candidate edges per real row (cols [nr][k], -1 skipped, duplicates skipped).  solve: augment every

@@ -15,16 +15,21 @@
 
 namespace pm {
 
-// moment sums + solve + apply + residual of one iteration (pm_transform.hip)
-int refit_apply(double *mov, int n, const double *fix, int m, const int32_t *nn, const double *origin6, double *A_icp16,
-                double *acc_ws, double *res_ring, int it, int32_t *status, hipStream_t s);
-int residual_rows(const double *res_ring, int n, int count, double *mean_out, hipStream_t s);
-size_t residual_ring_bytes(int n);
-constexpr int ICP_RES_RING = 64;               // = TF_RES_RING (pm_transform.hip)
+// apply + residual with a given 4x4 (pm_transform.hip): the tail of the fused loop
+int update(const double *sums, const double *origin6, const double *A_given, double *mov, int n, const double *fix, int m,
+           const int32_t *nn, double *A_icp16, double *A_est16, double *parts2, double *mean_out, double *ws, int32_t *status,
+           hipStream_t s);
 // uniform-grid search (pm_icp_grid.hip): same results as the brute-force kernels below, O(N) instead of O(N*M) per iteration
 size_t grid_ws_bytes(int m);
 int grid_build(const double *fix, int m, void *ws, hipStream_t s);
 int grid_query(const double *mov, int n, int m, const void *ws, int32_t *nn, double *dist, hipStream_t s);
+// one whole ICP iteration per launch (pm_icp_grid.hip)
+size_t iter_leaf_bytes(int n);
+size_t iter_group_bytes(int n);
+size_t iter_counter_bytes(int n);
+int icp_iteration(bool first, double *mov, int n, const double *fix, int m, const void *grid_ws, const int32_t *nn_prev, int32_t *nn_out,
+                  const double *origin6, double *leaf_partial, double *group_partial, unsigned int *counters, double *A_est,
+                  double *A_icp, double *res_prev_out, int32_t *status, hipStream_t s);
 
 constexpr int NN_THREADS = 256;
 constexpr int NN_TILE = 128;                   // moving points per wave (two per lane)
@@ -182,17 +187,19 @@ __global__ void icp_init_kernel(const double *__restrict__ fix, int m, double *_
 }
 
 struct IcpWs {
-    size_t nn_ws, nn, acc_ws, res_ring, origin, total;
+    size_t grid, nn, leaf, group, counters, update_ws, small, total;
 };
 
 inline IcpWs icp_layout(int n, int m) {
     IcpWs w;
     size_t o = 0;
-    w.nn_ws = o; o += align_up(grid_ws_bytes(m), 256);
-    w.nn = o; o += align_up((size_t)n * sizeof(int32_t), 256);
-    w.acc_ws = o; o += align_up(pm_icp_accumulate_workspace(n), 256);
-    w.res_ring = o; o += align_up(residual_ring_bytes(n), 256);
-    w.origin = o; o += 256;
+    w.grid = o; o += align_up(grid_ws_bytes(m), 256);
+    w.nn = o; o += align_up(2 * (size_t)n * sizeof(int32_t), 256);            // matches of this and of the previous iteration
+    w.leaf = o; o += align_up(iter_leaf_bytes(n), 256);
+    w.group = o; o += align_up(iter_group_bytes(n), 256);
+    w.counters = o; o += align_up(iter_counter_bytes(n), 256);
+    w.update_ws = o; o += align_up(pm_icp_update_workspace(n), 256);
+    w.small = o; o += 512;                                                       // origin[6] | A_est[16]
     w.total = o;
     return w;
 }
@@ -246,27 +253,26 @@ int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_ic
     const pm::IcpWs L = pm::icp_layout(n, m);
     char *base = (char *)ws;
     int32_t *nn_buf = (int32_t *)(base + L.nn);
-    double *acc_ws = (double *)(base + L.acc_ws);
-    double *res_ring = (double *)(base + L.res_ring);
-    double *origin = (double *)(base + L.origin);
+    double *origin = (double *)(base + L.small), *A_est = origin + 8;
+    unsigned int *counters = (unsigned int *)(base + L.counters);
     pm::icp_init_kernel<<<1, 64, 0, s>>>(fix, m, origin, A_icp16, status1);
-    if (iters > 0) {                                   // the fixed cloud never changes: bin it once
-        int rc = pm::grid_build(fix, m, base + L.nn_ws, s);
+    if (iters == 0) return pm::launch_status();
+    if (hipMemsetAsync(counters, 0, pm::iter_counter_bytes(n), s) != hipSuccess) return pm::launch_status();
+    int rc = pm::grid_build(fix, m, base + L.grid, s);             // the fixed cloud never changes: bin it once
+    if (rc != PM_OK) return rc;
+    // ONE launch per iteration: iteration `it` applies the transform fitted by iteration it-1 on the way in
+    const int32_t *nn_prev = nullptr;
+    for (int it = 0; it < iters; ++it) {
+        int32_t *nn = nn_all ? nn_all + (size_t)it * n : nn_buf + (size_t)(it & 1) * n;
+        rc = pm::icp_iteration(it == 0, mov, n, fix, m, base + L.grid, nn_prev, nn, origin, (double *)(base + L.leaf),
+                               (double *)(base + L.group), counters, A_est, A_icp16, (residuals && it > 0) ? residuals + (it - 1) : nullptr,
+                               status1, s);
         if (rc != PM_OK) return rc;
+        nn_prev = nn;
     }
-    for (int it = 0; it < iters; ++it) {               // three launches per iteration: search, moments, solve + apply
-        int32_t *nn = nn_all ? nn_all + (size_t)it * n : nn_buf;
-        int rc = pm::grid_query(mov, n, m, base + L.nn_ws, nn, nullptr, s);
-        if (rc != PM_OK) return rc;
-        rc = pm::refit_apply(mov, n, fix, m, nn, origin, A_icp16, acc_ws, res_ring, it, status1, s);
-        if (rc != PM_OK) return rc;
-        const int filled = it % pm::ICP_RES_RING + 1;  // residual partials waiting in the ring
-        if (residuals && (filled == pm::ICP_RES_RING || it + 1 == iters)) {
-            rc = pm::residual_rows(res_ring, n, filled, residuals + (it + 1 - filled), s);
-            if (rc != PM_OK) return rc;
-        }
-    }
-    return pm::launch_status();
+    // the last fitted transform still has to be applied (perform_icp.py:23) and its residual taken (:24)
+    return pm::update(nullptr, nullptr, A_est, mov, n, fix, m, nn_prev, nullptr, nullptr, nullptr,
+                      residuals ? residuals + (iters - 1) : nullptr, (double *)(base + L.update_ws), nullptr, s);
 }
 
 }  // extern "C"

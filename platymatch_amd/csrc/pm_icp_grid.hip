@@ -11,6 +11,7 @@
 // point that could tie or win lies within the explored radius; candidate order does not matter since ties are broken
 // on the stored original index explicitly.  Work per iteration drops from N*M to ~N * (points in ~27 cells).
 #include "pm_common.h"
+#include "pm_solve.h"
 
 namespace pm {
 
@@ -191,23 +192,24 @@ __device__ __forceinline__ bool grid_better(double aS, int aI, double bS, int bI
 // (the 3 x 3 x 3 cube around the home cell first, then shells of growing Chebyshev radius), GR_BATCH cells at a time —
 // the cell ranges of a batch are fetched together (independent loads, one round trip), then their points are compared —
 // and the group's candidates are merged with the exact comparator.
+// GridSearch holds one lane's view of one query; `bS`/`bI` may be pre-loaded with a known candidate (exact: a candidate
+// offered twice changes nothing).
 template <int L>
-__global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__ mov, int n, const GridHeader *__restrict__ hdp,
-                                                      const int *__restrict__ start, const double4 *__restrict__ pts,
-                                                      int32_t *__restrict__ nn, double *__restrict__ dist) {
-    const int sub = threadIdx.x & (L - 1);
-    const int i = (int)(((long)blockIdx.x * 256 + threadIdx.x) / L);
-    const int ic = min(i, n - 1);                                 // surplus groups shadow the last point (no divergent exit before shuffles)
-    const GridHeader hd = *hdp;
-    const double p0 = mov[ic], p1 = mov[(size_t)n + ic], p2 = mov[2 * (size_t)n + ic];
-    const int cx = cell_coord(p0, hd.lo[0], hd.inv_h, hd.g[0]);
-    const int cy = cell_coord(p1, hd.lo[1], hd.inv_h, hd.g[1]);
-    const int cz = cell_coord(p2, hd.lo[2], hd.inv_h, hd.g[2]);
-    const int rmax = max(max(max(cx, hd.g[0] - 1 - cx), max(cy, hd.g[1] - 1 - cy)), max(cz, hd.g[2] - 1 - cz));
-    double bS = INFINITY;
-    int bI = 0x7fffffff;           // "nothing yet": loses every index tie; replaced by 0 at the end if nothing ever matched
+struct GridSearch {
+    const GridHeader &hd;
+    const int *__restrict__ start;
+    const double4 *__restrict__ pts;
+    const double p0, p1, p2;
+    const int sub;
+    double bS;
+    int bI;
+
+    __device__ __forceinline__ GridSearch(const GridHeader &h, const int *st, const double4 *pt, double x, double y, double z, int s)
+        : hd(h), start(st), pts(pt), p0(x), p1(y), p2(z), sub(s), bS(INFINITY), bI(0x7fffffff) {}
+    // bI = 0x7fffffff is "nothing yet": loses every index tie; replaced by 0 at the end if nothing ever matched
+
     // candidates q0, q0 + step, ... < q1, GR_INFLIGHT loads in flight at a time
-    auto scan = [&](int q0, int q1, int step) {
+    __device__ __forceinline__ void scan(int q0, int q1, int step) {
         for (int q = q0; q < q1; q += GR_INFLIGHT * step) {
             double4 f[GR_INFLIGHT];
 #pragma unroll
@@ -220,9 +222,10 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__
                 if (grid_better(s, j, bS, bI)) { bS = s; bI = j; }     // a clamped repeat of the last candidate changes nothing
             }
         }
-    };
+    }
+
     // cells of the cube of radius r around the home cell; shell_only: those at Chebyshev distance exactly r
-    auto pass = [&](int r, bool shell_only) {
+    __device__ __forceinline__ void pass(int cx, int cy, int cz, int r, bool shell_only) {
         const int w = 2 * r + 1, cube = w * w * w;
         for (int k0 = sub; k0 < cube; k0 += L * GR_BATCH) {
             int q0[GR_BATCH], q1[GR_BATCH];
@@ -240,54 +243,249 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__
 #pragma unroll
             for (int u = 0; u < GR_BATCH; ++u) scan(q0[u], q1[u], 1);
         }
-    };
-    auto merge = [&]() {          // butterfly over the group: afterwards every lane holds the winner
+    }
+
+    __device__ __forceinline__ void merge() {          // butterfly over the group: afterwards every lane holds the winner
 #pragma unroll
         for (int off = L / 2; off > 0; off >>= 1) {
             const double oS = __shfl_xor(bS, off, 64);
             const int oI = __shfl_xor(bI, off, 64);
             if (grid_better(oS, oI, bS, bI)) { bS = oS; bI = oI; }
         }
-    };
-    // rings 0 and 1 together, the 3 x 3 x 3 cube around the home cell.  Cells adjacent in x are adjacent in memory, and so
-    // are their points: the cube is nine runs of (up to) three cells.  Three lanes share a run — the same two range
-    // loads, then interleaved points, so that neighbouring lanes touch neighbouring 32-byte records.
-    if (L >= 32) {
-        if (sub < 27) {
-            const int run = sub / 3, part = sub - 3 * run;
-            const int y = cy + run % 3 - 1, z = cz + run / 3 - 1;
-            if (y >= 0 && z >= 0 && y < hd.g[1] && z < hd.g[2]) {
-                const int row = (z * hd.g[1] + y) * hd.g[0];
-                scan(start[row + max(cx - 1, 0)] + part, start[row + min(cx + 1, hd.g[0] - 1) + 1], 3);
-            }
-        }
-    } else {
-        pass(1, false);
     }
-    merge();
-    int r = 1;
-    // everything not yet visited is farther than r*h (minus the rounding slack of the cell map)
-    // (reach_scale <= 0 for absurd coordinate / cell-size ratios simply widens the search to the full scan)
-    while (!(hd.reach_scale > 0.0 && bS < (r * hd.h * hd.reach_scale) * (r * hd.h * hd.reach_scale)) && r < rmax) {
-        ++r;
-        if (r > GR_RING_CAP) {                                  // sparse neighbourhood: scan every point (always exact)
-            const int m_all = start[hd.ncells];
-            for (int q = sub; q < m_all; q += L) {
-                const double4 f = pts[q];
-                const double d0 = f.x - p0, d1 = f.y - p1, d2 = f.z - p2;
-                const double s = (d0 * d0 + d1 * d1) + d2 * d2;
-                const int j = (int)__double_as_longlong(f.w);
-                if (grid_better(s, j, bS, bI)) { bS = s; bI = j; }
+
+    // The exact nearest neighbour by rings of cells around the home cell (every lane of the group ends with the winner).
+    __device__ __forceinline__ void rings() {
+        const int cx = cell_coord(p0, hd.lo[0], hd.inv_h, hd.g[0]);
+        const int cy = cell_coord(p1, hd.lo[1], hd.inv_h, hd.g[1]);
+        const int cz = cell_coord(p2, hd.lo[2], hd.inv_h, hd.g[2]);
+        const int rmax = max(max(max(cx, hd.g[0] - 1 - cx), max(cy, hd.g[1] - 1 - cy)), max(cz, hd.g[2] - 1 - cz));
+        // rings 0 and 1 together, the 3 x 3 x 3 cube around the home cell.  Cells adjacent in x are adjacent in memory, and so
+        // are their points: the cube is nine runs of (up to) three cells.  Three lanes share a run — the same two range
+        // loads, then interleaved points, so that neighbouring lanes touch neighbouring 32-byte records.
+        if (L >= 32) {
+            if (sub < 27) {
+                const int run = sub / 3, part = sub - 3 * run;
+                const int y = cy + run % 3 - 1, z = cz + run / 3 - 1;
+                if (y >= 0 && z >= 0 && y < hd.g[1] && z < hd.g[2]) {
+                    const int row = (z * hd.g[1] + y) * hd.g[0];
+                    scan(start[row + max(cx - 1, 0)] + part, start[row + min(cx + 1, hd.g[0] - 1) + 1], 3);
+                }
             }
-            merge();
-            break;
+        } else {
+            pass(cx, cy, cz, 1, false);
         }
-        pass(r, true);
         merge();
+        int r = 1;
+        // everything not yet visited is farther than r*h (minus the rounding slack of the cell map)
+        // (reach_scale <= 0 for absurd coordinate / cell-size ratios simply widens the search to the full scan)
+        while (!(hd.reach_scale > 0.0 && bS < (r * hd.h * hd.reach_scale) * (r * hd.h * hd.reach_scale)) && r < rmax) {
+            ++r;
+            if (r > GR_RING_CAP) {                                  // sparse neighbourhood: scan every point (always exact)
+                const int m_all = start[hd.ncells];
+                for (int q = sub; q < m_all; q += L) {
+                    const double4 f = pts[q];
+                    const double d0 = f.x - p0, d1 = f.y - p1, d2 = f.z - p2;
+                    const double s = (d0 * d0 + d1 * d1) + d2 * d2;
+                    const int j = (int)__double_as_longlong(f.w);
+                    if (grid_better(s, j, bS, bI)) { bS = s; bI = j; }
+                }
+                merge();
+                break;
+            }
+            pass(cx, cy, cz, r, true);
+            merge();
+        }
     }
+
+    // The same answer when a candidate at squared distance bS is already known (ICP: the previous iteration's match): every
+    // point that could beat or tie it lies within sqrt(bS) of the query, hence in the cells the box query +- rad covers
+    // (the point -> cell map is monotone per axis, so no slack beyond rad >= the true distance is needed).  The box is at
+    // most ny * nz <= L runs of x-adjacent cells; lanes share the runs.  Returns false (nothing scanned) if the box is larger.
+    __device__ __forceinline__ bool ball(double rad) {
+        const int x0 = cell_coord(p0 - rad, hd.lo[0], hd.inv_h, hd.g[0]), x1 = cell_coord(p0 + rad, hd.lo[0], hd.inv_h, hd.g[0]);
+        const int y0 = cell_coord(p1 - rad, hd.lo[1], hd.inv_h, hd.g[1]), y1 = cell_coord(p1 + rad, hd.lo[1], hd.inv_h, hd.g[1]);
+        const int z0 = cell_coord(p2 - rad, hd.lo[2], hd.inv_h, hd.g[2]), z1 = cell_coord(p2 + rad, hd.lo[2], hd.inv_h, hd.g[2]);
+        const int ny = y1 - y0 + 1, nruns = ny * (z1 - z0 + 1);
+        if (nruns > L || nruns < 1) return false;
+        const int per = L / nruns;                       // lanes per run
+        const int run = sub / per, part = sub - run * per;
+        if (run < nruns) {
+            const int row = ((z0 + run / ny) * hd.g[1] + (y0 + run % ny)) * hd.g[0];
+            scan(start[row + x0] + part, start[row + x1 + 1], per);
+        }
+        merge();
+        return true;
+    }
+};
+
+template <int L>
+__global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__ mov, int n, const GridHeader *__restrict__ hdp,
+                                                      const int *__restrict__ start, const double4 *__restrict__ pts,
+                                                      int32_t *__restrict__ nn, double *__restrict__ dist) {
+    const int sub = threadIdx.x & (L - 1);
+    const int i = (int)(((long)blockIdx.x * 256 + threadIdx.x) / L);
+    const int ic = min(i, n - 1);                                 // surplus groups shadow the last point (no divergent exit before shuffles)
+    const GridHeader hd = *hdp;
+    GridSearch<L> q(hd, start, pts, mov[ic], mov[(size_t)n + ic], mov[2 * (size_t)n + ic], sub);
+    q.rings();
     if (sub == 0 && i < n) {
-        nn[i] = (bI == 0x7fffffff) ? 0 : bI;                     // all-NaN row: np.argmin answers 0
-        if (dist) dist[i] = __builtin_sqrt(bS);
+        nn[i] = (q.bI == 0x7fffffff) ? 0 : q.bI;                 // all-NaN row: np.argmin answers 0
+        if (dist) dist[i] = __builtin_sqrt(q.bS);
+    }
+}
+
+// ---- one whole ICP iteration in one launch (perform_icp.py:14-25) -----------------------------------------------------------
+// Workgroup = 8 moving points x 32 lanes = one LEAF of the reduction tree (pm_solve.h).  Per point:
+//   (not FIRST) apply the previous iteration's A_est (:23), store the moved point, residual against the previous match (:24);
+//   nearest fixed point (:15-16): the previous match bounds the search (GridSearch::ball), rings otherwise;
+//   the 22 moment terms of (point, match) (:18's least squares as normal equations) and the residual term -> leaf partial.
+// The workgroup that completes a group of 64 leaves adds them in leaf order; the one that completes the last group adds the
+// groups in order, solves the 4 x 4 (A_est for the next launch), composes A_icp (:25) and writes the mean residual — the
+// "last one out" pattern: a counter per group, no workgroup ever waits for another.
+constexpr int IT_SLOTS = PM_NMOMENTS + 1;          // 22 moments + residual
+constexpr int IT_STRIDE = 24;
+
+struct IterArgs {
+    double *mov; int n;
+    const GridHeader *hd; const int *start; const double4 *pts;
+    const double *fix; int m;
+    const int32_t *nn_prev; int32_t *nn_out;
+    const double *A_prev;            // 16: the transform fitted by the previous launch (unused if FIRST)
+    const double *origin6;
+    double *leaf_partial;            // [leaves][IT_STRIDE]
+    double *group_partial;           // [groups][IT_STRIDE]
+    unsigned int *counters;          // [1 + groups], zero on entry, zero again on exit
+    double *A_est;                   // 16 out
+    double *A_icp;                   // 16 in/out
+    double *res_prev_out;            // mean residual of the previous iteration (may be null)
+    int32_t *status;
+    int leaves, groups;
+};
+
+__device__ __forceinline__ double coherent_load(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void coherent_store(double *p, double v) {
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int L, bool FIRST>
+__global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
+    static_assert(256 / L == PM_TREE_LEAF, "one workgroup must be one leaf of the reduction tree");
+    __shared__ double term[PM_TREE_LEAF][IT_STRIDE];
+    __shared__ double totals[IT_STRIDE + 1];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, sub = tid & (L - 1), slot = tid / L;
+    const int n = a.n, m = a.m;
+    const int i = blockIdx.x * PM_TREE_LEAF + slot;
+    const int ic = min(i, n - 1);
+    const GridHeader hd = *a.hd;
+    double p0 = a.mov[ic], p1 = a.mov[(size_t)n + ic], p2 = a.mov[2 * (size_t)n + ic];
+    double res_prev = 0.0, S0 = INFINITY;
+    int j_prev = 0x7fffffff;
+    if (!FIRST) {
+        const double x = p0, y = p1, z = p2;
+        p0 = ((a.A_prev[0] * x + a.A_prev[1] * y) + a.A_prev[2] * z) + a.A_prev[3];
+        p1 = ((a.A_prev[4] * x + a.A_prev[5] * y) + a.A_prev[6] * z) + a.A_prev[7];
+        p2 = ((a.A_prev[8] * x + a.A_prev[9] * y) + a.A_prev[10] * z) + a.A_prev[11];
+        j_prev = a.nn_prev[ic];
+        const double d0 = p0 - a.fix[j_prev], d1 = p1 - a.fix[(size_t)m + j_prev], d2 = p2 - a.fix[2 * (size_t)m + j_prev];
+        S0 = (d0 * d0 + d1 * d1) + d2 * d2;              // == the search's (f - p) form: negation is exact
+        res_prev = __builtin_sqrt(S0);
+        if (sub == 0 && i < n) { a.mov[i] = p0; a.mov[(size_t)n + i] = p1; a.mov[2 * (size_t)n + i] = p2; }
+    }
+    GridSearch<L> q(hd, a.start, a.pts, p0, p1, p2, sub);
+    bool done = false;
+    if (!FIRST && S0 < INFINITY) {                       // (NaN fails the comparison)
+        q.bS = S0;
+        q.bI = j_prev;
+        done = q.ball(res_prev * (1.0 + 0x1p-20) + 0x1p-1000);
+    }
+    if (!done) q.rings();
+    const int j = (q.bI == 0x7fffffff) ? 0 : q.bI;
+    if (sub == 0) {
+        double s[PM_NMOMENTS];
+        if (i < n) {
+            a.nn_out[i] = j;
+            moment_terms(p0 - a.origin6[0], p1 - a.origin6[1], p2 - a.origin6[2],
+                         a.fix[j] - a.origin6[3], a.fix[(size_t)m + j] - a.origin6[4], a.fix[2 * (size_t)m + j] - a.origin6[5], s);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PM_NMOMENTS; ++k) s[k] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < PM_NMOMENTS; ++k) term[slot][k] = s[k];
+        term[slot][PM_NMOMENTS] = (i < n) ? res_prev : 0.0;
+    }
+    __syncthreads();
+    if (tid < IT_SLOTS) {
+        double acc = 0.0;
+#pragma unroll
+        for (int pnt = 0; pnt < PM_TREE_LEAF; ++pnt) acc += term[pnt][tid];
+        coherent_store(&a.leaf_partial[(size_t)blockIdx.x * IT_STRIDE + tid], acc);
+    }
+    // ---- last one out: leaves -> group -> total -> solve
+    const int g = blockIdx.x / PM_TREE_GROUP;
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const unsigned int size = (unsigned int)min(PM_TREE_GROUP, a.leaves - g * PM_TREE_GROUP);
+        s_flag = (atomicAdd(&a.counters[1 + g], 1u) == size - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_flag) return;
+    __threadfence();
+    if (tid < IT_SLOTS) {
+        const int size = min(PM_TREE_GROUP, a.leaves - g * PM_TREE_GROUP);
+        const double *lp = a.leaf_partial + (size_t)g * PM_TREE_GROUP * IT_STRIDE + tid;
+        double acc = 0.0;
+        int b = 0;
+        for (; b + 8 <= size; b += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = coherent_load(lp + (size_t)(b + u) * IT_STRIDE);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; b < size; ++b) acc += coherent_load(lp + (size_t)b * IT_STRIDE);
+        coherent_store(&a.group_partial[(size_t)g * IT_STRIDE + tid], acc);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        s_flag = (atomicAdd(&a.counters[0], 1u) == (unsigned int)a.groups - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_flag) return;
+    __threadfence();
+    if (tid < IT_SLOTS) {
+        const double *gp = a.group_partial + tid;
+        double acc = 0.0;
+        int b = 0;
+        for (; b + 8 <= a.groups; b += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = coherent_load(gp + (size_t)(b + u) * IT_STRIDE);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; b < a.groups; ++b) acc += coherent_load(gp + (size_t)b * IT_STRIDE);
+        totals[1 + tid] = acc;
+    }
+    for (int c = tid; c < 1 + a.groups; c += 256) a.counters[c] = 0u;      // everyone has passed: ready for the next launch
+    __syncthreads();
+    if (tid == 0) {
+        totals[0] = (double)n;
+        double sums[PM_ICP_NSUMS];
+        for (int k = 0; k < PM_ICP_NSUMS - 1; ++k) sums[k] = totals[k];
+        sums[PM_ICP_NSUMS - 1] = 0.0;
+        double A[16];
+        const double ratio = affine_from_sums(sums, a.origin6, A);
+        if (a.status && !(ratio > PM_DEGENERATE_MOMENTS)) a.status[0] = 1;
+        for (int k = 0; k < 16; ++k) a.A_est[k] = A[k];
+        compose_affine(A, a.A_icp);
+        if (!FIRST && a.res_prev_out) a.res_prev_out[0] = totals[1 + PM_NMOMENTS] / (double)n;
     }
 }
 
@@ -315,6 +513,32 @@ int grid_query(const double *mov, int n, int m, const void *ws, int32_t *nn, dou
     const double4 *pts = (const double4 *)(base + L.pts);
     const unsigned int blocks = (unsigned int)(((long)n * GR_LANES + 255) / 256);
     grid_nn_kernel<GR_LANES><<<blocks, 256, 0, s>>>(mov, n, hd, start, pts, nn, dist);
+    return launch_status();
+}
+
+// one fused iteration: launch geometry and workspace sizes
+int iter_leaves(int n) { return (n + PM_TREE_LEAF - 1) / PM_TREE_LEAF; }
+int iter_groups(int n) { return (iter_leaves(n) + PM_TREE_GROUP - 1) / PM_TREE_GROUP; }
+size_t iter_leaf_bytes(int n) { return (size_t)iter_leaves(n) * IT_STRIDE * sizeof(double); }
+size_t iter_group_bytes(int n) { return (size_t)iter_groups(n) * IT_STRIDE * sizeof(double); }
+size_t iter_counter_bytes(int n) { return (size_t)(1 + iter_groups(n)) * sizeof(unsigned int); }
+
+int icp_iteration(bool first, double *mov, int n, const double *fix, int m, const void *grid_ws, const int32_t *nn_prev, int32_t *nn_out,
+                  const double *origin6, double *leaf_partial, double *group_partial, unsigned int *counters, double *A_est,
+                  double *A_icp, double *res_prev_out, int32_t *status, hipStream_t s) {
+    const GridWs Lw = grid_layout(m);
+    const char *base = (const char *)grid_ws;
+    IterArgs a;
+    a.mov = mov; a.n = n;
+    a.hd = (const GridHeader *)(base + Lw.header); a.start = (const int *)(base + Lw.start); a.pts = (const double4 *)(base + Lw.pts);
+    a.fix = fix; a.m = m;
+    a.nn_prev = nn_prev; a.nn_out = nn_out;
+    a.A_prev = A_est; a.origin6 = origin6;
+    a.leaf_partial = leaf_partial; a.group_partial = group_partial; a.counters = counters;
+    a.A_est = A_est; a.A_icp = A_icp; a.res_prev_out = res_prev_out; a.status = status;
+    a.leaves = iter_leaves(n); a.groups = iter_groups(n);
+    if (first) icp_iter_kernel<GR_LANES, true><<<a.leaves, 256, 0, s>>>(a);
+    else icp_iter_kernel<GR_LANES, false><<<a.leaves, 256, 0, s>>>(a);
     return launch_status();
 }
 

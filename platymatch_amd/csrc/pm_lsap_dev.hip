@@ -53,14 +53,15 @@ __global__ __launch_bounds__(LS_THREADS) void row_select_kernel(const double *__
 //   dual feasibility          (U[i][j] - v[j]) - u[i] >= -delta          for every entry            -> summary[0] counts failures
 //   complementary slackness   |(U[i][j] - v[j]) - u[i]| <= delta         for j = col4row[i]          -> summary[2] counts failures
 // and the non-matching entries with reduced cost <= eps (the "tight" edges uniqueness is decided on): appended to
-// tight[cap][2] in arbitrary order, summary[1] = their number (may exceed cap: then the list is incomplete).
+// tight[cap][2] (with their reduced costs in tight_red[cap]) in arbitrary order, summary[1] = their number (may exceed
+// cap: then the list is incomplete).
 // stats[0] = largest |reduced cost| on a matched entry, stats[1] = largest violation (positive number), as float64 bit
 // patterns (non-negative doubles order like their bit patterns, so an integer atomic max does it).
 __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *__restrict__ U, int nc, size_t ld,
                                                                  const double *__restrict__ u, const double *__restrict__ v,
                                                                  const int32_t *__restrict__ col4row, double delta, double eps,
                                                                  int32_t *__restrict__ summary, unsigned long long *__restrict__ stats,
-                                                                 int32_t *__restrict__ tight, int cap) {
+                                                                 int32_t *__restrict__ tight, double *__restrict__ tight_red, int cap) {
     __shared__ int s_cnt[2];
     __shared__ unsigned long long s_max[2];
     const int tid = threadIdx.x, i = blockIdx.x;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *_
             worst = fmax(worst, -red);
         } else if (red <= eps) {
             const int at = atomicAdd(&summary[1], 1);
-            if (at < cap) { tight[2 * (size_t)at] = i; tight[2 * (size_t)at + 1] = j; }
+            if (at < cap) { tight[2 * (size_t)at] = i; tight[2 * (size_t)at + 1] = j; tight_red[at] = red; }
         }
     }
     if (viol) atomicAdd(&s_cnt[0], viol);
@@ -113,15 +114,16 @@ int pm_lsap_row_select(const double *U, int nr, int nc, size_t ld, const double 
 }
 
 int pm_lsap_certificate(const double *U, int nr, int nc, size_t ld, const double *u, const double *v, const int32_t *col4row,
-                        double delta, double eps, int32_t *summary4, double *stats2, int32_t *tight, int cap, void *stream) {
-    if (!U || !u || !v || !col4row || !summary4 || !stats2 || !tight || nr <= 0 || nc < nr || ld < (size_t)nc || cap <= 0 ||
+                        double delta, double eps, int32_t *summary4, double *stats2, int32_t *tight, double *tight_red, int cap,
+                        void *stream) {
+    if (!U || !u || !v || !col4row || !summary4 || !stats2 || !tight || !tight_red || nr <= 0 || nc < nr || ld < (size_t)nc || cap <= 0 ||
         !(delta >= 0.0) || !(eps >= 0.0))
         return PM_ERR_INVALID_ARG;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(summary4, 0, 4 * sizeof(int32_t), s) != hipSuccess) return pm::launch_status();
     if (hipMemsetAsync(stats2, 0, 2 * sizeof(double), s) != hipSuccess) return pm::launch_status();
     pm::certificate_kernel<<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, u, v, col4row, delta, eps, summary4, (unsigned long long *)stats2,
-                                                          tight, cap);
+                                                          tight, tight_red, cap);
     return pm::launch_status();
 }
 

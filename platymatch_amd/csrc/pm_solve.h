@@ -84,6 +84,41 @@ __device__ __forceinline__ double affine_from_centred(const double cmm[6], const
     return ratio;
 }
 
+// ---- the fixed reduction tree of the ICP moment sums ---------------------------------------------------------------------
+// Every sum over the moving points (22 moment slots + the residual) is taken in ONE order wherever it is computed — the
+// stand-alone kernels of pm_transform.hip, the fused iteration kernel of pm_icp_grid.hip, any number of ranks:
+//   leaf   = the PM_TREE_LEAF (8) consecutive points 8b .. 8b+7, added one after the other starting from 0.0;
+//   group  = the PM_TREE_GROUP (64) consecutive leaves 64g .. 64g+63 (512 points), added in leaf order;
+//   total  = the groups, added in group order.
+// Points past the end of the cloud contribute +0.0.  Same additions in the same order => same bits.
+#define PM_TREE_LEAF 8
+#define PM_TREE_GROUP 64
+#define PM_TREE_POINTS (PM_TREE_LEAF * PM_TREE_GROUP)
+#define PM_NMOMENTS 22          // slots 1..22 of the PM_ICP_NSUMS layout (slot 0 is the count)
+
+// The 22 per-point terms: a = moving - origin_m, f = matched fixed - origin_f.
+__device__ __forceinline__ void moment_terms(double a0, double a1, double a2, double f0, double f1, double f2, double s[PM_NMOMENTS]) {
+    s[0] = a0; s[1] = a1; s[2] = a2;
+    s[3] = f0; s[4] = f1; s[5] = f2;
+    s[6] = a0 * a0; s[7] = a0 * a1; s[8] = a0 * a2; s[9] = a1 * a1; s[10] = a1 * a2; s[11] = a2 * a2;
+    s[12] = f0 * a0; s[13] = f0 * a1; s[14] = f0 * a2;
+    s[15] = f1 * a0; s[16] = f1 * a1; s[17] = f1 * a2;
+    s[18] = f2 * a0; s[19] = f2 * a1; s[20] = f2 * a2;
+    s[21] = (f0 * f0 + f1 * f1) + f2 * f2;
+}
+
+// A_icp <- A_est . A_icp (perform_icp.py:25, np.matmul), all four rows.
+__device__ __forceinline__ void compose_affine(const double A[16], double *A_icp16) {
+    double C[16];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double t = 0.0;
+            for (int k = 0; k < 4; ++k) t += A[4 * r + k] * A_icp16[4 * k + c];
+            C[4 * r + c] = t;
+        }
+    for (int k = 0; k < 16; ++k) A_icp16[k] = C[k];
+}
+
 // sums: PM_ICP_NSUMS layout about origin6 = {origin_m(3), origin_f(3)} -> A (4x4 row-major).
 // Returns the conditioning ratio of solve_sym3 (compare with PM_DEGENERATE_MOMENTS).
 __device__ __forceinline__ double affine_from_sums(const double *sums, const double *origin6, double A[16]) {

@@ -13,10 +13,9 @@
 namespace pm {
 
 constexpr int TF_THREADS = 256;
-constexpr int TF_PER_THREAD = 2;
-constexpr int TF_BLOCK_PTS = TF_THREADS * TF_PER_THREAD;
-constexpr int NS = 22;   // accumulated slots (PM_ICP_NSUMS - count - pad)
-constexpr int TF_RES_RING = 64;   // iterations of the fused ICP loop whose residual partials are reduced by one launch
+constexpr int TF_BLOCK_PTS = PM_TREE_POINTS;   // one workgroup of the reduction kernels = one group of the tree (512 points)
+constexpr int TF_RED_THREADS = PM_TREE_POINTS; // ... one thread per point
+constexpr int NS = PM_NMOMENTS;                // accumulated slots (PM_ICP_NSUMS - count - pad)
 
 __global__ __launch_bounds__(TF_THREADS) void apply_affine_kernel(const double *__restrict__ A, const double *in, int n,
                                                                   double *out) {
@@ -46,69 +45,66 @@ __device__ __forceinline__ double ordered_partial_sum(const double *__restrict__
     return t;
 }
 
-// Workgroup form of the same sums: all threads fetch a chunk of partials into LDS in one round trip, then thread k adds
-// slot k's values in block order.  Result for slot k in out_s[k] (k < nslots), valid after the call's final barrier.
-// stage: TF_STAGE doubles of LDS.
-constexpr int TF_STAGE = 2816;     // 128 blocks x 22 slots
-__device__ __forceinline__ void ordered_partial_sums_block(const double *__restrict__ partial, int nblocks, int nslots,
-                                                           double *__restrict__ stage, double *__restrict__ out_s) {
-    const int per = TF_STAGE / nslots;                   // blocks per chunk
-    double t = 0.0;
-    for (int b0 = 0; b0 < nblocks; b0 += per) {
-        const int cnt = min(per, nblocks - b0) * nslots;
-        __syncthreads();
-        for (int e = threadIdx.x; e < cnt; e += blockDim.x) stage[e] = partial[(size_t)b0 * nslots + e];
-        __syncthreads();
-        if ((int)threadIdx.x < nslots)
-            for (int e = threadIdx.x; e < cnt; e += nslots) t += stage[e];
-    }
-    if ((int)threadIdx.x < nslots) out_s[threadIdx.x] = t;
-    __syncthreads();
-}
-
-// per-block partial sums, slots 1..22 of the PM_ICP_NSUMS layout (slot 0, the count, is known).
-// Fixed reduction tree: lane butterfly per wave (no barrier), then the block's waves in order.
-__global__ __launch_bounds__(TF_THREADS) void accumulate_kernel(const double *__restrict__ mov, int n,
-                                                                const double *__restrict__ fix, int m,
-                                                                const int32_t *__restrict__ nn,
-                                                                const double *__restrict__ origin6,
-                                                                double *__restrict__ partial) {
-    __shared__ double wsum[TF_THREADS / 64][NS];
-    const double om0 = origin6[0], om1 = origin6[1], om2 = origin6[2];
-    const double of0 = origin6[3], of1 = origin6[4], of2 = origin6[5];
+// Group partial sums (slots 1..22 of the PM_ICP_NSUMS layout; slot 0, the count, is known): one workgroup = one group of
+// the reduction tree (pm_solve.h), one thread per point.  Terms go to LDS, half of the slots at a time; leaves are added
+// serially (8 points), then the 64 leaves serially.
+__global__ __launch_bounds__(TF_RED_THREADS) void accumulate_kernel(const double *__restrict__ mov, int n,
+                                                                    const double *__restrict__ fix, int m,
+                                                                    const int32_t *__restrict__ nn,
+                                                                    const double *__restrict__ origin6,
+                                                                    double *__restrict__ partial) {
+    constexpr int HALF = NS / 2;
+    __shared__ double term[HALF][TF_RED_THREADS];
+    __shared__ double leaf[HALF][PM_TREE_GROUP];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * TF_BLOCK_PTS + tid;
     double s[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) s[k] = 0.0;
-    const int base = blockIdx.x * TF_BLOCK_PTS;
+    if (i < n) {
+        const int j = nn ? nn[i] : i;
+        moment_terms(mov[i] - origin6[0], mov[(size_t)n + i] - origin6[1], mov[2 * (size_t)n + i] - origin6[2],
+                     fix[j] - origin6[3], fix[(size_t)m + j] - origin6[4], fix[2 * (size_t)m + j] - origin6[5], s);
+    }
 #pragma unroll
-    for (int u = 0; u < TF_PER_THREAD; ++u) {
-        const int i = base + u * TF_THREADS + threadIdx.x;
-        if (i < n) {
-            const int j = nn ? nn[i] : i;
-            const double a0 = mov[i] - om0, a1 = mov[(size_t)n + i] - om1, a2 = mov[2 * (size_t)n + i] - om2;
-            const double f0 = fix[j] - of0, f1 = fix[(size_t)m + j] - of1, f2 = fix[2 * (size_t)m + j] - of2;
-            s[0] += a0; s[1] += a1; s[2] += a2;
-            s[3] += f0; s[4] += f1; s[5] += f2;
-            s[6] += a0 * a0; s[7] += a0 * a1; s[8] += a0 * a2; s[9] += a1 * a1; s[10] += a1 * a2; s[11] += a2 * a2;
-            s[12] += f0 * a0; s[13] += f0 * a1; s[14] += f0 * a2;
-            s[15] += f1 * a0; s[16] += f1 * a1; s[17] += f1 * a2;
-            s[18] += f2 * a0; s[19] += f2 * a1; s[20] += f2 * a2;
-            s[21] += (f0 * f0 + f1 * f1) + f2 * f2;
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < HALF; ++k) term[k][tid] = s[half * HALF + k];
+        __syncthreads();
+        for (int item = tid; item < HALF * PM_TREE_GROUP; item += TF_RED_THREADS) {
+            const int k = item / PM_TREE_GROUP, b = item % PM_TREE_GROUP;
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < PM_TREE_LEAF; ++q) acc += term[k][PM_TREE_LEAF * b + q];
+            leaf[k][b] = acc;
+        }
+        __syncthreads();
+        if (tid < HALF) {
+            double acc = 0.0;
+            for (int b = 0; b < PM_TREE_GROUP; ++b) acc += leaf[tid][b];
+            partial[(size_t)blockIdx.x * NS + half * HALF + tid] = acc;
         }
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+}
+
+// The residual's group partial by the same tree: r = this thread's point's term (0.0 past the end); valid in thread 0.
+__device__ __forceinline__ double tree_group_sum(double r, double *__restrict__ term512, double *__restrict__ leaf64) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    term512[tid] = r;
+    __syncthreads();
+    if (tid < PM_TREE_GROUP) {
+        double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) {
-        const double t = wave_sum(s[k]);
-        if (lane == 0) wsum[wave][k] = t;
+        for (int q = 0; q < PM_TREE_LEAF; ++q) acc += term512[PM_TREE_LEAF * tid + q];
+        leaf64[tid] = acc;
     }
     __syncthreads();
-    if (threadIdx.x < NS) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < TF_THREADS / 64; ++w) t += wsum[w][threadIdx.x];
-        partial[(size_t)blockIdx.x * NS + threadIdx.x] = t;
-    }
+    double acc = 0.0;
+    if (tid == 0)
+        for (int b = 0; b < PM_TREE_GROUP; ++b) acc += leaf64[b];
+    return acc;
 }
 
 // ordered sum of the block partials -> sums[22]
@@ -130,29 +126,23 @@ __global__ void solve_kernel(const double *__restrict__ sums, const double *__re
     }
 }
 
-// mov <- A_est . mov ; residual partial per block ; block 0 composes A_icp <- A_est . A_icp.
-// A_est comes from `A_given`, or is solved from `sums`, or — fused ICP loop — from the per-block partials of
-// accumulate_kernel, which every block then sums itself in the fixed order (acc_partial != nullptr).
-__global__ __launch_bounds__(TF_THREADS) void update_kernel(const double *__restrict__ sums, const double *__restrict__ acc_partial,
-                                                            const double *__restrict__ origin6,
-                                                            const double *__restrict__ A_given, double *mov, int n, const double *__restrict__ fix, int m,
-                                                            const int32_t *__restrict__ nn, double *A_icp16, double *A_est16,
-                                                            double *__restrict__ partial, int32_t *status) {
-    __shared__ double scratch[TF_THREADS / 64];
+// mov <- A_est . mov (rows 0-2 of A_est); residual partial per group of the tree; workgroup 0 composes A_icp <- A_est . A_icp.
+// A_est comes from `A_given`, or is solved from `sums` (every workgroup solves the same 24 numbers: identical A_est).
+__global__ __launch_bounds__(TF_RED_THREADS) void update_kernel(const double *__restrict__ sums, const double *__restrict__ origin6,
+                                                                const double *__restrict__ A_given, double *mov, int n,
+                                                                const double *__restrict__ fix, int m, const int32_t *__restrict__ nn,
+                                                                double *A_icp16, double *A_est16, double *__restrict__ partial,
+                                                                int32_t *status) {
     __shared__ double As[16];
-    __shared__ double sums_s[PM_ICP_NSUMS];
-    __shared__ double stage[TF_STAGE];
-    if (acc_partial) {
-        if (threadIdx.x == 0) { sums_s[0] = (double)n; sums_s[1 + NS] = 0.0; }
-        ordered_partial_sums_block(acc_partial, gridDim.x, NS, stage, sums_s + 1);
-    }
+    __shared__ double term[TF_RED_THREADS];
+    __shared__ double leaf[PM_TREE_GROUP];
     if (threadIdx.x == 0) {
         double A[16];
         double ratio = 1.0;
         if (A_given) {
             for (int k = 0; k < 16; ++k) A[k] = A_given[k];
         } else {
-            ratio = affine_from_sums(acc_partial ? sums_s : sums, origin6, A);   // identical operations in every block -> identical A_est
+            ratio = affine_from_sums(sums, origin6, A);
         }
         for (int k = 0; k < 16; ++k) As[k] = A[k];
         if (blockIdx.x == 0) {
@@ -161,43 +151,24 @@ __global__ __launch_bounds__(TF_THREADS) void update_kernel(const double *__rest
             if (status && !(ratio > PM_DEGENERATE_MOMENTS)) status[0] = 1;
             if (A_est16)
                 for (int k = 0; k < 16; ++k) A_est16[k] = A[k];
-            if (A_icp16) {                   // perform_icp.py:25, np.matmul(A_est, A_icp)
-                double C[16];
-                for (int r = 0; r < 4; ++r)
-                    for (int c = 0; c < 4; ++c) {
-                        double t = 0.0;
-                        for (int k = 0; k < 4; ++k) t += A[4 * r + k] * A_icp16[4 * k + c];
-                        C[4 * r + c] = t;
-                    }
-                for (int k = 0; k < 16; ++k) A_icp16[k] = C[k];
-            }
+            if (A_icp16) compose_affine(A, A_icp16);                      // perform_icp.py:25
         }
     }
     __syncthreads();
     double res = 0.0;
-    const int base = blockIdx.x * TF_BLOCK_PTS;
-#pragma unroll
-    for (int u = 0; u < TF_PER_THREAD; ++u) {
-        const int i = base + u * TF_THREADS + threadIdx.x;
-        if (i < n) {
-            const double x = mov[i], y = mov[(size_t)n + i], z = mov[2 * (size_t)n + i];
-            const double q0 = ((As[0] * x + As[1] * y) + As[2] * z) + As[3];
-            const double q1 = ((As[4] * x + As[5] * y) + As[6] * z) + As[7];
-            const double q2 = ((As[8] * x + As[9] * y) + As[10] * z) + As[11];
-            mov[i] = q0; mov[(size_t)n + i] = q1; mov[2 * (size_t)n + i] = q2;
-            const int j = nn ? nn[i] : i;
-            const double d0 = q0 - fix[j], d1 = q1 - fix[(size_t)m + j], d2 = q2 - fix[2 * (size_t)m + j];
-            res += __builtin_sqrt((d0 * d0 + d1 * d1) + d2 * d2);     // get_error: mean of column norms
-        }
+    const int i = blockIdx.x * TF_BLOCK_PTS + threadIdx.x;
+    if (i < n) {
+        const double x = mov[i], y = mov[(size_t)n + i], z = mov[2 * (size_t)n + i];
+        const double q0 = ((As[0] * x + As[1] * y) + As[2] * z) + As[3];
+        const double q1 = ((As[4] * x + As[5] * y) + As[6] * z) + As[7];
+        const double q2 = ((As[8] * x + As[9] * y) + As[10] * z) + As[11];
+        mov[i] = q0; mov[(size_t)n + i] = q1; mov[2 * (size_t)n + i] = q2;
+        const int j = nn ? nn[i] : i;
+        const double d0 = q0 - fix[j], d1 = q1 - fix[(size_t)m + j], d2 = q2 - fix[2 * (size_t)m + j];
+        res = __builtin_sqrt((d0 * d0 + d1 * d1) + d2 * d2);          // get_error: mean of column norms
     }
-    double t = block_sum(res, scratch);
+    const double t = tree_group_sum(res, term, leaf);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
-}
-
-// mean residuals of `count` iterations at once: workgroup r adds row r of partial[count][nblocks] in block order
-// (the additions of residual_final) -> mean_out[r].  The fused ICP loop calls it once per TF_RES_RING iterations.
-__global__ __launch_bounds__(64) void residual_flush(const double *__restrict__ partial, int nblocks, int n, double *__restrict__ mean_out) {
-    if (threadIdx.x == 0) mean_out[blockIdx.x] = ordered_partial_sum(partial + (size_t)blockIdx.x * nblocks, nblocks, 1, 0) / (double)n;
 }
 
 __global__ void residual_final(const double *__restrict__ partial, int nblocks, int n, double *__restrict__ parts2,
@@ -210,20 +181,17 @@ __global__ void residual_final(const double *__restrict__ partial, int nblocks, 
 }
 
 // get_error (utils/utils.py:77-88): mean over columns of ||a - b||
-__global__ __launch_bounds__(TF_THREADS) void error_kernel(const double *__restrict__ a, const double *__restrict__ b, int n,
-                                                           double *__restrict__ partial) {
-    __shared__ double scratch[TF_THREADS / 64];
+__global__ __launch_bounds__(TF_RED_THREADS) void error_kernel(const double *__restrict__ a, const double *__restrict__ b, int n,
+                                                               double *__restrict__ partial) {
+    __shared__ double term[TF_RED_THREADS];
+    __shared__ double leaf[PM_TREE_GROUP];
     double res = 0.0;
-    const int base = blockIdx.x * TF_BLOCK_PTS;
-#pragma unroll
-    for (int u = 0; u < TF_PER_THREAD; ++u) {
-        const int i = base + u * TF_THREADS + threadIdx.x;
-        if (i < n) {
-            const double d0 = a[i] - b[i], d1 = a[(size_t)n + i] - b[(size_t)n + i], d2 = a[2 * (size_t)n + i] - b[2 * (size_t)n + i];
-            res += __builtin_sqrt((d0 * d0 + d1 * d1) + d2 * d2);
-        }
+    const int i = blockIdx.x * TF_BLOCK_PTS + threadIdx.x;
+    if (i < n) {
+        const double d0 = a[i] - b[i], d1 = a[(size_t)n + i] - b[(size_t)n + i], d2 = a[2 * (size_t)n + i] - b[2 * (size_t)n + i];
+        res = __builtin_sqrt((d0 * d0 + d1 * d1) + d2 * d2);
     }
-    double t = block_sum(res, scratch);
+    const double t = tree_group_sum(res, term, leaf);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
@@ -233,7 +201,7 @@ int tf_blocks(int n) { return (n + TF_BLOCK_PTS - 1) / TF_BLOCK_PTS; }
 int accumulate(const double *mov, int n, const double *fix, int m, const int32_t *nn, const double *origin6,
                double *sums, double *ws, hipStream_t s) {
     const int nb = tf_blocks(n);
-    accumulate_kernel<<<nb, TF_THREADS, 0, s>>>(mov, n, fix, m, nn, origin6, ws);
+    accumulate_kernel<<<nb, TF_RED_THREADS, 0, s>>>(mov, n, fix, m, nn, origin6, ws);
     accumulate_final<<<1, 64, 0, s>>>(ws, nb, n, sums);
     return launch_status();
 }
@@ -242,30 +210,10 @@ int update(const double *sums, const double *origin6, const double *A_given, dou
            const int32_t *nn, double *A_icp16, double *A_est16, double *parts2, double *mean_out, double *ws, int32_t *status,
            hipStream_t s) {
     const int nb = tf_blocks(n);
-    update_kernel<<<nb, TF_THREADS, 0, s>>>(sums, nullptr, origin6, A_given, mov, n, fix, m, nn, A_icp16, A_est16, ws, status);
+    update_kernel<<<nb, TF_RED_THREADS, 0, s>>>(sums, origin6, A_given, mov, n, fix, m, nn, A_icp16, A_est16, ws, status);
     residual_final<<<1, 64, 0, s>>>(ws, nb, n, parts2, mean_out);
     return launch_status();
 }
-
-// One refit + apply of the fused ICP loop in two launches: per-block moment partials, then a kernel whose every block
-// adds those partials in block order, solves and applies.  Same additions in the same order as accumulate() + update(),
-// hence the same bits.  The residual partials of iteration `it` go to row it % TF_RES_RING of res_ring; the caller
-// turns the rows into mean residuals with residual_rows().  acc_ws: tf_blocks(n) * NS doubles.
-int refit_apply(double *mov, int n, const double *fix, int m, const int32_t *nn, const double *origin6, double *A_icp16,
-                double *acc_ws, double *res_ring, int it, int32_t *status, hipStream_t s) {
-    const int nb = tf_blocks(n);
-    accumulate_kernel<<<nb, TF_THREADS, 0, s>>>(mov, n, fix, m, nn, origin6, acc_ws);
-    update_kernel<<<nb, TF_THREADS, 0, s>>>(nullptr, acc_ws, origin6, nullptr, mov, n, fix, m, nn, A_icp16, nullptr,
-                                            res_ring + (size_t)(it % TF_RES_RING) * nb, status);
-    return launch_status();
-}
-
-int residual_rows(const double *res_ring, int n, int count, double *mean_out, hipStream_t s) {
-    residual_flush<<<count, 64, 0, s>>>(res_ring, tf_blocks(n), n, mean_out);
-    return launch_status();
-}
-
-size_t residual_ring_bytes(int n) { return (size_t)TF_RES_RING * tf_blocks(n) * sizeof(double); }
 
 __global__ void origin_kernel(const double *__restrict__ mov, int n, const double *__restrict__ fix, int m,
                               double *__restrict__ origin6) {
@@ -321,7 +269,7 @@ int pm_get_error(const double *a, const double *b, int n, double *out1, void *ws
     if (!a || !b || !out1 || n <= 0) return PM_ERR_INVALID_ARG;
     if (!ws || ws_bytes < pm_get_error_workspace(n)) return PM_ERR_WORKSPACE;
     const int nb = pm::tf_blocks(n);
-    pm::error_kernel<<<nb, pm::TF_THREADS, 0, (hipStream_t)stream>>>(a, b, n, (double *)ws);
+    pm::error_kernel<<<nb, pm::TF_RED_THREADS, 0, (hipStream_t)stream>>>(a, b, n, (double *)ws);
     pm::residual_final<<<1, 64, 0, (hipStream_t)stream>>>((const double *)ws, nb, n, nullptr, out1);
     return pm::launch_status();
 }

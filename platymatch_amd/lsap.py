@@ -56,7 +56,9 @@ CORE_EDGES_PER_ROW = 48          # initial core: up to this many cheap entries p
 PRICE_EDGES_PER_ROW = 8          # offenders a row may hand back per pricing round
 MAX_PRICING_ROUNDS = 200
 REL_DELTA = 1e-13                # dual feasibility / tightness tolerance, relative to the largest dual or core cost
-REL_EPS = 1e-7                   # uniqueness margin: must exceed 2 * n * delta (n <= 2.5e5 here) and SciPy's own rounding
+REL_EPS_COLLECT = 1e-8           # entries with reduced cost below this (relative) are collected by the certificate kernel
+REL_EPS_FLOOR = 1e-11            # smallest uniqueness margin accepted (relative): ~1e5 x the rounding of one float64 operation
+EPS_SAFETY = 64.0                # margin >= EPS_SAFETY * 2 n * (observed violation + observed slack on matched entries)
 DEVICE_MIN_ROWS = 1024           # below this the dense host solver is quicker than the round trips of the device scheme
 # The eight matrices hold four distinct sets of terms: U11/U22, U12/U21, U13/U24, U14/U23 differ only in
 # summation order (<= 6e-16 per entry), so one solve serves both — the twin is CERTIFIED on its own entries, not assumed.
@@ -136,7 +138,8 @@ class DeviceMatrix:
         return self.U[d, d].cpu().numpy()
 
     def certificate(self, u, v, col4row, delta, eps, cap):
-        """-> (violations, loose matched entries, tight edges [t, 2] int32 or None if more than cap, (max slack, max violation))."""
+        """-> (violations, loose matched entries, tight edges [t, 2] int32 and their reduced costs [t] — None if more than
+        cap —, (max slack on a matched entry, max violation))."""
         torch = nat.torch_mod()
         U = self.U
         nr, nc = U.shape
@@ -145,11 +148,15 @@ class DeviceMatrix:
         summary = torch.empty(4, dtype=torch.int32, device=U.device)
         stats = torch.empty(2, dtype=torch.float64, device=U.device)
         tight = torch.empty((cap, 2), dtype=torch.int32, device=U.device)
+        red = torch.empty(cap, dtype=torch.float64, device=U.device)
         nat.check(nat.load().pm_lsap_certificate(nat.ptr(U), nr, nc, self.ld, nat.ptr(u_d), nat.ptr(v_d), nat.ptr(c_d), float(delta),
-                                                 float(eps), nat.ptr(summary), nat.ptr(stats), nat.ptr(tight), cap, nat.stream_ptr(U)))
+                                                 float(eps), nat.ptr(summary), nat.ptr(stats), nat.ptr(tight), nat.ptr(red), cap,
+                                                 nat.stream_ptr(U)))
         viol, n_tight, loose, _ = summary.cpu().tolist()
         st = stats.cpu().tolist()
-        return viol, loose, (tight[:n_tight].cpu().numpy() if n_tight <= cap else None), (st[0], st[1])
+        if n_tight > cap:
+            return viol, loose, None, None, (st[0], st[1])
+        return viol, loose, tight[:n_tight].cpu().numpy(), red[:n_tight].cpu().numpy(), (st[0], st[1])
 
 
 def certify(M, u, v, col4row, info=None):
@@ -159,14 +166,25 @@ def certify(M, u, v, col4row, info=None):
     lib = nat.load()
     nr, nc = M.shape
     scale = max(float(np.abs(u).max()), float(np.abs(v).max()), 1e-300)
-    delta, eps = REL_DELTA * scale, REL_EPS * scale
+    delta, eps_collect = REL_DELTA * scale, REL_EPS_COLLECT * scale
     cap = 8 * nc + 1024
-    viol, loose, tight, (slack, worst) = M.certificate(u, v, col4row, delta, eps, cap)
+    viol, loose, tight, red, (slack, worst) = M.certificate(u, v, col4row, delta, eps_collect, cap)
+    # How wide must the margin be?  With every reduced cost >= -worst and every matched entry within slack of tight, any other
+    # assignment costs at least (optimum + the reduced costs of its new entries - 2 n (worst + slack)): if each alternative
+    # needs an entry with reduced cost > eps, eps > 2 n (worst + slack) separates them — taken EPS_SAFETY times wider, and
+    # never below REL_EPS_FLOOR (far above the rounding any exact solver, SciPy's included, accumulates).
+    if red is not None and len(red):
+        worst = max(worst, float(-red.min()))        # negative reduced costs inside the tolerance count as well
+    eps = max(REL_EPS_FLOOR * scale, EPS_SAFETY * 2.0 * max(nr, nc) * (worst + slack))
     if info is not None:
         info.update(violations=viol, loose=loose, tight=None if tight is None else len(tight), max_matched_slack=slack,
                     max_violation=worst, delta=delta, eps=eps)
-    if viol or loose or tight is None:
+    if viol or loose or tight is None or eps > eps_collect:
         return False
+    keep = red <= eps
+    tight = tight[keep]
+    if info is not None:
+        info["tight_within_eps"] = int(keep.sum())
     v_free = 0.0
     if nc > nr:
         free = np.ones(nc, dtype=bool)

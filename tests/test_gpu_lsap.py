@@ -45,8 +45,8 @@ def test_kernels_equal_their_numpy_restatement(dev, shape):
         h = H.certificate(du, dv, dc4, 1e-13 * scale, 1e-7 * scale, cap)
         assert d[0] == h[0] and d[1] == h[1]
         if h[2] is not None:
-            assert sorted(map(tuple, d[2])) == sorted(map(tuple, h[2]))
-        assert d[3] == h[3]
+            assert sorted(zip(map(tuple, d[2]), d[3])) == sorted(zip(map(tuple, h[2]), h[3]))
+        assert d[4] == h[4]
     Wn = W.copy()
     Wn[W.shape[0] // 2, 3] = np.nan
     assert L.DeviceMatrix(dev(Wn)).row_select(None, 8)[2] == 1

@@ -50,9 +50,13 @@ class HostMatrix:
         matched[np.arange(nr), col4row] = True
         viol = int((~(red >= -delta) & ~matched).sum())
         loose = int((~(np.abs(red) <= delta) & matched).sum())
-        t = np.argwhere((red <= eps) & (red >= -delta) & ~matched).astype(np.int32)
+        sel = (red <= eps) & (red >= -delta) & ~matched
+        t = np.argwhere(sel).astype(np.int32)
         slack = float(np.abs(red[matched]).max())
-        return viol, loose, (t if len(t) <= cap else None), (slack, float(max(0.0, -(red[~matched]).min())))
+        worst = float(max(0.0, -(red[~matched & ~(red >= -delta)]).min())) if viol else 0.0
+        if len(t) > cap:
+            return viol, loose, None, None, (slack, worst)
+        return viol, loose, t, red[sel], (slack, worst)
 
 
 def run(U, force_k=None):
