@@ -24,6 +24,11 @@ constexpr int GR_BATCH = 4;               // cells per lane whose ranges are fet
 #ifndef GR_INFLIGHT
 #define GR_INFLIGHT 2                     // candidate records a lane requests before it compares them
 #endif
+constexpr int GR_BALL_RUNS = 36;          // largest box (in runs of x-adjacent cells) the bounded search of the fused ICP iteration takes on
+// Lanes per moving point once the previous match bounds the search (a handful of cells): 8, or 4 for large clouds so that
+// all workgroups of a launch are resident at once (measured per iteration at 50k: 16 lanes 43.0 us, 8 -> 30.3, 4 -> 25.8;
+// at 20k 8 -> 19.5, 4 -> 20.6; at 5k 8 -> 14.4, 4 -> 15.5).
+constexpr int GR_ITER_FEW_LANES_FROM = 32768;
 constexpr int GR_LANES = 32;              // lanes per moving point (measured on the 50k blob: 4 -> 73, 8 -> 67, 16 -> 63, 32 -> 56 us per ICP iteration)
 
 struct GridHeader {          // lives at the start of the workspace, written by grid_plan_kernel
@@ -42,7 +47,7 @@ inline int grid_max_cells(int m) {
 }
 
 struct GridWs {
-    size_t header, start, cursor, pts, total;
+    size_t header, start, cursor, chunk, pts, total;
 };
 
 inline GridWs grid_layout(int m) {
@@ -51,6 +56,7 @@ inline GridWs grid_layout(int m) {
     w.header = o; o += 256;
     w.start = o; o += align_up(((size_t)grid_max_cells(m) + 1) * sizeof(int), 256);
     w.cursor = o; o += align_up(((size_t)grid_max_cells(m) + 1) * sizeof(int), 256);
+    w.chunk = o; o += align_up(((size_t)grid_max_cells(m) / 8192 + 2) * sizeof(int), 256);      // one int per scan chunk
     w.pts = o; o += align_up((size_t)m * sizeof(double4), 256);
     w.total = o;
     return w;
@@ -138,33 +144,83 @@ __global__ __launch_bounds__(256) void grid_count_kernel(const double *__restric
     atomicAdd(&count[cell_of(*hd, fix[j], fix[(size_t)m + j], fix[2 * (size_t)m + j])], 1);
 }
 
-// exclusive scan of count[0..ncells) into start[0..ncells], one workgroup; cursor <- start
-__global__ __launch_bounds__(1024) void grid_scan_kernel(const GridHeader *__restrict__ hd, int *__restrict__ start, int *__restrict__ cursor) {
+// exclusive scan of count[0..ncells) into start[0..ncells] (cursor <- start) in three small launches: chunk sums, scan of the
+// chunk sums (one workgroup), chunk-local scan plus offset.  Chunk = 1024 threads x SCAN_PER cells.
+constexpr int SCAN_PER = 8;
+constexpr int SCAN_CHUNK = 1024 * SCAN_PER;
+
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int *wsum, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int prefix = 0, all = 0;
+    for (int w = 0; w < 16; ++w) {
+        const int t = wsum[w];
+        if (w < wave) prefix += t;
+        all += t;
+    }
+    *total = all;
+    return prefix + incl - v;
+}
+
+__global__ __launch_bounds__(1024) void grid_scan_sums_kernel(const GridHeader *__restrict__ hd, const int *__restrict__ count,
+                                                              int *__restrict__ chunk_sum) {
+    __shared__ int wsum[16];
+    const int n = hd->ncells;
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_PER;
+    int t = 0;
+    if (blockIdx.x * SCAN_CHUNK < n) {
+#pragma unroll
+        for (int q = 0; q < SCAN_PER; ++q) t += (base + q < n) ? count[base + q] : 0;
+    }
+    int all;
+    block_exclusive_scan_1024(t, wsum, &all);
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = all;
+}
+
+__global__ __launch_bounds__(1024) void grid_scan_offsets_kernel(int *__restrict__ chunk_sum, int nchunks) {
     __shared__ int wsum[16];
     __shared__ int carry;
-    const int n = hd->ncells;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
+    for (int base = 0; base < nchunks; base += 1024) {
         const int i = base + threadIdx.x;
-        const int v = (i < n) ? start[i] : 0;                    // counts were accumulated in `start`
-        int incl = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
+        const int v = (i < nchunks) ? chunk_sum[i] : 0;
+        int all;
+        const int excl = block_exclusive_scan_1024(v, wsum, &all);
+        const int c = carry;
+        if (i < nchunks) chunk_sum[i] = c + excl;
         __syncthreads();
-        int prefix = carry;
-        for (int w = 0; w < wave; ++w) prefix += wsum[w];
-        const int excl = prefix + incl - v;
-        if (i < n) { start[i] = excl; cursor[i] = excl; }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = prefix + incl;
+        if (threadIdx.x == 0) carry = c + all;
         __syncthreads();
     }
-    if (threadIdx.x == 0) start[n] = carry;
+}
+
+__global__ __launch_bounds__(1024) void grid_scan_apply_kernel(const GridHeader *__restrict__ hd, const int *__restrict__ chunk_off,
+                                                               int *__restrict__ start, int *__restrict__ cursor) {
+    __shared__ int wsum[16];
+    const int n = hd->ncells;
+    if (blockIdx.x * SCAN_CHUNK > n) return;                 // (the chunk holding index n writes start[n])
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_PER;
+    int c[SCAN_PER], t = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_PER; ++q) { c[q] = (base + q < n) ? start[base + q] : 0; t += c[q]; }   // counts were accumulated in `start`
+    int all;
+    int run = chunk_off[blockIdx.x] + block_exclusive_scan_1024(t, wsum, &all);
+#pragma unroll
+    for (int q = 0; q < SCAN_PER; ++q) {
+        if (base + q <= n) {
+            start[base + q] = run;                           // index n receives the grand total
+            if (base + q < n) cursor[base + q] = run;
+        }
+        run += c[q];
+    }
 }
 
 __global__ __launch_bounds__(256) void grid_scatter_kernel(const double *__restrict__ fix, int m, const GridHeader *__restrict__ hd,
@@ -194,7 +250,7 @@ __device__ __forceinline__ bool grid_better(double aS, int aI, double bS, int bI
 // and the group's candidates are merged with the exact comparator.
 // GridSearch holds one lane's view of one query; `bS`/`bI` may be pre-loaded with a known candidate (exact: a candidate
 // offered twice changes nothing).
-template <int L>
+template <int L, bool TRACK = false>
 struct GridSearch {
     const GridHeader &hd;
     const int *__restrict__ start;
@@ -203,9 +259,13 @@ struct GridSearch {
     const int sub;
     double bS;
     int bI;
+    double bX, bY, bZ;               // TRACK: coordinates of the best candidate (what the caller would otherwise gather again)
 
     __device__ __forceinline__ GridSearch(const GridHeader &h, const int *st, const double4 *pt, double x, double y, double z, int s)
-        : hd(h), start(st), pts(pt), p0(x), p1(y), p2(z), sub(s), bS(INFINITY), bI(0x7fffffff) {}
+        : hd(h), start(st), pts(pt), p0(x), p1(y), p2(z), sub(s), bS(INFINITY), bI(0x7fffffff), bX(0.0), bY(0.0), bZ(0.0) {}
+    __device__ __forceinline__ GridSearch(const GridHeader &h, const int *st, const double4 *pt, double x, double y, double z, int s,
+                                          double S, int I, double X, double Y, double Z)
+        : hd(h), start(st), pts(pt), p0(x), p1(y), p2(z), sub(s), bS(S), bI(I), bX(X), bY(Y), bZ(Z) {}
     // bI = 0x7fffffff is "nothing yet": loses every index tie; replaced by 0 at the end if nothing ever matched
 
     // candidates q0, q0 + step, ... < q1, GR_INFLIGHT loads in flight at a time
@@ -219,7 +279,10 @@ struct GridSearch {
                 const double d0 = f[u].x - p0, d1 = f[u].y - p1, d2 = f[u].z - p2;
                 const double s = (d0 * d0 + d1 * d1) + d2 * d2;
                 const int j = (int)__double_as_longlong(f[u].w);
-                if (grid_better(s, j, bS, bI)) { bS = s; bI = j; }     // a clamped repeat of the last candidate changes nothing
+                if (grid_better(s, j, bS, bI)) {                       // a clamped repeat of the last candidate changes nothing
+                    bS = s; bI = j;
+                    if (TRACK) { bX = f[u].x; bY = f[u].y; bZ = f[u].z; }
+                }
             }
         }
     }
@@ -250,7 +313,12 @@ struct GridSearch {
         for (int off = L / 2; off > 0; off >>= 1) {
             const double oS = __shfl_xor(bS, off, 64);
             const int oI = __shfl_xor(bI, off, 64);
-            if (grid_better(oS, oI, bS, bI)) { bS = oS; bI = oI; }
+            const bool take = grid_better(oS, oI, bS, bI);
+            if (TRACK) {
+                const double oX = __shfl_xor(bX, off, 64), oY = __shfl_xor(bY, off, 64), oZ = __shfl_xor(bZ, off, 64);
+                if (take) { bX = oX; bY = oY; bZ = oZ; }
+            }
+            if (take) { bS = oS; bI = oI; }
         }
     }
 
@@ -288,7 +356,10 @@ struct GridSearch {
                     const double d0 = f.x - p0, d1 = f.y - p1, d2 = f.z - p2;
                     const double s = (d0 * d0 + d1 * d1) + d2 * d2;
                     const int j = (int)__double_as_longlong(f.w);
-                    if (grid_better(s, j, bS, bI)) { bS = s; bI = j; }
+                    if (grid_better(s, j, bS, bI)) {
+                        bS = s; bI = j;
+                        if (TRACK) { bX = f.x; bY = f.y; bZ = f.z; }
+                    }
                 }
                 merge();
                 break;
@@ -300,17 +371,18 @@ struct GridSearch {
 
     // The same answer when a candidate at squared distance bS is already known (ICP: the previous iteration's match): every
     // point that could beat or tie it lies within sqrt(bS) of the query, hence in the cells the box query +- rad covers
-    // (the point -> cell map is monotone per axis, so no slack beyond rad >= the true distance is needed).  The box is at
-    // most ny * nz <= L runs of x-adjacent cells; lanes share the runs.  Returns false (nothing scanned) if the box is larger.
+    // (the point -> cell map is monotone per axis, so no slack beyond rad >= the true distance is needed).  The box is
+    // ny * nz runs of x-adjacent cells; lanes share the runs (several lanes per run while there are fewer runs than lanes).
+    // Returns false (nothing scanned) if the box has more than GR_BALL_RUNS runs: rings() is the better plan then.
     __device__ __forceinline__ bool ball(double rad) {
         const int x0 = cell_coord(p0 - rad, hd.lo[0], hd.inv_h, hd.g[0]), x1 = cell_coord(p0 + rad, hd.lo[0], hd.inv_h, hd.g[0]);
         const int y0 = cell_coord(p1 - rad, hd.lo[1], hd.inv_h, hd.g[1]), y1 = cell_coord(p1 + rad, hd.lo[1], hd.inv_h, hd.g[1]);
         const int z0 = cell_coord(p2 - rad, hd.lo[2], hd.inv_h, hd.g[2]), z1 = cell_coord(p2 + rad, hd.lo[2], hd.inv_h, hd.g[2]);
         const int ny = y1 - y0 + 1, nruns = ny * (z1 - z0 + 1);
-        if (nruns > L || nruns < 1) return false;
-        const int per = L / nruns;                       // lanes per run
-        const int run = sub / per, part = sub - run * per;
-        if (run < nruns) {
+        if (nruns > GR_BALL_RUNS || nruns < 1) return false;
+        const int per = (nruns < L) ? L / nruns : 1;     // lanes per run
+        const int part = sub % per;
+        for (int run = sub / per; run < nruns; run += L / per) {
             const int row = ((z0 + run / ny) * hd.g[1] + (y0 + run % ny)) * hd.g[0];
             scan(start[row + x0] + part, start[row + x1 + 1], per);
         }
@@ -342,7 +414,7 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__
 //   the 22 moment terms of (point, match) (:18's least squares as normal equations) and the residual term -> leaf partial.
 // The workgroup that completes a group of 64 leaves adds them in leaf order; the one that completes the last group adds the
 // groups in order, solves the 4 x 4 (A_est for the next launch), composes A_icp (:25) and writes the mean residual — the
-// "last one out" pattern: a counter per group, no workgroup ever waits for another.
+// "last one out" pattern: a counter per group, no workgroup ever waits for another (nothing can hang).
 constexpr int IT_SLOTS = PM_NMOMENTS + 1;          // 22 moments + residual
 constexpr int IT_STRIDE = 24;
 
@@ -372,44 +444,46 @@ __device__ __forceinline__ void coherent_store(double *p, double v) {
 
 template <int L, bool FIRST>
 __global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
-    static_assert(256 / L == PM_TREE_LEAF, "one workgroup must be one leaf of the reduction tree");
-    __shared__ double term[PM_TREE_LEAF][IT_STRIDE];
+    constexpr int PTS = 256 / L;                        // moving points per workgroup
+    constexpr int LPB = PTS / PM_TREE_LEAF;             // leaves of the reduction tree per workgroup
+    static_assert(PTS % PM_TREE_LEAF == 0 && LPB >= 1 && PM_TREE_GROUP % LPB == 0, "a workgroup must hold whole leaves of one group");
+    __shared__ double term[PTS][IT_STRIDE];
     __shared__ double totals[IT_STRIDE + 1];
     __shared__ int s_flag;
     const int tid = threadIdx.x, sub = tid & (L - 1), slot = tid / L;
     const int n = a.n, m = a.m;
-    const int i = blockIdx.x * PM_TREE_LEAF + slot;
+    const int i = blockIdx.x * PTS + slot;
     const int ic = min(i, n - 1);
     const GridHeader hd = *a.hd;
     double p0 = a.mov[ic], p1 = a.mov[(size_t)n + ic], p2 = a.mov[2 * (size_t)n + ic];
     double res_prev = 0.0, S0 = INFINITY;
-    int j_prev = 0x7fffffff;
+    double iS = INFINITY, iX = 0.0, iY = 0.0, iZ = 0.0;         // the candidate the search starts from: the previous match
+    int iI = 0x7fffffff;
     if (!FIRST) {
         const double x = p0, y = p1, z = p2;
         p0 = ((a.A_prev[0] * x + a.A_prev[1] * y) + a.A_prev[2] * z) + a.A_prev[3];
         p1 = ((a.A_prev[4] * x + a.A_prev[5] * y) + a.A_prev[6] * z) + a.A_prev[7];
         p2 = ((a.A_prev[8] * x + a.A_prev[9] * y) + a.A_prev[10] * z) + a.A_prev[11];
-        j_prev = a.nn_prev[ic];
-        const double d0 = p0 - a.fix[j_prev], d1 = p1 - a.fix[(size_t)m + j_prev], d2 = p2 - a.fix[2 * (size_t)m + j_prev];
+        const int j_prev = a.nn_prev[ic];
+        const double f0 = a.fix[j_prev], f1 = a.fix[(size_t)m + j_prev], f2 = a.fix[2 * (size_t)m + j_prev];
+        const double d0 = p0 - f0, d1 = p1 - f1, d2 = p2 - f2;
         S0 = (d0 * d0 + d1 * d1) + d2 * d2;              // == the search's (f - p) form: negation is exact
         res_prev = __builtin_sqrt(S0);
         if (sub == 0 && i < n) { a.mov[i] = p0; a.mov[(size_t)n + i] = p1; a.mov[2 * (size_t)n + i] = p2; }
+        if (S0 < INFINITY) { iS = S0; iI = j_prev; iX = f0; iY = f1; iZ = f2; }     // (NaN fails the comparison)
     }
-    GridSearch<L> q(hd, a.start, a.pts, p0, p1, p2, sub);
+    GridSearch<L, true> q(hd, a.start, a.pts, p0, p1, p2, sub, iS, iI, iX, iY, iZ);
     bool done = false;
-    if (!FIRST && S0 < INFINITY) {                       // (NaN fails the comparison)
-        q.bS = S0;
-        q.bI = j_prev;
-        done = q.ball(res_prev * (1.0 + 0x1p-20) + 0x1p-1000);
-    }
+    if (!FIRST && S0 < INFINITY) done = q.ball(res_prev * (1.0 + 0x1p-20) + 0x1p-1000);
     if (!done) q.rings();
-    const int j = (q.bI == 0x7fffffff) ? 0 : q.bI;
     if (sub == 0) {
         double s[PM_NMOMENTS];
         if (i < n) {
+            const bool none = q.bI == 0x7fffffff;        // all-NaN row: np.argmin answers 0
+            const int j = none ? 0 : q.bI;
             a.nn_out[i] = j;
-            moment_terms(p0 - a.origin6[0], p1 - a.origin6[1], p2 - a.origin6[2],
-                         a.fix[j] - a.origin6[3], a.fix[(size_t)m + j] - a.origin6[4], a.fix[2 * (size_t)m + j] - a.origin6[5], s);
+            const double f0 = none ? a.fix[0] : q.bX, f1 = none ? a.fix[(size_t)m] : q.bY, f2 = none ? a.fix[2 * (size_t)m] : q.bZ;
+            moment_terms(p0 - a.origin6[0], p1 - a.origin6[1], p2 - a.origin6[2], f0 - a.origin6[3], f1 - a.origin6[4], f2 - a.origin6[5], s);
         } else {
 #pragma unroll
             for (int k = 0; k < PM_NMOMENTS; ++k) s[k] = 0.0;
@@ -419,23 +493,29 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
         term[slot][PM_NMOMENTS] = (i < n) ? res_prev : 0.0;
     }
     __syncthreads();
-    if (tid < IT_SLOTS) {
-        double acc = 0.0;
+    // Hand-off discipline (MI355X_MICROARCH.md, "Valid forms": write-through stores, drained, one lane signals behind the
+    // workgroup barrier; the workgroup whose add came last reads with L1-bypassing loads — no fence, no waiting):
+    const int leaf0 = blockIdx.x * LPB;
+    const int mine = min(LPB, a.leaves - leaf0);        // leaves of this workgroup that exist
+    if (tid < LPB * IT_SLOTS) {
+        const int lf = tid / IT_SLOTS, k = tid - lf * IT_SLOTS;
+        if (lf < mine) {
+            double acc = 0.0;
 #pragma unroll
-        for (int pnt = 0; pnt < PM_TREE_LEAF; ++pnt) acc += term[pnt][tid];
-        coherent_store(&a.leaf_partial[(size_t)blockIdx.x * IT_STRIDE + tid], acc);
+            for (int pnt = 0; pnt < PM_TREE_LEAF; ++pnt) acc += term[lf * PM_TREE_LEAF + pnt][k];
+            coherent_store(&a.leaf_partial[(size_t)(leaf0 + lf) * IT_STRIDE + k], acc);
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- last one out: leaves -> group -> total -> solve
-    const int g = blockIdx.x / PM_TREE_GROUP;
+    const int g = leaf0 / PM_TREE_GROUP;
     __syncthreads();
     if (tid == 0) {
-        __threadfence();
         const unsigned int size = (unsigned int)min(PM_TREE_GROUP, a.leaves - g * PM_TREE_GROUP);
-        s_flag = (atomicAdd(&a.counters[1 + g], 1u) == size - 1u) ? 1 : 0;
+        s_flag = (atomicAdd(&a.counters[1 + g], (unsigned int)mine) + (unsigned int)mine == size) ? 1 : 0;
     }
     __syncthreads();
     if (!s_flag) return;
-    __threadfence();
     if (tid < IT_SLOTS) {
         const int size = min(PM_TREE_GROUP, a.leaves - g * PM_TREE_GROUP);
         const double *lp = a.leaf_partial + (size_t)g * PM_TREE_GROUP * IT_STRIDE + tid;
@@ -451,14 +531,11 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
         for (; b < size; ++b) acc += coherent_load(lp + (size_t)b * IT_STRIDE);
         coherent_store(&a.group_partial[(size_t)g * IT_STRIDE + tid], acc);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        s_flag = (atomicAdd(&a.counters[0], 1u) == (unsigned int)a.groups - 1u) ? 1 : 0;
-    }
+    if (tid == 0) s_flag = (atomicAdd(&a.counters[0], 1u) == (unsigned int)a.groups - 1u) ? 1 : 0;
     __syncthreads();
     if (!s_flag) return;
-    __threadfence();
     if (tid < IT_SLOTS) {
         const double *gp = a.group_partial + tid;
         double acc = 0.0;
@@ -473,7 +550,8 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
         for (; b < a.groups; ++b) acc += coherent_load(gp + (size_t)b * IT_STRIDE);
         totals[1 + tid] = acc;
     }
-    for (int c = tid; c < 1 + a.groups; c += 256) a.counters[c] = 0u;      // everyone has passed: ready for the next launch
+    for (int c = tid; c < 1 + a.groups; c += 256)                            // everyone has passed: ready for the next launch
+        __hip_atomic_store(&a.counters[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (tid == 0) {
         totals[0] = (double)n;
@@ -500,7 +578,11 @@ int grid_build(const double *fix, int m, void *ws, hipStream_t s) {
     if (hipMemsetAsync(start, 0, ((size_t)max_cells + 1) * sizeof(int), s) != hipSuccess) return launch_status();
     grid_plan_kernel<<<1, 1024, 0, s>>>(fix, m, max_cells, hd);
     grid_count_kernel<<<(m + 255) / 256, 256, 0, s>>>(fix, m, hd, start);
-    grid_scan_kernel<<<1, 1024, 0, s>>>(hd, start, cursor);
+    const int nchunks = max_cells / SCAN_CHUNK + 1;                          // covers index ncells <= max_cells too
+    int *chunk = (int *)(base + L.chunk);
+    grid_scan_sums_kernel<<<nchunks, 1024, 0, s>>>(hd, start, chunk);
+    grid_scan_offsets_kernel<<<1, 1024, 0, s>>>(chunk, nchunks);
+    grid_scan_apply_kernel<<<nchunks, 1024, 0, s>>>(hd, chunk, start, cursor);
     grid_scatter_kernel<<<(m + 255) / 256, 256, 0, s>>>(fix, m, hd, cursor, (double4 *)(base + L.pts));
     return launch_status();
 }
@@ -537,8 +619,11 @@ int icp_iteration(bool first, double *mov, int n, const double *fix, int m, cons
     a.leaf_partial = leaf_partial; a.group_partial = group_partial; a.counters = counters;
     a.A_est = A_est; a.A_icp = A_icp; a.res_prev_out = res_prev_out; a.status = status;
     a.leaves = iter_leaves(n); a.groups = iter_groups(n);
-    if (first) icp_iter_kernel<GR_LANES, true><<<a.leaves, 256, 0, s>>>(a);
-    else icp_iter_kernel<GR_LANES, false><<<a.leaves, 256, 0, s>>>(a);
+    // first iteration: nothing bounds the search, 32 lanes per point walk the rings; afterwards the previous match does
+    // and 8 or 4 lanes per point (4 or 8 leaves per workgroup) are plenty for the few cells left
+    if (first) icp_iter_kernel<GR_LANES, true><<<(n + 256 / GR_LANES - 1) / (256 / GR_LANES), 256, 0, s>>>(a);
+    else if (n >= GR_ITER_FEW_LANES_FROM) icp_iter_kernel<4, false><<<(n + 63) / 64, 256, 0, s>>>(a);
+    else icp_iter_kernel<8, false><<<(n + 31) / 32, 256, 0, s>>>(a);
     return launch_status();
 }
 
