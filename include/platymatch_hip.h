@@ -180,6 +180,10 @@ int pm_lsap_solve(const double *cost, long nr, long nc, int64_t *rows, int64_t *
 int pm_lsap_row_select(const double *U, int nr, int nc, size_t ld, const double *v, int k, int32_t *out_col,
                        double *out_cost, int32_t *nonfinite1, void *stream);
 
+/* DEVICE: column minima v[j] = min_i U[i][j] — the column reduction a square solve starts its duals from. */
+size_t pm_lsap_col_min_workspace(int nr, int nc);
+int pm_lsap_col_min(const double *U, int nr, int nc, size_t ld, double *v, void *ws, size_t ws_bytes, void *stream);
+
 /* DEVICE: certificate of (u[nr], v[nc], col4row[nr]) against every entry of U.  summary4 = { entries with reduced cost
  * (U[i][j] - v[j]) - u[i] < -delta; non-matching entries with reduced cost <= eps, appended to tight[cap][2] as (row, col)
  * with their reduced costs in tight_red[cap] — if the count exceeds cap the list is incomplete; matched entries with
@@ -196,6 +200,10 @@ int pm_lsap_certificate(const double *U, int nr, int nc, size_t ld, const double
  * *n_violated = number of such rows (0 = the core optimum is dual feasible on the dense matrix).  get: duals and
  * assignment of the real rows; stats4 = { edges, Dijkstra steps, augmentations, dummy-row scans }. */
 void *pm_lsap_core_create(int nr, int nc);
+/* Start from given duals instead of zeros (call before any solve): v[nc] any values with, for every core edge added so far
+ * or later, cost - v[col] >= u[row]; u[nr] = each row's minimum of cost - v[col] over the DENSE row (pm_lsap_row_select's
+ * rank-0 entry).  Rows whose minimising column is still free are matched to it at once (a tight edge).  nr == nc only. */
+int pm_lsap_core_init_duals(void *core, const double *u, const double *v, const int32_t *argmin_col);
 void pm_lsap_core_destroy(void *core);
 int pm_lsap_core_add(void *core, int k, const int32_t *cols, const double *costs);
 int pm_lsap_core_solve(void *core);

@@ -59,6 +59,36 @@ struct MT {
 
 constexpr int CHUNK = 64;
 
+// The first k entries of the shuffled arange(n), given every swap partner j[i] (i = 1 .. n-1; j[i] <= i) of the
+// Fisher-Yates pass `for i = n-1 .. 1: swap(a[i], a[j[i]])` — WITHOUT performing the swaps.  Follow position q backwards
+// through the swaps (last swap first, i.e. i ascending): the element that ends at q sat, before swap i = q, at j[q]; from
+// then on only a later swap whose partner IS the tracked position moves it (to that swap's i).  So: pos = j[q], then one
+// ascending scan of j[q+1 ..] for entries equal to pos (about ln(n/q) hits), each hit setting pos = i.  The element is `pos`
+// itself (the array starts as arange).  k scans run together; the compare loop vectorises.
+__attribute__((target_clones("avx512f", "avx2", "default"))) void first_entries(const int32_t *__restrict j, long n, int k,
+                                                                                 int32_t *__restrict out) {
+    for (int q = 0; q < k; ++q) {
+        int32_t pos = (q >= 1) ? j[q] : 0;
+        long i = q + 1;
+        while (i < n) {
+            // skip ahead in blocks while no entry equals pos
+            long stop = i;
+            for (; stop + 64 <= n; stop += 64) {
+                int hit = 0;
+                for (int u = 0; u < 64; ++u) hit |= (j[stop + u] == pos);
+                if (hit) break;
+            }
+            long e = stop + 64 < n ? stop + 64 : n;
+            long h = stop;
+            for (; h < e; ++h)
+                if (j[h] == pos) break;
+            if (h < e) { pos = (int32_t)h; i = h + 1; }
+            else i = e;
+        }
+        out[q] = pos;
+    }
+}
+
 }  // namespace
 
 // key[624], *pos: the MT19937 part of np.random.get_state() (updated in place).  out: trials x k int32, the first k
@@ -70,44 +100,34 @@ extern "C" int pm_legacy_choice(uint32_t *key, int *pos, long n, int k, long tri
     mt.key = key;
     mt.pos = *pos;
     mt.temper();                                        // outputs pos..623 of the block the caller's state is in
-    std::vector<int32_t> perm((size_t)n);
-    int32_t *__restrict a = perm.data();
-    const uint32_t *__restrict rnd = mt.out;           // locals the compiler can keep apart from the stores into a[]
+    std::vector<int32_t> partner((size_t)n + CHUNK);
+    int32_t *__restrict jv = partner.data();
+    const uint32_t *__restrict rnd = mt.out;           // locals the compiler can keep apart from the stores into jv[]
     int p = mt.pos;
     for (long t = 0; t < trials; ++t) {
-        for (long i = 0; i < n; ++i) a[i] = (int32_t)i;
-        // Fisher-Yates from the top, in runs of i that share one rejection mask (2^b - 1 for i in [2^(b-1), 2^b)).
-        // Two passes per chunk of generator outputs: (1) rejection only -- a draw is accepted if it is <= the current i,
-        // which then drops by one; accepted values are compacted without a data-dependent branch; (2) the swaps for the
-        // accepted values, in order.  Separating them keeps the ~30 % rejections out of the load/store stream.
+        // Fisher-Yates from the top, in runs of i that share one rejection mask (2^b - 1 for i in [2^(b-1), 2^b)): a draw
+        // is accepted if it is <= the current i, which then drops by one.  Accepted values are stored at jv[i] without a
+        // data-dependent branch (a rejected draw is overwritten by the next one); no array is permuted.
+        jv[0] = 0;
         long i = n - 1;
-        uint32_t js[CHUNK];
         while (i >= 1) {
             const uint32_t mask = 0xffffffffu >> __builtin_clz((uint32_t)i);   // smallest all-ones mask >= i
             const long lo = (long)(mask >> 1) + 1;                             // last i that uses this mask
             while (i >= lo) {
-                int cnt = 0;
-                long ii = i;
-                for (int q = 0; q < CHUNK && ii >= lo; ++q) {
-                    if (p == 624) {
-                        mt.refill();
-                        p = 0;
-                    }
-                    const uint32_t v = rnd[p++] & mask;
-                    const bool take = v <= (uint32_t)ii;
-                    js[cnt] = v;
-                    cnt += take;
-                    ii -= take;
+                if (p == 624) {
+                    mt.refill();
+                    p = 0;
                 }
-                for (int q = 0; q < cnt; ++q, --i) {
-                    const uint32_t j = js[q];
-                    const int32_t ai = a[i];
-                    a[i] = a[j];
-                    a[j] = ai;
+                // as many draws as this generator block and this mask run allow, at most
+                long room = 624 - p;
+                for (long q = 0; q < room && i >= lo; ++q) {
+                    const uint32_t v = rnd[p++] & mask;
+                    jv[i] = (int32_t)v;
+                    i -= (v <= (uint32_t)i);
                 }
             }
         }
-        for (int q = 0; q < k; ++q) out[t * k + q] = a[q];
+        first_entries(jv, n, k, out + t * k);
     }
     mt.pos = p;
     *pos = mt.pos;

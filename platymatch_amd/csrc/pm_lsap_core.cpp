@@ -39,18 +39,23 @@ struct Edge {
 struct Core {
     int nr, nc;                                   // real rows <= columns; rows nr..nc-1 are implicit dummy rows (cost 0 to every column)
     std::vector<std::vector<Edge>> adj;           // real rows only
-    std::vector<double> u, v;                     // duals: u[nc] (real + dummy rows), v[nc]
+    struct Col {                                  // everything a relaxation touches about a column, on one cache line
+        double v;                                 // dual
+        double dist;                              // tentative distance of the current augmentation (valid if seen == stamp)
+        int32_t seen, done;                       // stamps: reached / scanned in the current augmentation
+    };
+    std::vector<Col> col;                         // [nc]
+    std::vector<double> u;                        // row duals [nc] (real + dummy rows)
     std::vector<int32_t> col4row, row4col;        // [nc] each, -1 = free
     std::vector<int32_t> free_rows;               // rows waiting for an augmentation
     // Dijkstra scratch, reset lazily through `stamp`
-    std::vector<double> dist;
-    std::vector<int32_t> pred, seen_at, done_at;
+    std::vector<int32_t> pred;
     std::vector<int32_t> touched_rows, done_cols;
     int32_t stamp = 0;
     long edges = 0, steps = 0, dummy_scans = 0, augmentations = 0;
 
-    Core(int nr_, int nc_) : nr(nr_), nc(nc_), adj(nr_), u(nc_, 0.0), v(nc_, 0.0), col4row(nc_, -1), row4col(nc_, -1),
-                             dist(nc_), pred(nc_), seen_at(nc_, 0), done_at(nc_, 0) {
+    Core(int nr_, int nc_) : nr(nr_), nc(nc_), adj(nr_), col(nc_, Col{0.0, 0.0, 0, 0}), u(nc_, 0.0), col4row(nc_, -1), row4col(nc_, -1),
+                             pred(nc_) {
         free_rows.reserve(nc_);
         for (int i = 0; i < nc_; ++i) free_rows.push_back(i);
     }
@@ -74,8 +79,7 @@ struct Core {
         using Item = std::pair<double, int32_t>;
         std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
         if (++stamp == std::numeric_limits<int32_t>::max()) {
-            std::fill(seen_at.begin(), seen_at.end(), 0);
-            std::fill(done_at.begin(), done_at.end(), 0);
+            for (Col &c : col) c.seen = c.done = 0;
             stamp = 1;
         }
         touched_rows.clear();
@@ -88,11 +92,12 @@ struct Core {
             if (i < nr) {
                 for (const Edge &e : adj[i]) {
                     const int j = e.col;
-                    if (done_at[j] == stamp) continue;
-                    const double d = (base + e.cost) - v[j];
-                    if (seen_at[j] != stamp || d < dist[j]) {
-                        seen_at[j] = stamp;
-                        dist[j] = d;
+                    Col &c = col[j];
+                    if (c.done == stamp) continue;
+                    const double d = (base + e.cost) - c.v;
+                    if (c.seen != stamp || d < c.dist) {
+                        c.seen = stamp;
+                        c.dist = d;
                         pred[j] = i;
                         heap.push({d, j});
                     }
@@ -100,11 +105,12 @@ struct Core {
             } else {                                  // dummy row: zero cost to every column
                 ++dummy_scans;
                 for (int j = 0; j < nc; ++j) {
-                    if (done_at[j] == stamp) continue;
-                    const double d = base - v[j];
-                    if (seen_at[j] != stamp || d < dist[j]) {
-                        seen_at[j] = stamp;
-                        dist[j] = d;
+                    Col &c = col[j];
+                    if (c.done == stamp) continue;
+                    const double d = base - c.v;
+                    if (c.seen != stamp || d < c.dist) {
+                        c.seen = stamp;
+                        c.dist = d;
                         pred[j] = i;
                         heap.push({d, j});
                     }
@@ -114,11 +120,11 @@ struct Core {
             while (!heap.empty()) {
                 const Item top = heap.top();
                 heap.pop();
-                if (done_at[top.second] != stamp && top.first == dist[top.second]) { j = top.second; min_val = top.first; break; }
+                if (col[top.second].done != stamp && top.first == col[top.second].dist) { j = top.second; min_val = top.first; break; }
             }
             if (j < 0) return false;
             ++steps;
-            done_at[j] = stamp;
+            col[j].done = stamp;
             done_cols.push_back(j);
             if (row4col[j] < 0) sink = j;
             else i = row4col[j];
@@ -126,8 +132,8 @@ struct Core {
         // dual update (the same as SciPy's: scanned rows rise, scanned columns fall, matched edges stay tight)
         u[cur] += min_val;
         for (int r : touched_rows)
-            if (r != cur) u[r] += min_val - dist[col4row[r]];
-        for (int j : done_cols) v[j] -= min_val - dist[j];
+            if (r != cur) u[r] += min_val - col[col4row[r]].dist;
+        for (int j : done_cols) col[j].v -= min_val - col[j].dist;
         // flip the path
         int j = sink;
         while (true) {
@@ -154,7 +160,7 @@ struct Core {
             if (r >= nr) {
                 if (!clean_ready) {
                     for (int j = 0; j < nc; ++j)
-                        if (row4col[j] < 0 && v[j] == 0.0) clean.push_back(j);
+                        if (row4col[j] < 0 && col[j].v == 0.0) clean.push_back(j);
                     clean_ready = true;
                 }
                 // valid only while the dummy's own dual is the untouched 0 and no column has v > 0 (v never rises)
@@ -184,7 +190,7 @@ struct Core {
             for (int t = 0; t < k; ++t) {
                 const int j = cand_col[(size_t)i * k + t];
                 if (j < 0) continue;
-                const double red = cand_cost[(size_t)i * k + t] - v[j];
+                const double red = cand_cost[(size_t)i * k + t] - col[j].v;
                 if (red < best) best = red;
             }
             if (!(best - u[i] < -delta)) continue;
@@ -192,7 +198,7 @@ struct Core {
             for (int t = 0; t < k; ++t) {
                 const int j = cand_col[(size_t)i * k + t];
                 if (j < 0) continue;
-                if ((cand_cost[(size_t)i * k + t] - v[j]) - u[i] < -delta) add_edge(i, j, cand_cost[(size_t)i * k + t]);
+                if ((cand_cost[(size_t)i * k + t] - col[j].v) - u[i] < -delta) add_edge(i, j, cand_cost[(size_t)i * k + t]);
             }
             u[i] = best;
             const int j = col4row[i];
@@ -230,6 +236,21 @@ int pm_lsap_core_add(void *h, int k, const int32_t *cols, const double *costs) {
     return PM_OK;
 }
 
+int pm_lsap_core_init_duals(void *h, const double *u, const double *v, const int32_t *argmin_col) {
+    Core *c = static_cast<Core *>(h);
+    if (!c || !u || !v || !argmin_col || c->nr != c->nc || c->augmentations != 0) return PM_ERR_INVALID_ARG;
+    for (int j = 0; j < c->nc; ++j) c->col[j].v = v[j];
+    for (int i = 0; i < c->nr; ++i) {
+        c->u[i] = u[i];
+        const int j = argmin_col[i];
+        if (j >= 0 && j < c->nc && c->row4col[j] < 0 && c->has_edge(i, j)) {      // tight by construction: u[i] = cost - v[j]
+            c->row4col[j] = i;
+            c->col4row[i] = j;
+        }
+    }
+    return PM_OK;
+}
+
 int pm_lsap_core_solve(void *h) {
     Core *c = static_cast<Core *>(h);
     if (!c) return PM_ERR_INVALID_ARG;
@@ -255,7 +276,7 @@ int pm_lsap_core_get(void *h, double *u, double *v, int32_t *col4row, long *stat
     Core *c = static_cast<Core *>(h);
     if (!c || !u || !v || !col4row) return PM_ERR_INVALID_ARG;
     std::memcpy(u, c->u.data(), sizeof(double) * c->nr);
-    std::memcpy(v, c->v.data(), sizeof(double) * c->nc);
+    for (int j = 0; j < c->nc; ++j) v[j] = c->col[j].v;
     std::memcpy(col4row, c->col4row.data(), sizeof(int32_t) * c->nr);
     if (stats4) { stats4[0] = c->edges; stats4[1] = c->steps; stats4[2] = c->augmentations; stats4[3] = c->dummy_scans; }
     return PM_OK;

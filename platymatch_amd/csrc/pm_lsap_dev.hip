@@ -49,6 +49,35 @@ __global__ __launch_bounds__(LS_THREADS) void row_select_kernel(const double *__
     if (bad) nonfinite[0] = 1;
 }
 
+// Column minima v[j] = min_i U[i][j] (the column reduction that starts a square solve from good duals): thread <-> column,
+// rows streamed in slabs so that the launch has enough workgroups; slab minima combined by a second tiny kernel.
+constexpr int CM_ROWS = 256;          // rows per slab
+
+__global__ __launch_bounds__(LS_THREADS) void col_min_slab_kernel(const double *__restrict__ U, int nr, int nc, size_t ld,
+                                                                  double *__restrict__ slab_min) {
+    const int j = blockIdx.x * LS_THREADS + threadIdx.x;
+    if (j >= nc) return;
+    const int r0 = blockIdx.y * CM_ROWS, r1 = min(nr, r0 + CM_ROWS);
+    double best = INFINITY;
+    for (int i = r0; i < r1; ++i) {
+        const double c = U[(size_t)i * ld + j];
+        best = c < best ? c : best;
+    }
+    slab_min[(size_t)blockIdx.y * nc + j] = best;
+}
+
+__global__ __launch_bounds__(LS_THREADS) void col_min_final_kernel(const double *__restrict__ slab_min, int slabs, int nc,
+                                                                   double *__restrict__ v) {
+    const int j = blockIdx.x * LS_THREADS + threadIdx.x;
+    if (j >= nc) return;
+    double best = INFINITY;
+    for (int s = 0; s < slabs; ++s) {
+        const double c = slab_min[(size_t)s * nc + j];
+        best = c < best ? c : best;
+    }
+    v[j] = best;
+}
+
 // Optimality certificate of (u, v, col4row) for the nr x nc matrix U — the conditions of LP duality, entry by entry:
 //   dual feasibility          (U[i][j] - v[j]) - u[i] >= -delta          for every entry            -> summary[0] counts failures
 //   complementary slackness   |(U[i][j] - v[j]) - u[i]| <= delta         for j = col4row[i]          -> summary[2] counts failures
@@ -110,6 +139,20 @@ int pm_lsap_row_select(const double *U, int nr, int nc, size_t ld, const double 
     if (hipMemsetAsync(nonfinite1, 0, sizeof(int32_t), s) != hipSuccess) return pm::launch_status();
     if (v) pm::row_select_kernel<true><<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, v, k, out_col, out_cost, nonfinite1);
     else pm::row_select_kernel<false><<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, nullptr, k, out_col, out_cost, nonfinite1);
+    return pm::launch_status();
+}
+
+size_t pm_lsap_col_min_workspace(int nr, int nc) {
+    return (nr > 0 && nc > 0) ? (size_t)((nr + pm::CM_ROWS - 1) / pm::CM_ROWS) * nc * sizeof(double) : 0;
+}
+
+int pm_lsap_col_min(const double *U, int nr, int nc, size_t ld, double *v, void *ws, size_t ws_bytes, void *stream) {
+    if (!U || !v || nr <= 0 || nc <= 0 || ld < (size_t)nc) return PM_ERR_INVALID_ARG;
+    if (!ws || ws_bytes < pm_lsap_col_min_workspace(nr, nc)) return PM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int slabs = (nr + pm::CM_ROWS - 1) / pm::CM_ROWS, cb = (nc + pm::LS_THREADS - 1) / pm::LS_THREADS;
+    pm::col_min_slab_kernel<<<dim3(cb, slabs), pm::LS_THREADS, 0, s>>>(U, nr, nc, ld, (double *)ws);
+    pm::col_min_final_kernel<<<cb, pm::LS_THREADS, 0, s>>>((const double *)ws, slabs, nc, v);
     return pm::launch_status();
 }
 

@@ -59,6 +59,7 @@ REL_DELTA = 1e-13                # dual feasibility / tightness tolerance, relat
 REL_EPS_COLLECT = 1e-8           # entries with reduced cost below this (relative) are collected by the certificate kernel
 REL_EPS_FLOOR = 1e-11            # smallest uniqueness margin accepted (relative): ~1e5 x the rounding of one float64 operation
 EPS_SAFETY = 64.0                # margin >= EPS_SAFETY * 2 n * (observed violation + observed slack on matched entries)
+COLUMN_REDUCTION = True          # start square solves from the column reduction
 DEVICE_MIN_ROWS = 1024           # below this the dense host solver is quicker than the round trips of the device scheme
 # The eight matrices hold four distinct sets of terms: U11/U22, U12/U21, U13/U24, U14/U23 differ only in
 # summation order (<= 6e-16 per entry), so one solve serves both — the twin is CERTIFIED on its own entries, not assumed.
@@ -88,6 +89,11 @@ class _Core:
         cols = np.ascontiguousarray(cols, dtype=np.int32)
         costs = np.ascontiguousarray(costs, dtype=np.float64)
         nat.check(self.lib.pm_lsap_core_add(self.h, cols.shape[1], cols.ctypes.data, costs.ctypes.data))
+
+    def init_duals(self, u, v, argmin_col):
+        u, v = np.ascontiguousarray(u, dtype=np.float64), np.ascontiguousarray(v, dtype=np.float64)
+        a = np.ascontiguousarray(argmin_col, dtype=np.int32)
+        nat.check(self.lib.pm_lsap_core_init_duals(self.h, u.ctypes.data, v.ctypes.data, a.ctypes.data))
 
     def solve(self):
         rc = self.lib.pm_lsap_core_solve(self.h)
@@ -136,6 +142,17 @@ class DeviceMatrix:
         torch = nat.torch_mod()
         d = torch.arange(n, device=self.U.device)
         return self.U[d, d].cpu().numpy()
+
+    def col_min(self):
+        """-> v [nc] on the host: pm_lsap_col_min."""
+        torch = nat.torch_mod()
+        U = self.U
+        nr, nc = U.shape
+        lib = nat.load()
+        ws = nat.workspace(lib.pm_lsap_col_min_workspace(nr, nc), U.device)
+        v = torch.empty(nc, dtype=torch.float64, device=U.device)
+        nat.check(lib.pm_lsap_col_min(nat.ptr(U), nr, nc, self.ld, nat.ptr(v), nat.ptr(ws), ws.numel(), nat.stream_ptr(U)))
+        return v.cpu().numpy()
 
     def certificate(self, u, v, col4row, delta, eps, cap):
         """-> (violations, loose matched entries, tight edges [t, 2] int32 and their reduced costs [t] — None if more than
@@ -208,7 +225,10 @@ def solve_core(M, info=None):
     violating dual feasibility beyond delta, or None if M holds non-finite entries / pricing did not converge."""
     nr, nc = M.shape
     k = min(CORE_EDGES_PER_ROW, 256)
-    cols, costs, bad = M.row_select(None, k)
+    # square problems start from the column reduction (v = column minima, u = row minima of cost - v, rows matched to their
+    # minimising column where it is free): the core is then chosen by REDUCED cost and most rows never need a search
+    v0 = M.col_min() if (nr == nc and COLUMN_REDUCTION) else None
+    cols, costs, bad = M.row_select(v0, k)
     if bad:
         return None
     safety = M.diagonal(nr)                              # row i -> column i: the core always holds a perfect matching
@@ -218,6 +238,8 @@ def solve_core(M, info=None):
     with _Core(nr, nc) as core:
         core.add(cols, costs)
         core.add(np.arange(nr, dtype=np.int32)[:, None], safety[:, None])
+        if v0 is not None:
+            core.init_duals(costs[:, 0] - v0[cols[:, 0]], v0, cols[:, 0])
         rounds = 0
         while True:
             core.solve()

@@ -436,9 +436,14 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
 
     t0 = time.perf_counter()
     if mode == 'unsupervised':
-        U, bn = build_costs(be, mov, fix, group)
-        t0 = mark("gpu_descriptors_costs", t0)
+        # what do_ransac draws depends only on the number of matched pairs: start drawing before the GPU has built anything
         draws = _SampleDraws(be, min(mov.shape[1], fix.shape[1]), int(ransac_samples), int(ransac_trials), seed, private_rng)
+        try:
+            U, bn = build_costs(be, mov, fix, group)
+        except BaseException:
+            draws.thread.join()
+            raise
+        t0 = mark("gpu_descriptors_costs", t0)
         try:
             lsa = assign(U, bn, group, info=None if details is None else details.setdefault("assignment", {}))
         finally:
@@ -522,15 +527,38 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
         dev = nat.device(None if be is None else be.device)
         nat.load()
 
+    # HBM gate: the eight cost matrices of a pair (64 N M bytes, plus descriptors) live on the device while it is being
+    # assigned; workers wait until the pairs in flight leave room for theirs (a pair larger than the whole budget runs alone)
+    gate = threading.Condition()
+    in_flight = [0.0]
+    budget = 0.0
+    if on_gpu:
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        budget = 0.8 * free_b
+
+    def need(k):
+        n, m = _pair_size(pairs[k])
+        return 64.0 * n * m + 2880.0 * (2 * n + 4 * m) * 2
+
     def one(k):
         det = {"timing": True} if timings is not None else None
         if not on_gpu:                       # a caller-supplied host backend (tests): no stream to set
             out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, details=det, **kwargs)
         else:
-            stream = torch.cuda.Stream(device=dev)
-            with torch.cuda.device(dev), torch.cuda.stream(stream):
-                out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, details=det, **kwargs)
-                stream.synchronize()
+            want = min(need(k), budget)
+            with gate:
+                while in_flight[0] + want > budget and in_flight[0] > 0:
+                    gate.wait()
+                in_flight[0] += want
+            try:
+                stream = torch.cuda.Stream(device=dev)
+                with torch.cuda.device(dev), torch.cuda.stream(stream):
+                    out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, details=det, **kwargs)
+                    stream.synchronize()
+            finally:
+                with gate:
+                    in_flight[0] -= want
+                    gate.notify_all()
         if timings is not None:
             timings[k] = det["timing"]
         return out

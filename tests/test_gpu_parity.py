@@ -532,6 +532,26 @@ def test_similar_mode_matches_reference(gpu, oracle):
     A_ref = oracle.perform_icp(start, fx, 12, "Similar", log=olog)
     assert np.array_equal(A_icp, A_ref)
     assert np.array_equal(log["nn"], olog["nn"]) and np.array_equal(log["residuals"], olog["residuals"])
+    # ... and against what the REFERENCE itself produced in the build container (similar_mode.npz), not only against the
+    # oracle's run of the same NumPy calls on this machine.  Per-trial fits: the batched fit of do_ransac and the literal
+    # per-sample fit both agree with the reference to rounding unless LAPACK picked the other eigenvector sign on this CPU
+    # (the quirk of find_transform.py:60-66): a flipped fit is a different rotation, not a rounding difference, so the
+    # comparison is "equal to 1e-9, except for at most a few flips" and the flips are counted and printed.
+    from platymatch_amd.estimate_transform.find_transform import get_similar_transform, similar_fit_batch
+    flips = 0
+    for k in (4, 6, 9, 20):
+        S = d["samples_k%d" % k]
+        batch = similar_fit_batch(np.moveaxis(mv[:, S], 0, 1), np.moveaxis(fx[:, S], 0, 1))
+        for t_, s_ in enumerate(S):
+            one = get_similar_transform(mv[:, s_], fx[:, s_])
+            e1, e2 = relerr(one, d["fits_k%d" % k][t_]), relerr(batch[t_], d["fits_k%d" % k][t_])
+            if e1 > 1e-9 or e2 > 1e-9:
+                flips += 1
+    print("Similar mode: %d of 480 per-sample fits differ from the build container's reference run (eigenvector sign flips)" % flips)
+    assert flips <= 24                                   # 5 %: measured 0 on the build container and on the MI355X box's EPYC 9575F
+    err_icp = relerr(A_icp, d["icp_A"])
+    print("Similar-mode ICP (12 iterations) vs the reference fixture: relative difference %.2e" % err_icp)
+    assert err_icp < 1e-9 or flips > 0                   # identical chain unless this CPU's LAPACK flips a sign along the way
     # the whole driver in this mode
     got = estimate_transform(mv, fx, transform="Similar", ransac_trials=300, ransac_error=3.0, icp_iterations=8, seed=5)
     ref = oracle.estimate_transform(mv, fx, transform="Similar", ransac_trials=300, ransac_error=3.0, icp_iterations=8, seed=5)

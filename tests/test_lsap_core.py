@@ -42,6 +42,10 @@ class HostMatrix:
     def diagonal(self, n):
         return self.U[np.arange(n), np.arange(n)].copy()
 
+    def col_min(self):
+        self.passes += 1
+        return self.U.min(axis=0)
+
     def certificate(self, u, v, col4row, delta, eps, cap):
         self.passes += 1
         red = (self.U - v[None, :]) - u[:, None]
