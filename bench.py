@@ -258,17 +258,19 @@ def main():
         "shape_context": {
             "kernel": "pm::shape_context_kernel<2>, <4>", "bound": "hbm", "achieved": sc_bytes / (sc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": sc_bytes / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": sc_bytes,
-            "binding_bound": "float64 VALU: ~150 instructions per ordered pair for up to four frames (exact ring / theta / phi "
-                             "classification by comparison, DESIGN.md §5)",
+            "binding_bound": "float64 VALU: ~140 instructions per ordered pair for up to four frames (exact ring / theta / phi "
+                             "classification by comparison, DESIGN.md §5); no LDS staging of the cloud: every workgroup streams the "
+                             "1.2 MB SoA cloud from L2",
             "ns_per_pair": sc_ms * 1e6 / sc_pairs,
-            "fp64_valu_frac_of_issue_bound": (150.0 * 4.0 / 2.4e9) * sc_pairs / 64.0 / 1024.0 / (sc_ms * 1e-3)},
+            "valu_issue_estimate_ms": (140.0 * 4.0 / 2.4e9) * sc_pairs / 64.0 / 1024.0 * 1e3},
         "icp": {
-            "kernel": "pm::grid_nn_kernel<32> + accumulate_kernel + update_kernel per iteration", "bound": "hbm",
+            "kernel": "pm::icp_iter_kernel (one launch per iteration: apply + residual + bounded search + moment tree + solve)", "bound": "hbm",
             "achieved": icp_bytes_iter * args.icp_iters / (icp_ms * 1e-3) / 1e9 if args.icp_iters else None, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": (icp_bytes_iter * args.icp_iters / (icp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if args.icp_iters else None,
             "algorithmic_bytes_per_iteration": icp_bytes_iter, "us_per_iteration": icp_ms * 1e3 / max(args.icp_iters, 1),
-            "binding_bound": "latency: dependent launches per iteration (search -> moment sums -> solve + apply), each a few "
-                             "microseconds of fixed cost; the grid search itself is request-rate bound (DESIGN.md §4)"},
+            "binding_bound": "latency: one dependent launch per iteration whose workgroups each walk ~7 dependent memory round "
+                             "trips (previous match -> cell ranges -> candidates -> partial sums -> arrival counter); 2.6 MB of "
+                             "compulsory traffic per iteration cannot load HBM (DESIGN.md §4)"},
     }
 
     if rank == 0:

@@ -18,6 +18,29 @@
 //    rule depends on the order of its `remaining` list; that order only matters when two columns attain the minimum
 //    with equal values, so the step counts them and, only on such a tie, replays SciPy's scan over `remaining`
 //    (rebuilt lazily from the log of removals).  Same column chosen in every step => same duals, same indices.
+//
+// The scalar solver below (augmenting_path, solve_scalar) is derived from SciPy's rectangular_lsap.cpp and is used under
+// SciPy's BSD 3-Clause licence, whose notice follows; the AVX-512 path further down is this project's own code.
+//
+//   Copyright (c) 2001-2002 Enthought, Inc. 2003-2024, SciPy Developers.
+//   All rights reserved.
+//
+//   Redistribution and use in source and binary forms, with or without modification, are permitted provided that the
+//   following conditions are met:
+//   1. Redistributions of source code must retain the above copyright notice, this list of conditions and the following
+//      disclaimer.
+//   2. Redistributions in binary form must reproduce the above copyright notice, this list of conditions and the
+//      following disclaimer in the documentation and/or other materials provided with the distribution.
+//   3. Neither the name of the copyright holder nor the names of its contributors may be used to endorse or promote
+//      products derived from this software without specific prior written permission.
+//
+//   THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS "AS IS" AND ANY EXPRESS OR IMPLIED WARRANTIES,
+//   INCLUDING, BUT NOT LIMITED TO, THE IMPLIED WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A PARTICULAR PURPOSE ARE
+//   DISCLAIMED. IN NO EVENT SHALL THE COPYRIGHT OWNER OR CONTRIBUTORS BE LIABLE FOR ANY DIRECT, INDIRECT, INCIDENTAL,
+//   SPECIAL, EXEMPLARY, OR CONSEQUENTIAL DAMAGES (INCLUDING, BUT NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR
+//   SERVICES; LOSS OF USE, DATA, OR PROFITS; OR BUSINESS INTERRUPTION) HOWEVER CAUSED AND ON ANY THEORY OF LIABILITY,
+//   WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT (INCLUDING NEGLIGENCE OR OTHERWISE) ARISING IN ANY WAY OUT OF THE USE
+//   OF THIS SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
 #include <cmath>
 #include <cstdlib>
 #include <immintrin.h>
