@@ -12,6 +12,9 @@
 // stream continues as if NumPy had drawn.  Parity is anchored on NumPy itself (tests/test_host_logic.py).
 #include <cstdint>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "../../include/platymatch_hip.h"
 
@@ -59,35 +62,76 @@ struct MT {
 
 constexpr int CHUNK = 64;
 
-// The first k entries of the shuffled arange(n), given every swap partner j[i] (i = 1 .. n-1; j[i] <= i) of the
-// Fisher-Yates pass `for i = n-1 .. 1: swap(a[i], a[j[i]])` — WITHOUT performing the swaps.  Follow position q backwards
-// through the swaps (last swap first, i.e. i ascending): the element that ends at q sat, before swap i = q, at j[q]; from
-// then on only a later swap whose partner IS the tracked position moves it (to that swap's i).  So: pos = j[q], then one
-// ascending scan of j[q+1 ..] for entries equal to pos (about ln(n/q) hits), each hit setting pos = i.  The element is `pos`
-// itself (the array starts as arange).  k scans run together; the compare loop vectorises.
-__attribute__((target_clones("avx512f", "avx2", "default"))) void first_entries(const int32_t *__restrict j, long n, int k,
+// The first k entries of the shuffled arange(n), given every swap partner of the Fisher-Yates pass
+// `for i = n-1 .. 1: swap(a[i], a[j_i])` — WITHOUT performing the swaps.  The partners arrive in draw order:
+// w[t] = j_i for i = n-1-t (t = 0 .. n-2).  Follow position q backwards through the swaps (last swap first, i.e. i
+// ascending): the element that ends at q sat, before swap i = q, at j_q; from then on only a later swap whose partner IS the
+// tracked position moves it (to that swap's i).  So: pos = j_q, then one scan over i = q+1 .. n-1 for partners equal to pos
+// (about ln(n/q) hits), each hit setting pos = i.  The element is `pos` itself (the array starts as arange).
+__attribute__((target_clones("avx512f", "avx2", "default"))) void first_entries(const int32_t *__restrict w, long n, int k,
                                                                                  int32_t *__restrict out) {
     for (int q = 0; q < k; ++q) {
-        int32_t pos = (q >= 1) ? j[q] : 0;
-        long i = q + 1;
-        while (i < n) {
-            // skip ahead in blocks while no entry equals pos
-            long stop = i;
-            for (; stop + 64 <= n; stop += 64) {
+        int32_t pos = (q >= 1) ? w[n - 1 - q] : 0;
+        long t = n - 2 - q;                       // w index of i = q + 1; walk t downwards = i upwards
+        while (t >= 0) {
+            long stop = t;                        // skip blocks of 64 that do not contain pos
+            for (; stop - 64 >= -1; stop -= 64) {
                 int hit = 0;
-                for (int u = 0; u < 64; ++u) hit |= (j[stop + u] == pos);
+                for (int u = 0; u < 64; ++u) hit |= (w[stop - u] == pos);
                 if (hit) break;
             }
-            long e = stop + 64 < n ? stop + 64 : n;
+            const long e = stop - 64 >= -1 ? stop - 64 : -1;      // exclusive lower end of the block to look into
             long h = stop;
-            for (; h < e; ++h)
-                if (j[h] == pos) break;
-            if (h < e) { pos = (int32_t)h; i = h + 1; }
-            else i = e;
+            for (; h > e; --h)
+                if (w[h] == pos) break;
+            if (h > e) { pos = (int32_t)(n - 1 - h); t = h - 1; }
+            else t = e;
         }
         out[q] = pos;
     }
 }
+
+// One mask run of the rejection sampling, vectorised: draws v = rnd & mask are accepted iff v <= i, where i drops by one per
+// acceptance.  For a block of 16 draws starting at i0 the acceptance pattern is the fixed point of a_t = [v_t <= i0 - #{s < t:
+// a_s}]; the pattern that assumes every earlier draw accepted (threshold i0 - t) is a subset of it, the pattern computed from
+// that subset's counts a superset: when they coincide — always, unless a draw falls in the 16-wide band below i0 — it is the
+// answer and the accepted values are compress-stored.  Otherwise, and near the ends of runs and generator blocks, the scalar
+// loop decides.  Returns the number of draws consumed; *pi is advanced, accepted partners appended at w[*pw ...].
+#if defined(__x86_64__)
+__attribute__((target("avx512f,avx512bw,avx512vl,bmi2,popcnt"))) static long consume_avx512(const uint32_t *rnd, long avail, uint32_t mask,
+                                                                                         long lo, long *pi, int32_t *w, long *pw) {
+    long used = 0, i = *pi, wp = *pw;
+    const __m512i vmask = _mm512_set1_epi32((int)mask);
+    const __m512i lane = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    while (avail - used >= 16 && i - 16 >= lo) {
+        const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used)), vmask);
+        const __m512i thr0 = _mm512_sub_epi32(_mm512_set1_epi32((int)i), lane);                  // every earlier draw accepted
+        const __mmask16 a0 = _mm512_cmple_epu32_mask(v, thr0);
+        // counts of a0 before each lane: popcount of (a0 & ((1 << t) - 1))
+        alignas(64) int32_t cnt[16];
+        unsigned m0 = a0;
+        for (int t = 0; t < 16; ++t) cnt[t] = __builtin_popcount(m0 & ((1u << t) - 1u));
+        const __m512i thr1 = _mm512_sub_epi32(_mm512_set1_epi32((int)i), _mm512_load_si512((const void *)cnt));
+        const __mmask16 a1 = _mm512_cmple_epu32_mask(v, thr1);
+        if (a0 != a1) break;                                                                      // a draw in the band: scalar decides
+        _mm512_mask_compressstoreu_epi32((void *)(w + wp), a0, v);
+        const int acc = __builtin_popcount(m0);
+        wp += acc;
+        i -= acc;
+        used += 16;
+    }
+    *pi = i;
+    *pw = wp;
+    return used;
+}
+static bool have_avx512() {
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
+    return ok;
+}
+#else
+static long consume_avx512(const uint32_t *, long, uint32_t, long, long *, int32_t *, long *) { return 0; }
+static bool have_avx512() { return false; }
+#endif
 
 }  // namespace
 
@@ -101,15 +145,15 @@ extern "C" int pm_legacy_choice(uint32_t *key, int *pos, long n, int k, long tri
     mt.pos = *pos;
     mt.temper();                                        // outputs pos..623 of the block the caller's state is in
     std::vector<int32_t> partner((size_t)n + CHUNK);
-    int32_t *__restrict jv = partner.data();
-    const uint32_t *__restrict rnd = mt.out;           // locals the compiler can keep apart from the stores into jv[]
+    int32_t *__restrict w = partner.data();
+    const uint32_t *__restrict rnd = mt.out;           // locals the compiler can keep apart from the stores into w[]
+    const bool simd = have_avx512();
     int p = mt.pos;
     for (long t = 0; t < trials; ++t) {
         // Fisher-Yates from the top, in runs of i that share one rejection mask (2^b - 1 for i in [2^(b-1), 2^b)): a draw
-        // is accepted if it is <= the current i, which then drops by one.  Accepted values are stored at jv[i] without a
+        // is accepted if it is <= the current i, which then drops by one.  Accepted values are appended to w without a
         // data-dependent branch (a rejected draw is overwritten by the next one); no array is permuted.
-        jv[0] = 0;
-        long i = n - 1;
+        long i = n - 1, wp = 0;
         while (i >= 1) {
             const uint32_t mask = 0xffffffffu >> __builtin_clz((uint32_t)i);   // smallest all-ones mask >= i
             const long lo = (long)(mask >> 1) + 1;                             // last i that uses this mask
@@ -118,16 +162,18 @@ extern "C" int pm_legacy_choice(uint32_t *key, int *pos, long n, int k, long tri
                     mt.refill();
                     p = 0;
                 }
-                // as many draws as this generator block and this mask run allow, at most
-                long room = 624 - p;
-                for (long q = 0; q < room && i >= lo; ++q) {
+                if (simd) p += (int)consume_avx512(rnd + p, 624 - p, mask, lo, &i, w, &wp);
+                // scalar: up to 16 draws (the band case, the tail of a generator block, the end of a mask run)
+                for (int q = 0; q < 16 && p < 624 && i >= lo; ++q) {
                     const uint32_t v = rnd[p++] & mask;
-                    jv[i] = (int32_t)v;
-                    i -= (v <= (uint32_t)i);
+                    w[wp] = (int32_t)v;
+                    const long take = (v <= (uint32_t)i);
+                    wp += take;
+                    i -= take;
                 }
             }
         }
-        first_entries(jv, n, k, out + t * k);
+        first_entries(w, n, k, out + t * k);
     }
     mt.pos = p;
     *pos = mt.pos;
