@@ -48,9 +48,16 @@ def set_threads(t):
 def host_threads():
     """Cores this process may run on (its affinity mask, not the machine's socket count)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:                                   # a container's CPU quota (cgroup v2 cpu.max: "<quota> <period>" or "max <period>")
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def _p(a):
