@@ -35,8 +35,8 @@ struct Edge {
     double cost;
 };
 
-constexpr int PHASE_MIN_ROWS = 16;          // fewer free rows than this — or than 1/PHASE_MIN_FRACTION of the columns — are
-constexpr int PHASE_MIN_FRACTION = 16;      // augmented one by one (measured: a phase then costs more steps per matched row)
+constexpr int PHASE_MIN_ROWS = 16;          // fewer free rows than this are augmented one by one ...
+constexpr int PHASE_MAX_STEPS_PER_ROW = 384; // ... and so is the rest once a phase pays more Dijkstra steps than this per matched row
 
 struct Core {
     int nr, nc;                                   // real rows <= columns; rows nr..nc-1 are implicit dummy rows (cost 0 to every column)
@@ -300,8 +300,11 @@ struct Core {
             sources.clear();
             for (int r : free_rows)
                 if (r < nr && col4row[r] < 0 && (sources.empty() || sources.back() != r)) sources.push_back(r);
-            if ((int)sources.size() < std::max(PHASE_MIN_ROWS, nc / PHASE_MIN_FRACTION)) break;
-            if (phase(sources) == 0) return PM_ERR_UNSUPPORTED;
+            if ((int)sources.size() < PHASE_MIN_ROWS) break;
+            const long before = steps;
+            const int got = phase(sources);
+            if (got == 0) return PM_ERR_UNSUPPORTED;
+            if (steps - before > (long)PHASE_MAX_STEPS_PER_ROW * got) break;      // a lone search costs about this much per late row
         }
         cold = false;
         // ... the last few, and the dummy rows, one at a time
