@@ -68,26 +68,38 @@ constexpr int CHUNK = 64;
 // ascending): the element that ends at q sat, before swap i = q, at j_q; from then on only a later swap whose partner IS the
 // tracked position moves it (to that swap's i).  So: pos = j_q, then one scan over i = q+1 .. n-1 for partners equal to pos
 // (about ln(n/q) hits), each hit setting pos = i.  The element is `pos` itself (the array starts as arange).
-__attribute__((target_clones("avx512f", "avx2", "default"))) void first_entries(const int32_t *__restrict w, long n, int k,
-                                                                                 int32_t *__restrict out) {
-    for (int q = 0; q < k; ++q) {
-        int32_t pos = (q >= 1) ? w[n - 1 - q] : 0;
-        long t = n - 2 - q;                       // w index of i = q + 1; walk t downwards = i upwards
-        while (t >= 0) {
-            long stop = t;                        // skip blocks of 64 that do not contain pos
-            for (; stop - 64 >= -1; stop -= 64) {
-                int hit = 0;
-                for (int u = 0; u < 64; ++u) hit |= (w[stop - u] == pos);
-                if (hit) break;
-            }
-            const long e = stop - 64 >= -1 ? stop - 64 : -1;      // exclusive lower end of the block to look into
-            long h = stop;
-            for (; h > e; --h)
-                if (w[h] == pos) break;
-            if (h > e) { pos = (int32_t)(n - 1 - h); t = h - 1; }
-            else t = e;
+// follow one tracked position through swaps i_from .. i_to-1 (partners at w[n-1-i]); returns where it ends up
+__attribute__((target_clones("avx512f", "avx2", "default"))) int32_t trace_range(const int32_t *__restrict w, long n, int32_t pos,
+                                                                                 long i_from, long i_to) {
+    long t = n - 1 - i_from;                      // walk t downwards = i upwards
+    const long t_end = n - 1 - i_to;              // exclusive
+    while (t > t_end) {
+        long stop = t;                            // skip blocks of 64 that do not contain pos
+        for (; stop - 64 >= t_end; stop -= 64) {
+            int hit = 0;
+            for (int u = 0; u < 64; ++u) hit |= (w[stop - u] == pos);
+            if (hit) break;
         }
-        out[q] = pos;
+        const long e = stop - 64 >= t_end ? stop - 64 : t_end;    // exclusive lower end of the block to look into
+        long h = stop;
+        for (; h > e; --h)
+            if (w[h] == pos) break;
+        if (h > e) { pos = (int32_t)(n - 1 - h); t = h - 1; }
+        else t = e;
+    }
+    return pos;
+}
+
+void first_entries(const int32_t *__restrict w, long n, int k, int32_t *__restrict out) {
+    // the k traces advance together through chunks of the partner array that stay in L1 (one pass over memory for all k)
+    constexpr long CHUNK_SWAPS = 4096;
+    for (int q = 0; q < k; ++q) out[q] = (q >= 1 && q < n) ? w[n - 1 - q] : q;       // position after its own swap i = q
+    for (long i0 = 1; i0 < n; i0 += CHUNK_SWAPS) {
+        const long i1 = i0 + CHUNK_SWAPS < n ? i0 + CHUNK_SWAPS : n;
+        for (int q = 0; q < k; ++q) {
+            const long from = i0 > q ? i0 : (long)q + 1;
+            if (from < i1) out[q] = trace_range(w, n, out[q], from, i1);
+        }
     }
 }
 
@@ -107,11 +119,17 @@ __attribute__((target("avx512f,avx512bw,avx512vl,bmi2,popcnt"))) static long con
         const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used)), vmask);
         const __m512i thr0 = _mm512_sub_epi32(_mm512_set1_epi32((int)i), lane);                  // every earlier draw accepted
         const __mmask16 a0 = _mm512_cmple_epu32_mask(v, thr0);
-        // counts of a0 before each lane: popcount of (a0 & ((1 << t) - 1))
-        alignas(64) int32_t cnt[16];
-        unsigned m0 = a0;
-        for (int t = 0; t < 16; ++t) cnt[t] = __builtin_popcount(m0 & ((1u << t) - 1u));
-        const __m512i thr1 = _mm512_sub_epi32(_mm512_set1_epi32((int)i), _mm512_load_si512((const void *)cnt));
+        // counts of a0 before each lane: exclusive prefix sum of the 0/1 lanes (four shift-and-add steps)
+        const unsigned m0 = a0;
+        const __m512i ones = _mm512_maskz_set1_epi32(a0, 1);
+        const __m512i zero = _mm512_setzero_si512();
+        __m512i ps = ones;
+        ps = _mm512_add_epi32(ps, _mm512_alignr_epi32(ps, zero, 15));
+        ps = _mm512_add_epi32(ps, _mm512_alignr_epi32(ps, zero, 14));
+        ps = _mm512_add_epi32(ps, _mm512_alignr_epi32(ps, zero, 12));
+        ps = _mm512_add_epi32(ps, _mm512_alignr_epi32(ps, zero, 8));
+        const __m512i cnt = _mm512_sub_epi32(ps, ones);
+        const __m512i thr1 = _mm512_sub_epi32(_mm512_set1_epi32((int)i), cnt);
         const __mmask16 a1 = _mm512_cmple_epu32_mask(v, thr1);
         if (a0 != a1) break;                                                                      // a draw in the band: scalar decides
         _mm512_mask_compressstoreu_epi32((void *)(w + wp), a0, v);
