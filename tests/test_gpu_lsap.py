@@ -121,3 +121,17 @@ def test_eight_assignments_of_a_3000_point_pair_equal_scipy(dev):
         rs, cs = scipy_lsa(U[h].cpu().numpy())
         assert np.array_equal(got[h][0], rs) and np.array_equal(got[h][1], cs), h
     print({k: info["details"][0].get(k) for k in ("rounds", "edges", "steps", "violated_per_round", "max_matched_slack", "tight")})
+
+
+def test_eight_assignments_with_more_moving_than_fixed_points(dev):
+    """N > M: the solver works on the transposed matrices (rows = the short side, as SciPy does); answers in U's own indexing."""
+    from platymatch_amd import lsap as L, pipeline as P
+    mv, fx, _ = synth_pair(1400, 78)
+    be = P.GpuBackend()
+    U, _ = P.build_costs(be, be.cloud(mv), be.cloud(fx[:, :1150]))
+    info = {}
+    got = L.solve_eight_on_device(U, info=info)
+    assert all(r.startswith("device") for r in info["routes"]), info["routes"]
+    for h in range(8):
+        rs, cs = scipy_lsa(U[h].cpu().numpy())
+        assert len(got[h][0]) == 1150 and np.array_equal(got[h][0], rs) and np.array_equal(got[h][1], cs), h

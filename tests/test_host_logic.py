@@ -126,3 +126,33 @@ def test_similar_ransac_fits_follow_the_reference_bit_order():
         err = np.abs(got - ref).reshape(len(S), -1).max(1) / np.abs(ref).reshape(len(S), -1).max(1)
         assert err.max() < 1e-12, (k, err.max())
         assert np.array_equal(similar_fit_batch(np.moveaxis(mv[:, S[:1]], 0, 1), np.moveaxis(fx[:, S[:1]], 0, 1))[0], got[0])
+
+
+def test_unary_array_rows_remember_their_origin_and_nothing_else_does():
+    """get_unary's NumPy return type (shape_context.UnaryArray): an ordinary float64 ndarray whose INTEGER row views carry
+    (descriptor set, frame, row) for get_unary_distance's table lookup; every derived array is plain data again."""
+    import pickle
+    from platymatch_amd.estimate_transform.shape_context import UnaryArray, _DescriptorSet
+    host = np.random.default_rng(0).random((2, 6, 360))
+    dset = _DescriptorSet(None, host)
+    a = host[1].view(UnaryArray)
+    a._pm_set, a._pm_frame = dset, 1
+    assert isinstance(a, np.ndarray) and a.shape == (6, 360) and a.dtype == np.float64
+    r = a[4]
+    assert (r._pm_set is dset, r._pm_frame, r._pm_row) == (True, 1, 4) and np.array_equal(r, host[1, 4])
+    assert a[-1]._pm_row == 5 and a[np.int64(2)]._pm_row == 2
+    assert [row._pm_row for row in a] == list(range(6))                       # iteration yields tagged rows
+    for derived in (a[1:3], a[1:3][0], a + 0.0, a * 2, a.copy(), a[4].copy(), a[4][10:20], a.T, a[[1, 2]], np.array(a), a.astype(np.float32)):
+        assert getattr(derived, "_pm_set", None) is None and getattr(derived, "_pm_row", -1) < 0
+    assert isinstance(a[4][7], np.float64) and float(a.sum()) == float(host[1].sum())
+    assert type(pickle.loads(pickle.dumps(a))) is np.ndarray and np.array_equal(pickle.loads(pickle.dumps(a)), host[1])
+
+
+def test_batch_cost_model_orders_pairs_largest_first():
+    from platymatch_amd import pipeline as P
+    sizes = [(2000, 2000), (20000, 19000), (5000, 9000), (3000, 3000)]
+    cost = P.batch_costs(sizes)
+    assert int(np.argmax(cost)) == 1 and cost[2] > cost[3] > cost[0]
+    assert P.batch_assignment(sizes, 1) == [0, 0, 0, 0]
+    owner = P.batch_assignment(sizes, 2)
+    assert owner[1] != owner[2]                                              # the two largest pairs go to different ranks

@@ -42,7 +42,8 @@ def main():
     group = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        # rehearsal switches (as in bench.py): PM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0, PM_BENCH_BACKEND=gloo replaces RCCL
+        torch.cuda.set_device(0 if os.environ.get("PM_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0")))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("PM_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
         group = dist.group.WORLD
@@ -76,6 +77,13 @@ def main():
         for tm in timings.values():
             for name, v in tm.items():
                 split[name] = split.get(name, 0.0) + v
+        if group is not None:                 # every rank must hold every result: compare with rank 0's copy
+            import torch.distributed as dist
+            flat = torch.as_tensor(np.concatenate([np.concatenate([np.asarray(o[0]).ravel(), np.asarray(o[1]).ravel(), np.asarray(o[2], dtype=np.float64)])
+                                                   for o in out]))
+            ref = flat.clone()
+            dist.broadcast(ref, src=0)
+            assert torch.equal(flat, ref), "ranks disagree on the batch results"
         run = {"workers_per_gpu": w, "n_gpus": world, "pairs": len(pairs), "seconds": dt, "registrations_per_s": len(pairs) / dt,
                "worst_rel_error_vs_ground_truth": err,
                "stage_seconds_summed_over_this_ranks_pairs": split,
