@@ -34,7 +34,7 @@ def timed(label, fn):
 
 timed("warm-up (library load, first launches)", lambda: P.build_costs(be, mov[:, :256].contiguous(), fix[:, :256].contiguous()))
 U, bn = timed("descriptors + 8 cost matrices (GPU)", lambda: P.build_costs(be, mov, fix))
-lsa = timed("8 x linear_sum_assignment (host)", lambda: P.assign(U, bn))
+lsa = timed("8 x assignment (core on host, matrix on GPU)", lambda: P.assign(U, bn))
 np.random.seed(0)
 res = timed("8 x RANSAC, %d trials (host RNG + GPU)" % trials,
             lambda: [be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), trials, 16, "Affine", 4) for r, c in lsa])
