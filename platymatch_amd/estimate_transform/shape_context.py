@@ -26,13 +26,15 @@ MATRIX_CACHE_BYTES = 4 << 30          # all matrices of a combination are built 
 class _DescriptorSet:
     """What one get_unary call produced: the device histograms [F, N, 360], their host copy, and the cost matrices
     already built against other sets."""
-    __slots__ = ("hist", "host", "tables", "lock", "__weakref__")
+    __slots__ = ("hist", "host", "tables", "fast", "rows", "lock", "__weakref__")
 
     def __init__(self, hist, host):
         import threading
         import weakref
         self.hist, self.host = hist, host
         self.tables = weakref.WeakKeyDictionary()        # other set -> {(frame_a, frame_b): N x M ndarray}  (or False: do not cache)
+        self.fast = {}                                   # (id(other set), frame_a, frame_b) -> that ndarray: the per-call path
+        self.rows = {}                                   # frame -> list of tagged row views (made once, handed out by a[i])
         self.lock = threading.Lock()
 
 
@@ -46,11 +48,18 @@ class UnaryArray(np.ndarray):
         self._pm_row = -1
 
     def __getitem__(self, idx):
-        out = super().__getitem__(idx)
-        if self._pm_set is not None and self._pm_row < 0 and self.ndim == 2 and isinstance(idx, (int, np.integer)):
-            out._pm_set, out._pm_frame = self._pm_set, self._pm_frame
-            out._pm_row = int(idx) + (self.shape[0] if idx < 0 else 0)
-        return out
+        dset = self._pm_set
+        if dset is not None and self._pm_row < 0 and self.ndim == 2 and isinstance(idx, (int, np.integer)):
+            rows = dset.rows.get(self._pm_frame)
+            if rows is None:         # the widget asks for every row N (or M) times: make the tagged views once
+                rows = []
+                for r in range(self.shape[0]):
+                    v = super().__getitem__(r)
+                    v._pm_set, v._pm_frame, v._pm_row = dset, self._pm_frame, r
+                    rows.append(v)
+                dset.rows[self._pm_frame] = rows
+            return rows[idx]         # (IndexError for an out-of-range row, like ndarray; negative rows count from the end)
+        return super().__getitem__(idx)
 
     def __reduce__(self):            # pickling / copying yields plain data
         return np.asarray(self).__reduce__()
@@ -79,7 +88,20 @@ def _cost_table(sa, sb, fa, fb):
                     tabs.clear()
                 tabs[(fa, fb)] = K.chi2_cost(sa.hist[fa], sb.hist[fb]).cpu().numpy()
             t = tabs[(fa, fb)]
+            # the per-call index (keyed by id: dropped again when the other set dies, so that a recycled id cannot alias)
+            import weakref
+            if not any(k[0] == id(sb) for k in sa.fast):
+                weakref.finalize(sb, _forget, weakref.ref(sa), id(sb))
+            sa.fast = {k: v for k, v in sa.fast.items() if k[0] != id(sb)}
+            for (a, b), tab in tabs.items():
+                sa.fast[(id(sb), a, b)] = tab
         return t
+
+
+def _forget(sa_ref, other_id):
+    sa = sa_ref()
+    if sa is not None:
+        sa.fast = {k: v for k, v in sa.fast.items() if k[0] != other_id}
 
 
 def get_Y(z, x):
@@ -138,6 +160,10 @@ def get_unary_distance(sc1, sc2):
     unary_11[i], unary_21[j]) are answered from the cost matrix of their two descriptor sets, built on the device at
     the first call (see UnaryArray); any other input is one launch per pair.  Whole clouds: unary_distance_matrix /
     unary_distance_matrices."""
+    try:        # the per-call path of the widget's loops: two attribute reads, one dict lookup, one element
+        return sc1._pm_set.fast[(id(sc2._pm_set), sc1._pm_frame, sc2._pm_frame)][sc1._pm_row, sc2._pm_row]
+    except (AttributeError, KeyError, TypeError):
+        pass
     sa, sb = getattr(sc1, "_pm_set", None), getattr(sc2, "_pm_set", None)
     if sa is not None and sb is not None and sc1._pm_row >= 0 and sc2._pm_row >= 0:
         t = _cost_table(sa, sb, sc1._pm_frame, sc2._pm_frame)

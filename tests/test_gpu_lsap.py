@@ -135,3 +135,36 @@ def test_eight_assignments_with_more_moving_than_fixed_points(dev):
     for h in range(8):
         rs, cs = scipy_lsa(U[h].cpu().numpy())
         assert len(got[h][0]) == 1150 and np.array_equal(got[h][0], rs) and np.array_equal(got[h][1], cs), h
+
+
+def test_fuzz_of_distributions_and_shapes_against_scipy(dev):
+    """Negative costs, large offsets, tiny scales, heavy tails, low-rank structure, near-ties, wide and tall shapes: whatever
+    route is taken, the indices are SciPy's."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(11)
+    routes = {"device": 0, "host": 0}
+    for trial in range(120):
+        n, m = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        kind = trial % 8
+        if kind == 0:
+            U = rng.normal(size=(n, m))
+        elif kind == 1:
+            U = rng.random((n, m)) + 1e6
+        elif kind == 2:
+            U = rng.random((n, m)) * 1e-200
+        elif kind == 3:
+            U = rng.standard_cauchy(size=(n, m))
+        elif kind == 4:
+            U = np.outer(rng.random(n), rng.random(m)) + 1e-3 * rng.random((n, m))
+        elif kind == 5:
+            U = np.round(rng.random((n, m)), 2)                      # many ties
+        elif kind == 6:
+            U = np.abs(rng.normal(size=(n, 1)) - rng.normal(size=(1, m)))     # 1-D geometry: structured, near-ties
+        else:
+            U = -rng.random((n, m)) ** 3
+        info = {}
+        r, c = L.solve_on_device(dev(U), info=info, force=True)
+        rs, cs = scipy_lsa(U)
+        assert np.array_equal(r, rs) and np.array_equal(c, cs), (trial, kind, n, m, info)
+        routes[info["route"]] += 1
+    assert routes["device"] >= 60, routes                              # generic matrices are certified; ties go to the host
