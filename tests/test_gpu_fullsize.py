@@ -95,6 +95,30 @@ def test_fused_icp_loop_equals_stepwise_loop(big):
     assert float(res[-1]) < float(res[0])
 
 
+def test_fused_icp_is_bit_reproducible_under_concurrent_load(big):
+    """The fused iteration hands partial sums between workgroups inside one launch (write-through stores, arrival
+    counters, L1-bypassing loads — no fence).  Such hand-offs must be tested under UNEVEN load: the same 40-iteration
+    loop is run 12 times while another stream keeps the chip busy with cost-matrix tiles, and every run must reproduce
+    the quiet run bit for bit (a stale partial sum would change the fitted 4x4)."""
+    K, t = big["K"], big["t"]
+    iters = 40
+    quiet = big["start"].clone()
+    A0, res0, _ = K.icp(quiet, big["fix"], iters)
+    hm = K.shape_context(big["mov"], *big["mov_stats"], 2, row0=0, nrows=1024)["hist"]
+    hf = K.shape_context(big["fix"], *big["fix_stats"], 4, row0=0, nrows=8192)["hist"]
+    noise_stream = t.cuda.Stream()
+    out = t.empty((8, 1024, 8192), dtype=t.float64, device=hm.device)
+    t.cuda.synchronize()
+    for rep in range(12):
+        with t.cuda.stream(noise_stream):
+            for _ in range(3 + rep % 4):
+                K.chi2_cost8(hm, hf, out=out)                 # ~30 ms of VALU-bound tiles on every CU
+        work = big["start"].clone()
+        A, res, _ = K.icp(work, big["fix"], iters)
+        assert t.equal(A, A0) and t.equal(res, res0) and t.equal(work, quiet), rep
+    t.cuda.synchronize()
+
+
 def test_config3_icp_correspondences_equal_oracle_at_50k(big, oracle):
     """BASELINE config 3 pinned to the CPU oracle at its full size: for the first three iterations of the 50k ICP, the
     nearest fixed point of EVERY moving point (and its distance) equals the oracle's scan of all 2.5e9 pairs
