@@ -187,11 +187,13 @@ int pm_lsap_col_min(const double *U, int nr, int nc, size_t ld, double *v, void 
 /* DEVICE: certificate of (u[nr], v[nc], col4row[nr]) against every entry of U.  summary4 = { entries with reduced cost
  * (U[i][j] - v[j]) - u[i] < -delta; non-matching entries with reduced cost <= eps, appended to tight[cap][2] as (row, col)
  * with their reduced costs in tight_red[cap] — if the count exceeds cap the list is incomplete; matched entries with
- * |reduced cost| > delta; 0 }.  stats2 = { largest |reduced cost| on a matched entry, largest violation }: the caller
- * derives from them how small an eps still separates the optimum from every alternative, and filters the list by it. */
+ * |reduced cost| > delta; 0 }.  stats2 = { largest |reduced cost| on a matched entry, largest negative reduced cost };
+ * row_slack[nr], row_neg[nr] (may be NULL) = the same two quantities per row: any other assignment costs at least
+ * (reduced costs of its new entries) - sum(row_slack) - sum(row_neg) more than this one, so the caller knows how small an
+ * eps still separates the optimum from every alternative, and filters the list by it. */
 int pm_lsap_certificate(const double *U, int nr, int nc, size_t ld, const double *u, const double *v,
                         const int32_t *col4row, double delta, double eps, int32_t *summary4, double *stats2,
-                        int32_t *tight, double *tight_red, int cap, void *stream);
+                        int32_t *tight, double *tight_red, int cap, double *row_slack, double *row_neg, void *stream);
 
 /* HOST: the sparse core solver, one instance per matrix (nr <= nc; nc - nr implicit zero-cost dummy rows square the
  * problem).  add: k candidate edges per real row (cols [nr][k], -1 skipped, duplicates skipped).  solve: augment every

@@ -38,7 +38,7 @@ SIGNATURES = {
     "pm_lsap_solve": (_c_int, [_c_void_p, ctypes.c_long, ctypes.c_long, _c_void_p, _c_void_p]),
     "pm_lsap_row_select": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "pm_lsap_certificate": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_void_p, _c_void_p, _c_double, _c_double,
-                                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p]),
+                                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "pm_lsap_col_min_workspace": (_c_size_t, [_c_int, _c_int]),
     "pm_lsap_col_min": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_lsap_core_init_duals": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p]),

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *_
                                                                  const double *__restrict__ u, const double *__restrict__ v,
                                                                  const int32_t *__restrict__ col4row, double delta, double eps,
                                                                  int32_t *__restrict__ summary, unsigned long long *__restrict__ stats,
-                                                                 int32_t *__restrict__ tight, double *__restrict__ tight_red, int cap) {
+                                                                 int32_t *__restrict__ tight, double *__restrict__ tight_red, int cap,
+                                                                 double *__restrict__ row_slack, double *__restrict__ row_neg) {
     __shared__ int s_cnt[2];
     __shared__ unsigned long long s_max[2];
     const int tid = threadIdx.x, i = blockIdx.x;
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *_
             ++viol;
             worst = fmax(worst, -red);
         } else if (red <= eps) {
+            worst = fmax(worst, -red);                       // a negative reduced cost inside the tolerance still counts in the bound
             const int at = atomicAdd(&summary[1], 1);
             if (at < cap) { tight[2 * (size_t)at] = i; tight[2 * (size_t)at + 1] = j; tight_red[at] = red; }
         }
@@ -124,6 +126,10 @@ __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *_
         if (s_cnt[1]) atomicAdd(&summary[2], s_cnt[1]);
         if (s_max[0]) atomicMax(&stats[0], s_max[0]);
         if (s_max[1]) atomicMax(&stats[1], s_max[1]);
+        // per row: |reduced cost| of its matched entry, and its most negative reduced cost — the host adds them up: any other
+        // assignment costs at least (the new entries' reduced costs) - sum(row_slack) - sum(row_neg) more than this one
+        if (row_slack) row_slack[i] = __longlong_as_double((long long)s_max[0]);
+        if (row_neg) row_neg[i] = __longlong_as_double((long long)s_max[1]);
     }
 }
 
@@ -158,7 +164,7 @@ int pm_lsap_col_min(const double *U, int nr, int nc, size_t ld, double *v, void 
 
 int pm_lsap_certificate(const double *U, int nr, int nc, size_t ld, const double *u, const double *v, const int32_t *col4row,
                         double delta, double eps, int32_t *summary4, double *stats2, int32_t *tight, double *tight_red, int cap,
-                        void *stream) {
+                        double *row_slack, double *row_neg, void *stream) {
     if (!U || !u || !v || !col4row || !summary4 || !stats2 || !tight || !tight_red || nr <= 0 || nc < nr || ld < (size_t)nc || cap <= 0 ||
         !(delta >= 0.0) || !(eps >= 0.0))
         return PM_ERR_INVALID_ARG;
@@ -166,7 +172,7 @@ int pm_lsap_certificate(const double *U, int nr, int nc, size_t ld, const double
     if (hipMemsetAsync(summary4, 0, 4 * sizeof(int32_t), s) != hipSuccess) return pm::launch_status();
     if (hipMemsetAsync(stats2, 0, 2 * sizeof(double), s) != hipSuccess) return pm::launch_status();
     pm::certificate_kernel<<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, u, v, col4row, delta, eps, summary4, (unsigned long long *)stats2,
-                                                          tight, tight_red, cap);
+                                                          tight, tight_red, cap, row_slack, row_neg);
     return pm::launch_status();
 }
 

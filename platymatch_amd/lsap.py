@@ -56,9 +56,9 @@ CORE_EDGES_PER_ROW = 48          # initial core: up to this many cheap entries p
 PRICE_EDGES_PER_ROW = 8          # offenders a row may hand back per pricing round
 MAX_PRICING_ROUNDS = 200
 REL_DELTA = 1e-13                # dual feasibility / tightness tolerance, relative to the largest dual or core cost
-REL_EPS_COLLECT = 1e-8           # entries with reduced cost below this (relative) are collected by the certificate kernel
+REL_EPS_COLLECT = 1e-7           # entries with reduced cost below this (relative) are collected by the certificate kernel
 REL_EPS_FLOOR = 1e-11            # smallest uniqueness margin accepted (relative): ~1e5 x the rounding of one float64 operation
-EPS_SAFETY = 64.0                # margin >= EPS_SAFETY * 2 n * (observed violation + observed slack on matched entries)
+EPS_SAFETY = 16.0                # margin >= EPS_SAFETY * (sum of the rows' matched slack + sum of the rows' worst negative reduced cost)
 COLUMN_REDUCTION = True          # start square solves from the column reduction
 DEVICE_MIN_ROWS = 1024           # below this the dense host solver is quicker than the round trips of the device scheme
 # The eight matrices hold four distinct sets of terms: U11/U22, U12/U21, U13/U24, U14/U23 differ only in
@@ -156,7 +156,7 @@ class DeviceMatrix:
 
     def certificate(self, u, v, col4row, delta, eps, cap):
         """-> (violations, loose matched entries, tight edges [t, 2] int32 and their reduced costs [t] — None if more than
-        cap —, (max slack on a matched entry, max violation))."""
+        cap —, sum over rows of (|reduced cost| of the matched entry + the row's worst negative reduced cost))."""
         torch = nat.torch_mod()
         U = self.U
         nr, nc = U.shape
@@ -166,14 +166,16 @@ class DeviceMatrix:
         stats = torch.empty(2, dtype=torch.float64, device=U.device)
         tight = torch.empty((cap, 2), dtype=torch.int32, device=U.device)
         red = torch.empty(cap, dtype=torch.float64, device=U.device)
+        rows = torch.empty((2, nr), dtype=torch.float64, device=U.device)
         nat.check(nat.load().pm_lsap_certificate(nat.ptr(U), nr, nc, self.ld, nat.ptr(u_d), nat.ptr(v_d), nat.ptr(c_d), float(delta),
                                                  float(eps), nat.ptr(summary), nat.ptr(stats), nat.ptr(tight), nat.ptr(red), cap,
-                                                 nat.stream_ptr(U)))
+                                                 nat.ptr(rows[0]), nat.ptr(rows[1]), nat.stream_ptr(U)))
         viol, n_tight, loose, _ = summary.cpu().tolist()
-        st = stats.cpu().tolist()
+        rows_h = rows.cpu().numpy()
+        bound = float(rows_h[0].sum() + rows_h[1].sum())         # what the observed imperfections can cost any alternative, in total
         if n_tight > cap:
-            return viol, loose, None, None, (st[0], st[1])
-        return viol, loose, tight[:n_tight].cpu().numpy(), red[:n_tight].cpu().numpy(), (st[0], st[1])
+            return viol, loose, None, None, bound
+        return viol, loose, tight[:n_tight].cpu().numpy(), red[:n_tight].cpu().numpy(), bound
 
 
 def certify(M, u, v, col4row, info=None):
@@ -185,17 +187,15 @@ def certify(M, u, v, col4row, info=None):
     scale = max(float(np.abs(u).max()), float(np.abs(v).max()), 1e-300)
     delta, eps_collect = REL_DELTA * scale, REL_EPS_COLLECT * scale
     cap = 8 * nc + 1024
-    viol, loose, tight, red, (slack, worst) = M.certificate(u, v, col4row, delta, eps_collect, cap)
-    # How wide must the margin be?  With every reduced cost >= -worst and every matched entry within slack of tight, any other
-    # assignment costs at least (optimum + the reduced costs of its new entries - 2 n (worst + slack)): if each alternative
-    # needs an entry with reduced cost > eps, eps > 2 n (worst + slack) separates them — taken EPS_SAFETY times wider, and
-    # never below REL_EPS_FLOOR (far above the rounding any exact solver, SciPy's included, accumulates).
-    if red is not None and len(red):
-        worst = max(worst, float(-red.min()))        # negative reduced costs inside the tolerance count as well
-    eps = max(REL_EPS_FLOOR * scale, EPS_SAFETY * 2.0 * max(nr, nc) * (worst + slack))
+    viol, loose, tight, red, bound = M.certificate(u, v, col4row, delta, eps_collect, cap)
+    # How wide must the margin be?  Any other assignment costs at least (the reduced costs of its new entries) - bound more than
+    # this one, bound = sum over rows of the matched entry's |reduced cost| and of the row's most negative reduced cost (both
+    # ~1e-17 per row: rounding).  If every alternative needs an entry with reduced cost > eps, eps > bound separates them —
+    # taken EPS_SAFETY times wider, and never below REL_EPS_FLOOR (far above the rounding any exact solver, SciPy's included,
+    # accumulates along a cycle).
+    eps = max(REL_EPS_FLOOR * scale, EPS_SAFETY * bound)
     if info is not None:
-        info.update(violations=viol, loose=loose, tight=None if tight is None else len(tight), max_matched_slack=slack,
-                    max_violation=worst, delta=delta, eps=eps)
+        info.update(violations=viol, loose=loose, tight=None if tight is None else len(tight), slack_bound=bound, delta=delta, eps=eps)
     if viol or loose or tight is None or eps > eps_collect:
         return False
     keep = red <= eps

@@ -261,11 +261,18 @@ def assign(U_loc, bounds, group=None, info=None):
         owner = h % world
         padded = torch.zeros((biggest, U_loc.shape[2]), dtype=U_loc.dtype, device=U_loc.device)
         padded[:U_loc.shape[1]].copy_(U_loc[h])
-        blocks = [torch.empty_like(padded) for _ in range(world)] if owner == rank else None
+        # the owner receives the blocks into ONE allocation; with equal blocks (N divisible by the ranks) that allocation IS
+        # the matrix, otherwise the padding rows are squeezed out by one copy
+        whole = torch.empty((world, biggest, U_loc.shape[2]), dtype=U_loc.dtype, device=U_loc.device) if owner == rank else None
+        blocks = [whole[g] for g in range(world)] if owner == rank else None
         dist.gather(padded, blocks, dst=_global_rank(group, owner), group=group)   # row blocks -> the owner only
+        del padded
         if owner == rank:    # keep the assembled matrix (on the device if that is where it is); solve after all gathers so ranks solve concurrently
-            mine[h] = torch.cat([blocks[g][:bounds[g + 1] - bounds[g]] for g in range(world)], dim=0)
-            del blocks
+            if all(bounds[g + 1] - bounds[g] == biggest for g in range(world)):
+                mine[h] = whole.view(world * biggest, U_loc.shape[2])
+            else:
+                mine[h] = torch.cat([blocks[g][:bounds[g + 1] - bounds[g]] for g in range(world)], dim=0)
+            del blocks, whole
     # A solver refusal (NaN / -inf costs from degenerate descriptors, infeasible matrix) on the owner of one hypothesis
     # must not leave the other ranks waiting in the broadcasts below: collect a status word per hypothesis, agree on it,
     # and raise the same exception everywhere.

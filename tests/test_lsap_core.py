@@ -56,11 +56,12 @@ class HostMatrix:
         loose = int((~(np.abs(red) <= delta) & matched).sum())
         sel = (red <= eps) & (red >= -delta) & ~matched
         t = np.argwhere(sel).astype(np.int32)
-        slack = float(np.abs(red[matched]).max())
-        worst = float(max(0.0, -(red[~matched & ~(red >= -delta)]).min())) if viol else 0.0
+        neg = np.where(matched, 0.0, np.maximum(-red, 0.0))
+        neg = np.where(np.isnan(neg), 0.0, neg)
+        bound = float(np.abs(red[matched]).sum() + neg.max(axis=1).sum())
         if len(t) > cap:
-            return viol, loose, None, None, (slack, worst)
-        return viol, loose, t, red[sel], (slack, worst)
+            return viol, loose, None, None, bound
+        return viol, loose, t, red[sel], bound
 
 
 def run(U, force_k=None):
