@@ -45,6 +45,8 @@ A_icp = timed("ICP, 50 iterations (GPU)", lambda: be.icp(moved, fix, 50, "Affine
 final = A_icp.cpu().numpy() @ (A_sc.cpu().numpy() if hasattr(A_sc, "cpu") else A_sc)
 print("inliers", inl, " rel. error vs ground truth %.2e" % (np.linalg.norm(final - A_gt) / np.linalg.norm(A_gt)))
 
+del U            # the staged run's eight matrices (64 N M bytes: 160 GB at 50k) must go before the driver builds its own
+torch.cuda.empty_cache()
 # the same registration through the driver, where the RANSAC index sets are drawn while the solver runs and each
 # solver thread fetches its own matrix
 t = time.perf_counter()
