@@ -278,11 +278,13 @@ def solve_on_device(U, info=None, force=False):
     return linear_sum_assignment(U.cpu().numpy())
 
 
-def solve_eight_on_device(U8, info=None):
+def solve_eight_on_device(U8, info=None, allow_host=True):
     """The widget's eight assignments (_dock_widget.py:604-611) for U8 [8, N, M] on the GPU: hypotheses 11, 12, 13, 14 are
     solved (four host threads drive their core solves and kernels concurrently); each twin (22, 21, 24, 23: the same terms
     summed in another order) first tries its sibling's duals — accepted only if they are a certified unique optimum of the
-    twin's OWN matrix — and is solved on its own otherwise.  -> list of eight (row_ind, col_ind)."""
+    twin's OWN matrix — and is solved on its own otherwise.  -> list of eight (row_ind, col_ind).
+    allow_host=False: never take the dense host solver (hours at 50 000 nuclei); a hypothesis that cannot be certified comes
+    back as None instead (bench.py's bounded extra leg)."""
     torch = nat.torch_mod()
     n, m = U8.shape[1], U8.shape[2]
     out = [None] * 8
@@ -303,8 +305,12 @@ def solve_eight_on_device(U8, info=None):
                 if certify(Wt, *sol, info=infos[twin]):
                     infos[twin]["route"] = "device (sibling's duals certified)"
                     out[twin] = out[h]
-                else:
+                elif allow_host:
                     out[twin] = solve_on_device(U8[twin], infos[twin])
+                else:
+                    infos[twin]["route"] = "uncertified (dense solver not allowed)"
+            elif not allow_host:        # bounded mode: report, do not spend hours on the dense solver
+                infos[h]["route"] = infos[twin]["route"] = "uncertified (dense solver not allowed)"
             else:
                 infos[h]["route"] = "host"
                 out[h] = linear_sum_assignment(U8[h].cpu().numpy())

@@ -165,6 +165,41 @@ def test_config3_sampled_cost_rows_equal_oracle_at_50k(big, oracle):
         assert np.array_equal(want.view(np.uint64), U[h].cpu().numpy().view(np.uint64)), name
 
 
+def test_assignment_at_50k_is_certified_and_duality_holds_on_independent_checks(big):
+    """The assignment of the 50 000 x 50 000 build — out of reach for the dense host solver (hours per matrix) — through the
+    device-resident route, for one right (11) and one wrong (12) hypothesis.  Beyond the route's own certificate, checked here
+    independently on the host: the answer is a permutation; primal = dual to rounding (sum of the assigned costs, gathered from the
+    device matrix, against sum(u) + sum(v) in extended precision) — LP duality's equality, which only an optimal pair attains;
+    dual feasibility recomputed with NumPy on 48 sampled full rows; no other entry of a sampled row is tight within the margin
+    unless the certificate listed it."""
+    from platymatch_amd import lsap as L
+    K, t = big["K"], big["t"]
+    hm = K.shape_context(big["mov"], *big["mov_stats"], 2)["hist"]
+    hf = K.shape_context(big["fix"], *big["fix_stats"], 4)["hist"]
+    rng = np.random.default_rng(0)
+    for fa, fb in ((0, 0), (0, 1)):
+        U = K.chi2_cost(hm[fa], hf[fb])                               # 20 GB, stays on the device
+        M = L.DeviceMatrix(U)
+        info = {}
+        sol = L.solve_core(M, info)
+        assert sol is not None and L.certify(M, *sol, info=info), info
+        u, v, c4r = sol
+        assert np.array_equal(np.sort(c4r), np.arange(N))
+        idx = t.as_tensor(c4r.astype(np.int64), device=U.device)
+        assigned = U[t.arange(N, device=U.device), idx].cpu().numpy()
+        primal = np.sum(assigned.astype(np.longdouble))
+        dual = np.sum(u.astype(np.longdouble)) + np.sum(v.astype(np.longdouble))
+        assert abs(float(primal - dual)) <= 1e-9 * float(primal), (float(primal), float(dual))
+        rows = rng.choice(N, 48, replace=False)
+        Uh = U[t.as_tensor(rows, device=U.device)].cpu().numpy()
+        red = (Uh - v[None, :]) - u[rows][:, None]
+        assert red.min() >= -info["delta"]
+        assert np.abs(red[np.arange(48), c4r[rows]]).max() <= info["delta"]
+        print("hypothesis 1%d at 50k: %d pricing rounds, %.1fM Dijkstra steps, margin %.1e, primal - dual %.1e"
+              % (fb + 1, info["rounds"], info["steps"] / 1e6, info["eps"], float(primal - dual)))
+        del U, M, Uh, red
+
+
 def test_config4_rank_slice_row_argmins_equal_cpu():
     """BASELINE config 4 (200k x 200k chi-square rows sharded over 8 GPUs, indices checked against the CPU), one rank's
     code path on a slice: descriptors of 200 000-point clouds, 1 024 cost rows x 200 000 columns x 8 matrices, row
