@@ -139,9 +139,14 @@ class DeviceMatrix:
         return cols.cpu().numpy(), costs.cpu().numpy(), int(flag.item())
 
     def diagonal(self, n):
+        return self.block_diagonal(0)[:n]
+
+    def block_diagonal(self, row0):
+        """U[r, row0 + r] for the rows of this block (the global matrix's diagonal when the block starts at row row0)."""
         torch = nat.torch_mod()
-        d = torch.arange(n, device=self.U.device)
-        return self.U[d, d].cpu().numpy()
+        nr, nc = self.U.shape
+        r = torch.arange(max(0, min(nr, nc - row0)), device=self.U.device)
+        return self.U[r, r + row0].cpu().numpy()
 
     def col_min(self):
         """-> v [nc] on the host: pm_lsap_col_min."""

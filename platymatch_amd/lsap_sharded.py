@@ -1,0 +1,136 @@
+"""The device-resident assignment solve (lsap.py) for a cost matrix whose ROWS are sharded over the ranks of a
+torch.distributed group — the layout the sharded cost build leaves behind (pipeline.build_costs: rank g holds rows
+[b_g, b_g+1) of every hypothesis, all M columns).
+
+Nothing of the matrix travels.  One rank (the root of a hypothesis) runs the sparse-core solver; every query it makes of the
+dense matrix — column minima, per-row candidates for the core / for pricing, the certificate — is answered by all ranks for
+their own rows with the same HIP kernels as on one GPU, and only the answers cross the wire: k candidates per row, the
+column duals (8 M bytes per pricing round), a few counters.  At 50 000 x 50 000 that is ~30 MB per hypothesis instead of
+the 20 GB a gather of the matrix moves, and it is the only way to assign a matrix that does not fit one GPU (BASELINE
+config 4: 200 000 x 200 000 is 320 GB; a rank's block of one hypothesis is 40 GB).
+
+Protocol: the root broadcasts (operation, which matrix, arguments); every rank, the root included, runs it on its block;
+the answers are gathered on the root.  Workers loop in `serve` until the root says stop.  Rows must be the short side
+(N <= M): with N > M the solver works on the transpose, whose rows are this layout's columns."""
+import numpy as np
+
+from . import lsap
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def _answer(local, row0, rows, op, args):
+    """One rank's share of a query on its block `local` (rows [row0, row0 + rows) of the matrix)."""
+    if op == "row_select":
+        v, k = args
+        return local.row_select(v, k)
+    if op == "diagonal":
+        # entry (i, i) of the global matrix for the block's rows
+        return local.block_diagonal(row0) if hasattr(local, "block_diagonal") else None
+    if op == "col_min":
+        return local.col_min()
+    if op == "certificate":
+        u, v, c4r, delta, eps, cap = args
+        viol, loose, tight, red, bound = local.certificate(u[row0:row0 + rows], v, c4r[row0:row0 + rows], delta, eps, cap)
+        if tight is not None and len(tight):
+            tight = tight.copy()
+            tight[:, 0] += row0                           # block rows -> matrix rows
+        return viol, loose, tight, red, bound
+    raise ValueError("unknown operation %r" % (op,))
+
+
+class ShardedMatrix:
+    """lsap.DeviceMatrix's interface over row blocks on several ranks — the object the ROOT hands to lsap.solve_core /
+    lsap.certify.  `locals_` are this rank's blocks of the matrices that may be queried (e.g. a hypothesis and its twin)."""
+
+    def __init__(self, locals_, which, bounds, group, root, n_cols):
+        self.locals, self.which, self.bounds, self.group, self.root = locals_, which, bounds, group, root
+        self.shape = (bounds[-1], n_cols)
+
+    def _ask(self, op, args):
+        dist = _dist()
+        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        dist.broadcast_object_list([(op, self.which, args)], src=_global(self.group, self.root), group=self.group)
+        mine = _answer(self.locals[self.which], self.bounds[rank], self.bounds[rank + 1] - self.bounds[rank], op, args)
+        parts = [None] * world
+        dist.gather_object(mine, parts, dst=_global(self.group, self.root), group=self.group)
+        return parts
+
+    def row_select(self, v, k):
+        parts = self._ask("row_select", (v, k))
+        return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), int(max(p[2] for p in parts)))
+
+    def diagonal(self, n):
+        return np.concatenate(self._ask("diagonal", None))[:n]
+
+    def col_min(self):
+        return np.minimum.reduce(self._ask("col_min", None))
+
+    def certificate(self, u, v, col4row, delta, eps, cap):
+        parts = self._ask("certificate", (u, v, col4row, delta, eps, cap))
+        viol, loose = sum(p[0] for p in parts), sum(p[1] for p in parts)
+        bound = float(sum(p[4] for p in parts))
+        if any(p[2] is None for p in parts) or sum(len(p[2]) for p in parts) > cap:
+            return viol, loose, None, None, bound
+        return viol, loose, np.concatenate([p[2] for p in parts]), np.concatenate([p[3] for p in parts]), bound
+
+    def stop(self):
+        _dist().broadcast_object_list([("stop", 0, None)], src=_global(self.group, self.root), group=self.group)
+
+
+def _global(group, group_rank):
+    dist = _dist()
+    if group is None or group is dist.group.WORLD:
+        return group_rank
+    return dist.get_global_rank(group, group_rank)
+
+
+def serve(locals_, bounds, group, root):
+    """A worker's side: answer the root's queries about this rank's blocks until it says stop."""
+    dist = _dist()
+    rank = dist.get_rank(group)
+    row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
+    while True:
+        box = [None]
+        dist.broadcast_object_list(box, src=_global(group, root), group=group)
+        op, which, args = box[0]
+        if op == "stop":
+            return
+        dist.gather_object(_answer(locals_[which], row0, rows, op, args), None, dst=_global(group, root), group=group)
+
+
+def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=None):
+    """One hypothesis and (optionally) its twin, rows sharded: the root solves the first on its sparse core and certifies the
+    result on both matrices.  -> (col4row of the hypothesis or None, col4row of the twin or None) on EVERY rank; None = not
+    certified (the caller takes another route for that matrix).  N <= M required."""
+    dist = _dist()
+    rank = dist.get_rank(group)
+    locals_ = [local_h] + ([local_twin] if local_twin is not None else [])
+    out = [None, None, None]                              # col4row, twin's col4row, error message
+    if rank == root:
+        try:
+            M = ShardedMatrix(locals_, 0, bounds, group, root, n_cols)
+            sol = lsap.solve_core(M, info)
+            if sol is not None and lsap.certify(M, *sol, info=info):
+                out[0] = sol[2]
+                if local_twin is not None:
+                    Mt = ShardedMatrix(locals_, 1, bounds, group, root, n_cols)
+                    tinfo = {} if info is not None else None
+                    if lsap.certify(Mt, *sol, info=tinfo):
+                        out[1] = sol[2]
+                    if info is not None:
+                        info["twin"] = tinfo
+        except Exception as e:                            # the workers are waiting for queries: release them, then raise everywhere
+            out[2] = "%s: %s" % (type(e).__name__, e)
+        finally:
+            ShardedMatrix(locals_, 0, bounds, group, root, n_cols).stop()
+    else:
+        serve(locals_, bounds, group, root)
+    box = [out]
+    dist.broadcast_object_list(box, src=_global(group, root), group=group)
+    if box[0][2] is not None:
+        raise RuntimeError("sharded assignment failed on rank %d: %s" % (root, box[0][2]))
+    return box[0][0], box[0][1]

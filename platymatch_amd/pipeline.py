@@ -238,12 +238,19 @@ def cost_row_argmins(be, mov, fix, rows_per_block=None, group=None):
     return all_gather_rows(idx, bn, 1, group)
 
 
-def assign(U_loc, bounds, group=None, info=None):
+SHARDED_ASSIGN_MIN_ROWS = 1024     # below this the gather + dense host solve is quicker than the sharded solve's round trips
+
+
+def assign(U_loc, bounds, group=None, info=None, local_matrix=None):
     """linear_sum_assignment on each of the eight matrices (_dock_widget.py:604-611) -> list of
     (row_ind, col_ind) int64 arrays, identical on every rank.  On a GPU the matrices never leave HBM: a sparse core
     of each is solved on the host and certified against every entry on the device (lsap.solve_on_device; tied or small
     matrices fall back to SciPy's algorithm restated in C++, lsap.linear_sum_assignment: identical indices either way).
-    Sharded, hypothesis h is assembled and solved on rank h mod G.  info (dict): which route each hypothesis took."""
+    Sharded: the matrices stay where the cost build left them — row blocks on their ranks — and only the sparse core's
+    candidates, the column duals and the certificate's counters travel (lsap_sharded.py; N <= M); a hypothesis that cannot
+    be certified that way (ties, non-finite costs, N > M, small clouds) is assembled on rank h mod G and solved there.
+    info (dict): which route each hypothesis took.  local_matrix: how to query a rank's block (default: lsap.DeviceMatrix
+    for GPU tensors; the CPU tests pass a NumPy double)."""
     import torch
     from .lsap import solve_eight_on_device, solve_on_device
     rank, world = _world(group)
@@ -255,9 +262,30 @@ def assign(U_loc, bounds, group=None, info=None):
         return solve_many([U_loc[h].numpy() for h in range(8)])
     dist = _dist()
     n = bounds[-1]
+    done = {}
+    if local_matrix is None and U_loc.is_cuda:
+        from .lsap import DeviceMatrix as local_matrix
+    if local_matrix is not None and n <= U_loc.shape[2] and n >= SHARDED_ASSIGN_MIN_ROWS:
+        from .lsap import TWINS
+        from .lsap_sharded import solve_pair_sharded
+        routes = {}
+        for twin, h in sorted(TWINS.items(), key=lambda kv: kv[1]):
+            pinfo = {} if info is not None else None
+            c_h, c_t = solve_pair_sharded(local_matrix(U_loc[h]), local_matrix(U_loc[twin]), bounds, U_loc.shape[2], group, h % world, pinfo)
+            rows = np.arange(n, dtype=np.int64)
+            if c_h is not None:
+                done[h] = (rows, np.asarray(c_h, dtype=np.int64))
+                routes[h] = "sharded device"
+            if c_t is not None:
+                done[twin] = (rows, np.asarray(c_t, dtype=np.int64))
+                routes[twin] = "sharded device (sibling's duals certified)"
+        if info is not None:
+            info["routes"] = [routes.get(h, "gathered") for h in range(8)]
     biggest = max(bounds[g + 1] - bounds[g] for g in range(world))
     mine = {}
     for h in range(8):
+        if h in done:
+            continue
         owner = h % world
         padded = torch.zeros((biggest, U_loc.shape[2]), dtype=U_loc.dtype, device=U_loc.device)
         padded[:U_loc.shape[1]].copy_(U_loc[h])
@@ -292,6 +320,9 @@ def assign(U_loc, bounds, group=None, info=None):
     k = min(n, U_loc.shape[2])
     out = []
     for h in range(8):
+        if h in done:
+            out.append(done[h])
+            continue
         buf = torch.zeros((2, k), dtype=torch.int64, device=U_loc.device)
         if h in mine:
             buf[0] = torch.as_tensor(mine[h][0], device=U_loc.device)
@@ -452,7 +483,8 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             raise
         t0 = mark("gpu_descriptors_costs", t0)
         try:
-            lsa = assign(U, bn, group, info=None if details is None else details.setdefault("assignment", {}))
+            lsa = assign(U, bn, group, info=None if details is None else details.setdefault("assignment", {}),
+                         local_matrix=getattr(be, "local_matrix", None))
         finally:
             del U
             t0 = mark("host_assignment", t0)

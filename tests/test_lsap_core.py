@@ -40,7 +40,11 @@ class HostMatrix:
         return cols, costs, int(not np.isfinite(self.U).all())
 
     def diagonal(self, n):
-        return self.U[np.arange(n), np.arange(n)].copy()
+        return self.block_diagonal(0)[:n]
+
+    def block_diagonal(self, row0):
+        r = np.arange(max(0, min(self.U.shape[0], self.U.shape[1] - row0)))
+        return self.U[r, r + row0].copy()
 
     def col_min(self):
         self.passes += 1

@@ -170,6 +170,10 @@ def _worker(rank, world, port, name, out_path):
         be = OracleBackend()
         if variant == "general":             # as if some row sat on a sector edge: all four frames must travel
             be.symmetry_flag = lambda sc_m, sc_f: (SYMMETRY_SEEN.append(False), torch.tensor([1], dtype=torch.int32))[1]
+        if variant == "sharded_lsap":        # the assignment with the matrices left on their ranks (lsap_sharded.py), NumPy double for the kernels
+            from test_lsap_core import HostMatrix
+            P.SHARDED_ASSIGN_MIN_ROWS = 0
+            be.local_matrix = lambda U2d: HostMatrix(U2d.numpy())
         det = {}
         A_sc, A_icp, inl = P.estimate_transform(d["moving"], d["fixed"], ransac_trials=int(d["ransac_trials"]),
                                                 ransac_error=float(d["ransac_error"]), icp_iterations=int(d["icp_iters"]),
@@ -183,12 +187,13 @@ def _worker(rank, world, port, name, out_path):
         amin = P.cost_row_argmins(be, mov, fix, 29, dist.group.WORLD)          # streamed in slabs, gathered
         np.savez(out_path % rank, A_sc=np.asarray(A_sc), A_icp=np.asarray(A_icp), inl=inl, residuals=det["residuals"],
                  lsa_cols=np.stack([c for _, c in det["lsa"]]), U=U.numpy(), bounds=np.array(bn), amin=amin.numpy(),
-                 sym=np.array(SYMMETRY_SEEN))
+                 sym=np.array(SYMMETRY_SEEN), routes=np.array(det.get("assignment", {}).get("routes", ["?"] * 8)))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["synth96x128", "insitu02_affine", "synth96x128|general"])
+@pytest.mark.parametrize("name", ["synth96x128", "insitu02_affine", "synth96x128|general", "synth96x128|sharded_lsap",
+                                  "insitu02_affine|sharded_lsap"])
 def test_two_rank_pipeline_matches_single_process(tmp_path, oracle, name):
     world = 2
     out = str(tmp_path / "rank%d.npz")
@@ -198,6 +203,9 @@ def test_two_rank_pipeline_matches_single_process(tmp_path, oracle, name):
     d = load_golden(name)
     # the frame-1-only gather was taken (generic data) unless the variant forbids it; both ranks decided alike
     assert len(r0["sym"]) > 0 and np.array_equal(r0["sym"], r1["sym"]) and bool(r0["sym"].all()) == (variant != "general")
+    if variant == "sharded_lsap":            # no matrix was gathered: every hypothesis certified where it lay
+        assert all(str(x).startswith("sharded device") for x in r0["routes"]), r0["routes"]
+        assert np.array_equal(r0["routes"], r1["routes"])
     # every rank returns the same thing
     for k in ("A_sc", "A_icp", "inl", "lsa_cols", "residuals", "amin"):
         assert np.array_equal(r0[k], r1[k]), k

@@ -5,7 +5,7 @@ run of the same call — assignment vectors and inlier counts identical, 4x4 mat
 sharded ICP.  (The N-GPU run over RCCL is the driver's; this checks the code path, not the speed.)
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
-        tools/two_rank_registration.py [N]"""
+        tools/two_rank_registration.py [N [M]]"""
 import os
 import sys
 
@@ -25,7 +25,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
-mv, fx, _ = synth_pair(n, 77, m=n - 37)
+m = int(sys.argv[2]) if len(sys.argv) > 2 else n - 37       # N > M by default (assignment by gather); pass M >= N for the sharded solve
+mv, fx, _ = synth_pair(max(n, m), 77, m=m)
+mv = np.ascontiguousarray(mv[:, :n])
 kw = dict(ransac_trials=500, ransac_error=8.0, icp_iterations=12, seed=4)
 ok = True
 for shard_icp in (False, True):
@@ -40,6 +42,7 @@ for shard_icp in (False, True):
         res = np.abs(det["residuals"] - ref_det["residuals"]).max()
         good = same_lsa and np.array_equal(got[2], ref[2]) and err_sc == 0.0 and err_f < 1e-9 and res < 1e-9
         ok &= good
+        print("assignment routes:", det.get("assignment", {}).get("routes"), flush=True)
         print("ICP %s: assignments identical %s, inliers identical %s, A_sc identical %s, final rel. diff %.1e, residual diff %.1e -> %s"
               % ("sharded" if shard_icp else "replicated", same_lsa, np.array_equal(got[2], ref[2]), err_sc == 0.0, err_f, res,
                  "OK" if good else "MISMATCH"), flush=True)
