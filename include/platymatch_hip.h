@@ -146,6 +146,13 @@ int pm_chi2_symmetry_check(const double *sc_m1, const double *sc_m2, int nM, con
 int pm_chi2_cost8_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
                       size_t matrix_stride, void *stream);
 
+/* One hypothesis and its twin only (pairing t = 0..3: U11/U22, U12/U21, U13/U24, U14/U23 — the same terms summed in two
+ * orders): out2 + 0*matrix_stride = the natural-order matrix (U11, U12, U13, U14), out2 + 1*matrix_stride = the rolled-order
+ * one (U22, U21, U24, U23).  Same bits as the corresponding two matrices of pm_chi2_cost8_sym at a quarter of its work; for
+ * clouds whose eight matrices do not fit in HBM together (64 N M bytes) but two do.  Same precondition (symmetry flag 0). */
+int pm_chi2_cost_pair_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out2, size_t ld,
+                          size_t matrix_stride, void *stream);
+
 /* np.argmin(U_h, axis=1) for n_mat stacked cost matrices (U_h = U + h*matrix_stride, rows x cols, leading
  * dimension ld): idx[h*rows + i] = first index of the minimum of row i, or of the first NaN if the row holds one
  * (NumPy's rule); val (may be NULL) receives the minimum itself.  This is the per-row check BASELINE.json's

@@ -259,6 +259,35 @@ def chi2_cost8_frame1(sc_m1, sc_f1, out=None):
     return out
 
 
+PAIRINGS = ((0, 5), (1, 4), (2, 7), (3, 6))      # pairing t -> (hypothesis summed in natural order, its twin), widget numbering
+
+
+def chi2_cost_pair(sc_m, sc_f, pairing, symmetric, out=None):
+    """The two cost matrices of pairing t (PAIRINGS[t]: U11/U22, U12/U21, U13/U24, U14/U23) alone -> [2, nM, nF]: what a cloud
+    whose eight matrices do not fit in HBM together is assigned from, two at a time.  symmetric (the frame-permutation
+    relation was verified: chi2_symmetric): one launch of the half-cost kernel restricted to that pairing, sc_f may hold
+    frame 1 only; otherwise two launches of the general kernel on the frames themselves.  Same bits as chi2_cost8's rows."""
+    torch = _t()
+    t = int(pairing)
+    if t not in (0, 1, 2, 3):
+        raise ValueError("pairing must be 0..3")
+    nM, nF = sc_m.shape[1], sc_f.shape[1]
+    if out is None:
+        out = torch.empty((2, nM, nF), dtype=torch.float64, device=sc_m.device)
+    elif not (out.is_cuda and out.dtype == torch.float64 and tuple(out.shape) == (2, nM, nF) and out.is_contiguous()):
+        raise ValueError("out must be a contiguous float64 GPU tensor [2, nM, nF]")
+    if symmetric:
+        a, b = _desc(sc_m[0], "sc_m[0]"), _desc(sc_f[0], "sc_f[0]")
+        check(nat.load().pm_chi2_cost_pair_sym(ptr(a), nM, ptr(b), nF, t, ptr(out), out.stride(1), out.stride(0), nat.stream_ptr()))
+    else:
+        if sc_f.shape[0] != 4 or sc_m.shape[0] != 2:
+            raise ValueError("the general path needs all frames: sc_m [2, nM, 360], sc_f [4, nF, 360]")
+        twin_fixed = (1, 0, 3, 2)[t]                     # U22, U21, U24, U23: moving frame 2 against fixed frame 2, 1, 4, 3
+        chi2_cost(sc_m[0], sc_f[t], out=out[0])
+        chi2_cost(sc_m[1], sc_f[twin_fixed], out=out[1])
+    return out
+
+
 def _out8(out, nM, nF, device):
     torch = _t()
     if out is None:

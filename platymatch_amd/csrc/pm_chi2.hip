@@ -154,7 +154,10 @@ int chi2_launch(const Chi2Args<NFA, NFB> &args, int nA, int nB, double *out, siz
 // computed once and added into both running sums in the reference's order, so all eight matrices stay
 // bit-identical to the general kernel at half its divisions.  Whether the permutation relation holds
 // for the given descriptor arrays is CHECKED bit for bit by symmetry_check_kernel, never assumed.
-template <int SY_RI, int MINW>            // rows per wave; minimum waves per SIMD asked of the register allocator
+// TSEL = -1: all four pairings -> eight matrices in the widget's order; TSEL = t: pairing t alone -> its two matrices
+// (natural order first, rolled order second): the cost build of ONE hypothesis and its twin, for clouds whose eight
+// matrices do not fit in HBM together (each pairing's terms are exactly a quarter of the eight-matrix launch).
+template <int SY_RI, int MINW, int TSEL = -1>   // rows per wave; minimum waves per SIMD asked of the register allocator; pairing
 __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double *__restrict__ scA, int nA,
                                                                  const double *__restrict__ scB, int nB,
                                                                  double *__restrict__ out, size_t ld, size_t mstride,
@@ -172,11 +175,12 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    double acc[SY_RI][8];
+    constexpr int NH = (TSEL < 0) ? 8 : 2;
+    double acc[SY_RI][NH];
 #pragma unroll
     for (int r = 0; r < SY_RI; ++r)
 #pragma unroll
-        for (int h = 0; h < 8; ++h) acc[r][h] = 0.0;
+        for (int h = 0; h < NH; ++h) acc[r][h] = 0.0;
 
     for (int g = 0; g < CH_STAGES; ++g) {
         __syncthreads();
@@ -208,8 +212,9 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (TSEL >= 0 && t != TSEL) continue;
                 // pairing t: B index for A index p; natural-order matrix, rolled-order matrix (widget numbering 0..7)
-                const int hn = t, hr = (t == 0) ? 5 : (t == 1) ? 4 : (t == 2) ? 7 : 6;
+                const int hn = (TSEL < 0) ? t : 0, hr = (TSEL >= 0) ? 1 : (t == 0) ? 5 : (t == 1) ? 4 : (t == 2) ? 7 : 6;
                 double T[CH_K];
 #pragma unroll
                 for (int p = 0; p < CH_K; ++p) {
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
             const int gi = i0 + wave * SY_RI + r;
             if (gi < nA) {
 #pragma unroll
-                for (int h = 0; h < 8; ++h) out[(size_t)h * mstride + (size_t)gi * ld + gj] = 0.5 * acc[r][h];
+                for (int h = 0; h < NH; ++h) out[(size_t)h * mstride + (size_t)gi * ld + gj] = 0.5 * acc[r][h];
             }
         }
     }
@@ -272,16 +277,31 @@ extern "C" int pm_chi2_symmetry_check(const double *sc_m1, const double *sc_m2, 
 }
 
 namespace pm {
-template <int RI, int MINW>
+template <int RI, int MINW, int TSEL = -1>
 int chi2_sym_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld, size_t mstride, hipStream_t s) {
     const long nTi = ((long)nM + 4 * RI - 1) / (4 * RI), nTj = ((long)nF + CH_TJ - 1) / CH_TJ;
     const long nblocks = nTi * nTj;
     if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
-    chi2_sym_kernel<RI, MINW><<<(unsigned int)nblocks, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, mstride, (int)nTi,
-                                                                          (unsigned int)nblocks);
+    chi2_sym_kernel<RI, MINW, TSEL><<<(unsigned int)nblocks, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, mstride, (int)nTi,
+                                                                                (unsigned int)nblocks);
     return launch_status();
 }
 }  // namespace pm
+
+extern "C" int pm_chi2_cost_pair_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out2, size_t ld,
+                                     size_t matrix_stride, void *stream) {
+    if (!sc_m1 || !sc_f1 || !out2 || nM <= 0 || nF <= 0 || ld < (size_t)nF || matrix_stride < (size_t)nM * ld)
+        return PM_ERR_INVALID_ARG;
+    if (((uintptr_t)sc_f1 & 15) != 0 || ((uintptr_t)sc_m1 & 15) != 0) return PM_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (pairing) {
+        case 0: return pm::chi2_sym_launch<4, 2, 0>(sc_m1, nM, sc_f1, nF, out2, ld, matrix_stride, s);
+        case 1: return pm::chi2_sym_launch<4, 2, 1>(sc_m1, nM, sc_f1, nF, out2, ld, matrix_stride, s);
+        case 2: return pm::chi2_sym_launch<4, 2, 2>(sc_m1, nM, sc_f1, nF, out2, ld, matrix_stride, s);
+        case 3: return pm::chi2_sym_launch<4, 2, 3>(sc_m1, nM, sc_f1, nF, out2, ld, matrix_stride, s);
+        default: return PM_ERR_INVALID_ARG;
+    }
+}
 
 // tuning hook (not part of the public ABI): same result from differently shaped launches
 extern "C" int pm_chi2_cost8_sym_variant(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,

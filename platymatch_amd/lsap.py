@@ -283,46 +283,64 @@ def solve_on_device(U, info=None, force=False):
     return linear_sum_assignment(U.cpu().numpy())
 
 
+DENSE_FALLBACK_MAX_ENTRIES = 1 << 30      # matrices above this many entries are never handed to the dense host solver (hours)
+
+
+def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=True):
+    """One hypothesis and its twin (the same terms summed in another order: U11/U22, U12/U21, U13/U24, U14/U23), both float64
+    GPU matrices [N, M]: the hypothesis is solved on its sparse core and certified; the twin first tries its sibling's duals —
+    accepted only if they are a certified unique optimum of the twin's OWN entries — and is solved on its own otherwise.
+    -> [(row_ind, col_ind) or None, (row_ind, col_ind) or None]; None only with allow_host=False (or a matrix too large for
+    the dense solver): the hypothesis could not be certified and the dense host solver was not allowed."""
+    n, m = U_h.shape
+    info_h = {} if info_h is None else info_h
+    info_twin = {} if info_twin is None else info_twin
+    host_ok = allow_host and n * m <= DENSE_FALLBACK_MAX_ENTRIES
+    refused = "uncertified (dense solver not allowed)" if not allow_host else "uncertified (too large for the dense solver)"
+    if min(n, m) < DEVICE_MIN_ROWS:
+        info_h["route"] = info_twin["route"] = "host"
+        return [linear_sum_assignment(U_h.cpu().numpy()), linear_sum_assignment(U_twin.cpu().numpy())]
+    out = [None, None]
+    W = DeviceMatrix(U_h if n <= m else U_h.t().contiguous())
+    sol = solve_core(W, info_h)
+    if sol is not None and certify(W, *sol, info=info_h):
+        info_h["route"] = "device"
+        out[0] = _answer(sol[2], n, m)
+        Wt = DeviceMatrix(U_twin if n <= m else U_twin.t().contiguous())
+        if certify(Wt, *sol, info=info_twin):
+            info_twin["route"] = "device (sibling's duals certified)"
+            out[1] = out[0]
+            return out
+    elif host_ok:
+        info_h["route"] = "host"
+        out[0] = linear_sum_assignment(U_h.cpu().numpy())
+    else:
+        info_h["route"] = refused
+    # the twin on its own
+    Wt = DeviceMatrix(U_twin if n <= m else U_twin.t().contiguous())
+    sol_t = solve_core(Wt, info_twin)
+    if sol_t is not None and certify(Wt, *sol_t, info=info_twin):
+        info_twin["route"] = "device"
+        out[1] = _answer(sol_t[2], n, m)
+    elif host_ok:
+        info_twin["route"] = "host"
+        out[1] = linear_sum_assignment(U_twin.cpu().numpy())
+    else:
+        info_twin["route"] = refused
+    return out
+
+
 def solve_eight_on_device(U8, info=None, allow_host=True):
     """The widget's eight assignments (_dock_widget.py:604-611) for U8 [8, N, M] on the GPU: hypotheses 11, 12, 13, 14 are
-    solved (four host threads drive their core solves and kernels concurrently); each twin (22, 21, 24, 23: the same terms
-    summed in another order) first tries its sibling's duals — accepted only if they are a certified unique optimum of the
-    twin's OWN matrix — and is solved on its own otherwise.  -> list of eight (row_ind, col_ind).
+    solved (four host threads drive their core solves and kernels concurrently), each together with its twin (22, 21, 24,
+    23: solve_pair_on_device).  -> list of eight (row_ind, col_ind).
     allow_host=False: never take the dense host solver (hours at 50 000 nuclei); a hypothesis that cannot be certified comes
     back as None instead (bench.py's bounded extra leg)."""
     torch = nat.torch_mod()
     n, m = U8.shape[1], U8.shape[2]
     out = [None] * 8
     infos = [dict() for _ in range(8)]
-    small = min(n, m) < DEVICE_MIN_ROWS
-
-    def pair(h):
-        stream = torch.cuda.Stream(device=U8.device)
-        with torch.cuda.device(U8.device), torch.cuda.stream(stream):
-            twin = [t for t, s in TWINS.items() if s == h][0]
-            W = DeviceMatrix(U8[h] if n <= m else U8[h].t().contiguous())
-            sol = None if small else solve_core(W, infos[h])
-            ok = sol is not None and certify(W, *sol, info=infos[h])
-            if ok:
-                infos[h]["route"] = "device"
-                out[h] = _answer(sol[2], n, m)
-                Wt = DeviceMatrix(U8[twin] if n <= m else U8[twin].t().contiguous())
-                if certify(Wt, *sol, info=infos[twin]):
-                    infos[twin]["route"] = "device (sibling's duals certified)"
-                    out[twin] = out[h]
-                elif allow_host:
-                    out[twin] = solve_on_device(U8[twin], infos[twin])
-                else:
-                    infos[twin]["route"] = "uncertified (dense solver not allowed)"
-            elif not allow_host:        # bounded mode: report, do not spend hours on the dense solver
-                infos[h]["route"] = infos[twin]["route"] = "uncertified (dense solver not allowed)"
-            else:
-                infos[h]["route"] = "host"
-                out[h] = linear_sum_assignment(U8[h].cpu().numpy())
-                out[twin] = solve_on_device(U8[twin], infos[twin]) if not small else linear_sum_assignment(U8[twin].cpu().numpy())
-            stream.synchronize()
-
-    if small:       # eight dense host solves on eight threads, each fetching its own matrix (the round-1 path)
+    if min(n, m) < DEVICE_MIN_ROWS:       # eight dense host solves on eight threads, each fetching its own matrix (the round-1 path)
         stream = torch.cuda.current_stream(U8.device)
 
         def fetch(h):
@@ -332,6 +350,14 @@ def solve_eight_on_device(U8, info=None, allow_host=True):
         if info is not None:
             info["routes"] = ["host"] * 8
         return res
+
+    def pair(h):
+        twin = [t for t, s in TWINS.items() if s == h][0]
+        stream = torch.cuda.Stream(device=U8.device)
+        with torch.cuda.device(U8.device), torch.cuda.stream(stream):
+            out[h], out[twin] = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], allow_host)
+            stream.synchronize()
+
     torch.cuda.current_stream(U8.device).synchronize()      # U8 was produced on the caller's stream
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(pair, range(4)))

@@ -64,6 +64,16 @@ class GpuBackend:
             return self.K.chi2_cost8_frame1(sc_m[0], sc_f[0], out=out)
         return self.K.chi2_cost8(sc_m, sc_f, out=out)
 
+    def chi2_cost_pair(self, sc_m, sc_f, pairing, out=None):
+        """The two matrices of one pairing (hypothesis + twin) only -> [2, rows, M]; symmetric iff sc_f holds frame 1 only or
+        the permutation relation checks out (symmetric_hint caches the check of the whole-cloud call)."""
+        sym = sc_f.shape[0] == 1 or self.K.chi2_symmetric(sc_m, sc_f)
+        return self.K.chi2_cost_pair(sc_m, sc_f, pairing, sym, out=out)
+
+    def free_bytes(self):
+        import torch
+        return torch.cuda.mem_get_info(self.device)[0]
+
     def row_argmin(self, U):
         return self.K.row_argmin(U)
 
@@ -201,6 +211,47 @@ def build_costs(be, mov, fix, group=None):
     """Descriptors + the eight chi-square matrices for this rank's moving rows -> (U [8, rows_g, M], bounds)."""
     sc_m, sc_f, bn = build_descriptors(be, mov, fix, group)
     return be.chi2_cost8(sc_m, sc_f), bn
+
+
+def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=None):
+    """Cost matrices and assignments two matrices at a time, for clouds whose eight matrices (64 N M bytes per rank-block) do not
+    fit in HBM together: for each pairing t the hypothesis and its twin are built (be.chi2_cost_pair: a quarter of the
+    eight-matrix launch, the same bits), assigned with the matrices resident (one GPU: lsap.solve_pair_on_device; sharded:
+    lsap_sharded.solve_pair_sharded, nothing gathered) and released.  -> list of eight (row_ind, col_ind), widget order.
+    A hypothesis that can be neither certified nor (for its size) handed to the dense solver raises."""
+    from . import lsap
+    rank, world = _world(group)
+    n, m = bounds[-1], sc_f.shape[1]
+    out = [None] * 8
+    routes = [None] * 8
+    buf = None
+    for t, (h, twin) in enumerate(((0, 5), (1, 4), (2, 7), (3, 6))):
+        U2 = be.chi2_cost_pair(sc_m, sc_f, t, out=buf)
+        buf = U2
+        ih, it = {}, {}
+        if world == 1:
+            got = lsap.solve_pair_on_device(U2[0], U2[1], ih, it)
+            routes[h], routes[twin] = ih.get("route"), it.get("route")
+        else:
+            from .lsap_sharded import solve_pair_sharded
+            lm = local_matrix or lsap.DeviceMatrix
+            if n > m:
+                raise NotImplementedError("sharded streamed assignment needs N <= M (rows are the sharded side)")
+            c_h, c_t = solve_pair_sharded(lm(U2[0]), lm(U2[1]), bounds, m, group, h % world, ih)
+            rows = np.arange(n, dtype=np.int64)
+            got = [None if c_h is None else (rows, np.asarray(c_h, dtype=np.int64)),
+                   None if c_t is None else (rows, np.asarray(c_t, dtype=np.int64))]
+            routes[h] = "sharded device" if c_h is not None else "uncertified"
+            routes[twin] = "sharded device (sibling's duals certified)" if c_t is not None else "uncertified"
+        for idx, g in zip((h, twin), got):
+            if g is None:
+                raise RuntimeError("hypothesis %s: the assignment could not be certified unique (ties or non-finite costs) and the "
+                                   "matrix is too large for the dense solver" % HYPOTHESES[idx])
+            out[idx] = g
+    if info is not None:
+        info["routes"] = routes
+        info["mode"] = "streamed: two matrices resident at a time"
+    return out
 
 
 def iter_cost_blocks(be, mov, fix, rows_per_block, group=None):
@@ -441,7 +492,7 @@ class _SampleDraws:
 
 def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
                        ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, group=None,
-                       backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS, private_rng=False):
+                       backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS, private_rng=False, stream_hypotheses=None):
     """Reproduces _dock_widget.py:526-718 -> (A_sc, A_icp, inliers[8]); final transform = A_icp @ A_sc (:428).
 
     moving, fixed   3 x N / 3 x M float64 (rows z, y, x), NumPy or torch
@@ -455,6 +506,8 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     group           torch.distributed process group to shard over (None = this GPU only); every rank
                     passes the same clouds and gets the same results
     icp_shard_min_points  moving-cloud size from which ICP is sharded too (below it every rank runs it whole)
+    stream_hypotheses     None: build all eight cost matrices at once if they fit in HBM (64 N M bytes), else two at a time
+                          (assign_streamed); True / False force one or the other
     details         optional dict filled with intermediate results (lsa, ransac_A, residuals)
     """
     import time
@@ -476,17 +529,25 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     if mode == 'unsupervised':
         # what do_ransac draws depends only on the number of matched pairs: start drawing before the GPU has built anything
         draws = _SampleDraws(be, min(mov.shape[1], fix.shape[1]), int(ransac_samples), int(ransac_trials), seed, private_rng)
+        a_info = None if details is None else details.setdefault("assignment", {})
         try:
-            U, bn = build_costs(be, mov, fix, group)
+            sc_m, sc_f, bn = build_descriptors(be, mov, fix, group)
+            # all eight matrices at once when they fit (four assignments then run side by side); otherwise two at a time
+            need = 64.0 * sc_m.shape[1] * sc_f.shape[1]
+            streamed = stream_hypotheses if stream_hypotheses is not None else (
+                hasattr(be, "free_bytes") and hasattr(be, "chi2_cost_pair") and need > 0.85 * be.free_bytes())
+            U = None if streamed else be.chi2_cost8(sc_m, sc_f)
         except BaseException:
             draws.thread.join()
             raise
         t0 = mark("gpu_descriptors_costs", t0)
         try:
-            lsa = assign(U, bn, group, info=None if details is None else details.setdefault("assignment", {}),
-                         local_matrix=getattr(be, "local_matrix", None))
+            if streamed:
+                lsa = assign_streamed(be, sc_m, sc_f, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None))
+            else:
+                lsa = assign(U, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None))
         finally:
-            del U
+            del U, sc_m, sc_f
             t0 = mark("host_assignment", t0)
             sets = draws.result()                    # every rank draws the same 8 x trials: same RNG stream everywhere
             t0 = mark("host_draws_exposed", t0)

@@ -168,3 +168,46 @@ def test_fuzz_of_distributions_and_shapes_against_scipy(dev):
         assert np.array_equal(r, rs) and np.array_equal(c, cs), (trial, kind, n, m, info)
         routes[info["route"]] += 1
     assert routes["device"] >= 60, routes                              # generic matrices are certified; ties go to the host
+
+
+def test_pairing_cost_kernel_equals_the_eight_matrix_launch(dev):
+    """One hypothesis and its twin at a time (pm_chi2_cost_pair_sym / the general kernel twice) against the rows of the
+    eight-matrix build, bit for bit, on generic descriptors and on a set that breaks the frame-permutation relation."""
+    import torch
+    from platymatch_amd import _kernels as K, pipeline as P
+    mv, fx, _ = synth_pair(700, 31)
+    be = P.GpuBackend()
+    sc_m, sc_f, _ = P.build_descriptors(be, be.cloud(mv), be.cloud(fx[:, :650]))
+    U8 = K.chi2_cost8(sc_m, sc_f)
+    assert K.chi2_symmetric(sc_m, sc_f)
+    for t, (h, twin) in enumerate(K.PAIRINGS):
+        for sym in (True, False):
+            U2 = K.chi2_cost_pair(sc_m, sc_f, t, sym)
+            assert torch.equal(U2[0], U8[h]) and torch.equal(U2[1], U8[twin]), (t, sym)
+        U2f = K.chi2_cost_pair(sc_m[:1], sc_f[:1], t, True)                    # frame 1 only is enough for the half-cost path
+        assert torch.equal(U2f[0], U8[h]) and torch.equal(U2f[1], U8[twin])
+    broken = sc_f.clone()
+    broken[2, 5, 7] += 0.25                                                     # frame 3 no longer a permutation of frame 1
+    assert not K.chi2_symmetric(sc_m, broken)
+    U8b = K.chi2_cost8(sc_m, broken)
+    for t, (h, twin) in enumerate(K.PAIRINGS):
+        U2 = be.chi2_cost_pair(sc_m, broken, t)
+        assert torch.equal(U2[0], U8b[h]) and torch.equal(U2[1], U8b[twin]), t
+
+
+def test_streamed_hypotheses_give_the_same_registration(dev):
+    """estimate_transform with two cost matrices resident at a time (the mode for clouds whose eight matrices exceed HBM)
+    against the default: assignment vectors, inlier counts and 4x4 matrices identical."""
+    from platymatch_amd import pipeline as P
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    mv, fx, _ = synth_pair(1700, 33)
+    kw = dict(ransac_trials=400, ransac_error=16, icp_iterations=10, seed=2)
+    for fixed in (fx[:, :1650], fx):                                            # N > M and N == M
+        d0, d1 = {}, {}
+        a = P.estimate_transform(mv, fixed, details=d0, stream_hypotheses=False, **kw)
+        b = P.estimate_transform(mv, fixed, details=d1, stream_hypotheses=True, **kw)
+        assert d1["assignment"]["mode"].startswith("streamed")
+        for h in range(8):
+            assert np.array_equal(d0["lsa"][h][0], d1["lsa"][h][0]) and np.array_equal(d0["lsa"][h][1], d1["lsa"][h][1]), h
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -29,10 +29,12 @@ m = int(sys.argv[2]) if len(sys.argv) > 2 else n - 37       # N > M by default (
 mv, fx, _ = synth_pair(max(n, m), 77, m=m)
 mv = np.ascontiguousarray(mv[:, :n])
 kw = dict(ransac_trials=500, ransac_error=8.0, icp_iterations=12, seed=4)
+streamed = os.environ.get("PM_STREAM_HYPOTHESES") == "1"       # two cost matrices resident at a time on every rank (config 4's mode)
 ok = True
 for shard_icp in (False, True):
     det = {}
-    got = P.estimate_transform(mv, fx, group=dist.group.WORLD, details=det, icp_shard_min_points=0 if shard_icp else 10 ** 9, **kw)
+    got = P.estimate_transform(mv, fx, group=dist.group.WORLD, details=det, icp_shard_min_points=0 if shard_icp else 10 ** 9,
+                               stream_hypotheses=True if streamed else None, **kw)
     if rank == 0:
         ref_det = {}
         ref = P.estimate_transform(mv, fx, details=ref_det, **kw)
