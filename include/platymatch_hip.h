@@ -187,6 +187,12 @@ int pm_lsap_solve(const double *cost, long nr, long nc, int64_t *rows, int64_t *
 int pm_lsap_row_select(const double *U, int nr, int nc, size_t ld, const double *v, int k, int32_t *out_col,
                        double *out_cost, int32_t *nonfinite1, void *stream);
 
+/* DEVICE: bids of the listed rows (rows[n_rows], each in [0, nr) — the CALLER checks the range) against prices v: per row the
+ * column j1 with the smallest U[i][j] - v[j] (lowest column on ties), that value u1, and the row's second smallest value u2.
+ * The Jacobi form of the augmenting row reduction that warms up a solve on the dense rows: lsap._row_reduction. */
+int pm_lsap_bid(const double *U, int nr, int nc, size_t ld, const double *v, const int32_t *rows, int n_rows,
+                int32_t *out_j1, double *out_u1, double *out_u2, void *stream);
+
 /* DEVICE: column minima v[j] = min_i U[i][j] — the column reduction a square solve starts its duals from. */
 size_t pm_lsap_col_min_workspace(int nr, int nc);
 int pm_lsap_col_min(const double *U, int nr, int nc, size_t ld, double *v, void *ws, size_t ws_bytes, void *stream);
@@ -213,6 +219,9 @@ void *pm_lsap_core_create(int nr, int nc);
  * or later, cost - v[col] >= u[row]; u[nr] = each row's minimum of cost - v[col] over the DENSE row (pm_lsap_row_select's
  * rank-0 entry).  Rows whose minimising column is still free are matched to it at once (a tight edge).  nr == nc only. */
 int pm_lsap_core_init_duals(void *core, const double *u, const double *v, const int32_t *argmin_col);
+/* Start from a given dual-feasible state with a partial matching (call before any solve, after the edges were added):
+ * u[nr], v[nc], col4row[nr] (-1 = free); every matched pair must be a core edge with cost - v[col] = u[row] (tight). */
+int pm_lsap_core_init_state(void *core, const double *u, const double *v, const int32_t *col4row);
 void pm_lsap_core_destroy(void *core);
 int pm_lsap_core_add(void *core, int k, const int32_t *cols, const double *costs);
 int pm_lsap_core_solve(void *core);

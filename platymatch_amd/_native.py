@@ -42,6 +42,8 @@ SIGNATURES = {
     "pm_lsap_col_min_workspace": (_c_size_t, [_c_int, _c_int]),
     "pm_lsap_col_min": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_lsap_core_init_duals": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_lsap_core_init_state": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_lsap_bid": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "pm_lsap_core_create": (_c_void_p, [_c_int, _c_int]),
     "pm_lsap_core_destroy": (None, [_c_void_p]),
     "pm_lsap_core_add": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),

@@ -407,6 +407,22 @@ int pm_lsap_core_init_duals(void *h, const double *u, const double *v, const int
     return PM_OK;
 }
 
+int pm_lsap_core_init_state(void *h, const double *u, const double *v, const int32_t *col4row) {
+    Core *c = static_cast<Core *>(h);
+    if (!c || !u || !v || !col4row || c->augmentations != 0) return PM_ERR_INVALID_ARG;
+    for (int j = 0; j < c->nc; ++j) { c->col[j].v = v[j]; c->row4col[j] = -1; }
+    for (int i = 0; i < c->nr; ++i) {
+        c->u[i] = u[i];
+        c->col4row[i] = -1;
+        const int j = col4row[i];
+        if (j < 0) continue;
+        if (j >= c->nc || c->row4col[j] >= 0 || !c->has_edge(i, j)) return PM_ERR_INVALID_ARG;
+        c->row4col[j] = i;
+        c->col4row[i] = j;
+    }
+    return PM_OK;
+}
+
 int pm_lsap_core_solve(void *h) {
     Core *c = static_cast<Core *>(h);
     if (!c) return PM_ERR_INVALID_ARG;

@@ -49,6 +49,58 @@ __global__ __launch_bounds__(LS_THREADS) void row_select_kernel(const double *__
     if (bad) nonfinite[0] = 1;
 }
 
+// Bids of a list of rows (the Jacobi form of Jonker & Volgenant's augmenting row reduction, run on the DENSE rows): for
+// row i = rows[b]: j1 = the column minimising red = U[i][j] - v[j] (lowest column on ties), u1 = that minimum, u2 = the
+// second smallest red of the row (= u1 if two columns tie).  One workgroup per listed row; every thread keeps its two
+// smallest over its interleaved columns, then the (min, column, second) triples are merged — the merge is exact: the second
+// smallest of a union is the smaller of the two seconds and the larger of the two firsts.
+struct Bid {
+    double m1, m2;
+    int c1;
+};
+__device__ __forceinline__ Bid bid_merge(const Bid &a, const Bid &b) {
+    Bid r;
+    const bool a_first = a.m1 < b.m1 || (a.m1 == b.m1 && a.c1 <= b.c1);
+    if (a_first) { r.m1 = a.m1; r.c1 = a.c1; r.m2 = fmin(a.m2, b.m1); }
+    else { r.m1 = b.m1; r.c1 = b.c1; r.m2 = fmin(b.m2, a.m1); }
+    return r;
+}
+
+__global__ __launch_bounds__(LS_THREADS) void bid_kernel(const double *__restrict__ U, int nc, size_t ld, const double *__restrict__ v,
+                                                         const int32_t *__restrict__ rows, int32_t *__restrict__ out_j1,
+                                                         double *__restrict__ out_u1, double *__restrict__ out_u2) {
+    __shared__ double s_m1[LS_THREADS / 64], s_m2[LS_THREADS / 64];
+    __shared__ int s_c1[LS_THREADS / 64];
+    const int tid = threadIdx.x;
+    const double *row = U + (size_t)rows[blockIdx.x] * ld;
+    Bid b = {INFINITY, INFINITY, 0x7fffffff};
+    for (int j = tid; j < nc; j += LS_THREADS) {
+        const double red = row[j] - v[j];
+        if (red < b.m1) { b.m2 = b.m1; b.m1 = red; b.c1 = j; }
+        else if (red < b.m2) b.m2 = red;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Bid o;
+        o.m1 = __shfl_xor(b.m1, off, 64);
+        o.m2 = __shfl_xor(b.m2, off, 64);
+        o.c1 = __shfl_xor(b.c1, off, 64);
+        b = bid_merge(b, o);
+    }
+    if ((tid & 63) == 0) { s_m1[tid >> 6] = b.m1; s_m2[tid >> 6] = b.m2; s_c1[tid >> 6] = b.c1; }
+    __syncthreads();
+    if (tid == 0) {
+        Bid t = {s_m1[0], s_m2[0], s_c1[0]};
+        for (int w = 1; w < LS_THREADS / 64; ++w) {
+            const Bid o = {s_m1[w], s_m2[w], s_c1[w]};
+            t = bid_merge(t, o);
+        }
+        out_j1[blockIdx.x] = (t.c1 == 0x7fffffff) ? -1 : t.c1;
+        out_u1[blockIdx.x] = t.m1;
+        out_u2[blockIdx.x] = t.m2;
+    }
+}
+
 // Column minima v[j] = min_i U[i][j] (the column reduction that starts a square solve from good duals): thread <-> column,
 // rows streamed in slabs so that the launch has enough workgroups; slab minima combined by a second tiny kernel.
 constexpr int CM_ROWS = 256;          // rows per slab
@@ -145,6 +197,14 @@ int pm_lsap_row_select(const double *U, int nr, int nc, size_t ld, const double 
     if (hipMemsetAsync(nonfinite1, 0, sizeof(int32_t), s) != hipSuccess) return pm::launch_status();
     if (v) pm::row_select_kernel<true><<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, v, k, out_col, out_cost, nonfinite1);
     else pm::row_select_kernel<false><<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, nullptr, k, out_col, out_cost, nonfinite1);
+    return pm::launch_status();
+}
+
+int pm_lsap_bid(const double *U, int nr, int nc, size_t ld, const double *v, const int32_t *rows, int n_rows, int32_t *out_j1,
+                double *out_u1, double *out_u2, void *stream) {
+    if (!U || !v || !rows || !out_j1 || !out_u1 || !out_u2 || nr <= 0 || nc <= 0 || ld < (size_t)nc || n_rows <= 0)
+        return PM_ERR_INVALID_ARG;
+    pm::bid_kernel<<<n_rows, pm::LS_THREADS, 0, (hipStream_t)stream>>>(U, nc, ld, v, rows, out_j1, out_u1, out_u2);
     return pm::launch_status();
 }
 

@@ -90,6 +90,11 @@ class _Core:
         costs = np.ascontiguousarray(costs, dtype=np.float64)
         nat.check(self.lib.pm_lsap_core_add(self.h, cols.shape[1], cols.ctypes.data, costs.ctypes.data))
 
+    def init_state(self, u, v, col4row):
+        u, v = np.ascontiguousarray(u, dtype=np.float64), np.ascontiguousarray(v, dtype=np.float64)
+        c = np.ascontiguousarray(col4row, dtype=np.int32)
+        nat.check(self.lib.pm_lsap_core_init_state(self.h, u.ctypes.data, v.ctypes.data, c.ctypes.data))
+
     def init_duals(self, u, v, argmin_col):
         u, v = np.ascontiguousarray(u, dtype=np.float64), np.ascontiguousarray(v, dtype=np.float64)
         a = np.ascontiguousarray(argmin_col, dtype=np.int32)
@@ -147,6 +152,32 @@ class DeviceMatrix:
         nr, nc = self.U.shape
         r = torch.arange(max(0, min(nr, nc - row0)), device=self.U.device)
         return self.U[r, r + row0].cpu().numpy()
+
+    def bid(self, v, rows):
+        """Bids of the listed rows against prices v -> (j1 int32, u1, u2) per row: pm_lsap_bid."""
+        torch = nat.torch_mod()
+        U = self.U
+        nr, nc = U.shape
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        if rows.size == 0:
+            return np.zeros(0, np.int32), np.zeros(0), np.zeros(0)
+        if rows.min() < 0 or rows.max() >= nr:
+            raise IndexError("row outside the matrix")
+        r_d = nat.to_dev(rows, dtype=torch.int32, dev=U.device)
+        v_d = nat.to_dev(v, dev=U.device)
+        j1 = torch.empty(rows.size, dtype=torch.int32, device=U.device)
+        u12 = torch.empty((2, rows.size), dtype=torch.float64, device=U.device)
+        nat.check(nat.load().pm_lsap_bid(nat.ptr(U), nr, nc, self.ld, nat.ptr(v_d), nat.ptr(r_d), int(rows.size), nat.ptr(j1),
+                                         nat.ptr(u12[0]), nat.ptr(u12[1]), nat.stream_ptr(U)))
+        u12_h = u12.cpu().numpy()
+        return j1.cpu().numpy(), u12_h[0], u12_h[1]
+
+    def entries(self, rows, cols):
+        """U[rows[k], cols[k]] on the host (exact costs of given pairs)."""
+        torch = nat.torch_mod()
+        r = torch.as_tensor(np.asarray(rows, dtype=np.int64), device=self.U.device)
+        c = torch.as_tensor(np.asarray(cols, dtype=np.int64), device=self.U.device)
+        return self.U[r, c].cpu().numpy()
 
     def col_min(self):
         """-> v [nc] on the host: pm_lsap_col_min."""
@@ -225,6 +256,51 @@ def certify(M, u, v, col4row, info=None):
     return rc == 1
 
 
+ROW_REDUCTION_ROUNDS = 12          # Jacobi rounds of augmenting row reduction on the dense rows before the core is chosen
+
+
+def _row_reduction(M, v, rounds):
+    """Warm start on the DENSE matrix (Jonker & Volgenant's augmenting row reduction in its parallel, auction-like form): every
+    free row bids for its cheapest column j1 at current prices; each column goes to the bid that lowers its price most —
+    by u2 - u1, the margin over the bidder's second choice — and whoever held it is free again.  Prices only fall, so duals
+    stay feasible; the winner's edge is tight (u = u2 = cost - new price).  A round is one pass of the bid kernel over the
+    free rows (their dense rows: no core yet, nothing is missed) and a vectorised conflict resolution on the host.
+    -> (u [nr] with NaN for free rows, v, col4row [nr] with -1 for free rows)."""
+    nr, nc = M.shape
+    v = np.array(v, dtype=np.float64, copy=True)
+    u = np.full(nr, np.nan)
+    col4row = np.full(nr, -1, dtype=np.int32)
+    row4col = np.full(nc, -1, dtype=np.int32)
+    free = np.arange(nr, dtype=np.int32)
+    for _ in range(rounds):
+        if free.size == 0:
+            break
+        j1, u1, u2 = M.bid(v, free)
+        ok = (j1 >= 0) & np.isfinite(u1)
+        if not ok.any():
+            break
+        rows_b, j1, u1, u2 = free[ok], j1[ok], u1[ok], u2[ok]
+        inc = np.where(np.isfinite(u2), u2 - u1, 0.0)            # a one-column row bids without a margin
+        order = np.lexsort((rows_b, -inc, j1))                    # per column: largest margin first, lowest row on ties
+        first = np.ones(order.size, dtype=bool)
+        first[1:] = j1[order][1:] != j1[order][:-1]
+        win = order[first]
+        wr, wc, winc, wu = rows_b[win], j1[win], inc[win], np.where(np.isfinite(u2[win]), u2[win], u1[win])
+        if wr.size == 0:
+            break
+        old = row4col[wc]
+        col4row[old[old >= 0]] = -1                               # displaced holders are free again
+        row4col[wc] = wr
+        col4row[wr] = wc
+        u[wr] = wu
+        v[wc] -= winc
+        free = np.flatnonzero(col4row < 0).astype(np.int32)
+        if not (winc > 0).any():                                  # only zero-margin moves left: rounds would ping-pong
+            break
+    u[col4row < 0] = np.nan
+    return u, v, col4row
+
+
 def solve_core(M, info=None):
     """The sparse-core solve of one matrix M [nr, nc], nr <= nc, finite entries -> (u, v, col4row) with no entry of M
     violating dual feasibility beyond delta, or None if M holds non-finite entries / pricing did not converge."""
@@ -232,19 +308,40 @@ def solve_core(M, info=None):
     k = min(CORE_EDGES_PER_ROW, 256)
     # square problems start from the column reduction (v = column minima, u = row minima of cost - v, rows matched to their
     # minimising column where it is free): the core is then chosen by REDUCED cost and most rows never need a search
-    v0 = M.col_min() if (nr == nc and COLUMN_REDUCTION) else None
+    v0 = M.col_min() if (nr == nc and COLUMN_REDUCTION) else np.zeros(nc)
+    if not np.isfinite(v0).all():
+        return None
+    u_rr = None
+    if ROW_REDUCTION_ROUNDS > 0 and hasattr(M, "bid"):
+        # warm start: a dozen bidding rounds on the dense rows match most rows and leave prices close to the optimum's
+        u_rr, v0, c4r_rr = _row_reduction(M, v0, ROW_REDUCTION_ROUNDS)
     cols, costs, bad = M.row_select(v0, k)
     if bad:
         return None
     safety = M.diagonal(nr)                              # row i -> column i: the core always holds a perfect matching
-    scale = max(float(np.abs(costs[cols >= 0]).max()), float(np.abs(safety).max()), 1e-300)
+    scale = max(float(np.abs(costs[cols >= 0]).max()), float(np.abs(safety).max()), float(np.abs(v0).max()), 1e-300)
     delta = REL_DELTA * scale
     kp = min(PRICE_EDGES_PER_ROW, 256)
+    dense_min = costs[:, 0] - v0[cols[:, 0]]              # each row's minimum of cost - v over the DENSE row (rank 0 of the selection)
     with _Core(nr, nc) as core:
         core.add(cols, costs)
         core.add(np.arange(nr, dtype=np.int32)[:, None], safety[:, None])
-        if v0 is not None:
-            core.init_duals(costs[:, 0] - v0[cols[:, 0]], v0, cols[:, 0])
+        if u_rr is not None:
+            held = np.flatnonzero(c4r_rr >= 0)
+            pair_cost = M.entries(held, c4r_rr[held])
+            extra_c = np.full((nr, 1), -1, dtype=np.int32)
+            extra_v = np.zeros((nr, 1))
+            extra_c[held, 0], extra_v[held, 0] = c4r_rr[held], pair_cost
+            core.add(extra_c, extra_v)                    # the matched pairs are core edges, with their exact costs
+            u0 = np.where(c4r_rr >= 0, u_rr, dense_min)
+            # a held row's dual is its second choice's reduced cost at the time of its bid: never above the dense minimum now
+            # (prices only fell since), except by the rounding of (cost - price) itself: keep it feasible to the bit
+            u0 = np.minimum(u0, dense_min)
+            tight = np.zeros(nr, dtype=bool)
+            tight[held] = (pair_cost - v0[c4r_rr[held]]) == u0[held]
+            core.init_state(u0, v0, np.where(tight, c4r_rr, -1).astype(np.int32))
+        elif nr == nc and COLUMN_REDUCTION:
+            core.init_duals(dense_min, v0, cols[:, 0])
         rounds = 0
         while True:
             core.solve()

@@ -32,6 +32,15 @@ def _answer(local, row0, rows, op, args):
         return local.block_diagonal(row0) if hasattr(local, "block_diagonal") else None
     if op == "col_min":
         return local.col_min()
+    if op == "bid":                                      # the listed matrix rows that live in this block
+        v, all_rows = args
+        sel = np.flatnonzero((all_rows >= row0) & (all_rows < row0 + rows))
+        j1, u1, u2 = local.bid(v, all_rows[sel] - row0)
+        return sel, j1, u1, u2
+    if op == "entries":
+        all_rows, all_cols = args
+        sel = np.flatnonzero((all_rows >= row0) & (all_rows < row0 + rows))
+        return sel, local.entries(all_rows[sel] - row0, all_cols[sel])
     if op == "certificate":
         u, v, c4r, delta, eps, cap = args
         viol, loose, tight, red, bound = local.certificate(u[row0:row0 + rows], v, c4r[row0:row0 + rows], delta, eps, cap)
@@ -68,6 +77,20 @@ class ShardedMatrix:
 
     def col_min(self):
         return np.minimum.reduce(self._ask("col_min", None))
+
+    def bid(self, v, rows):
+        rows = np.asarray(rows, dtype=np.int64)
+        j1, u1, u2 = np.full(rows.size, -1, np.int32), np.full(rows.size, np.inf), np.full(rows.size, np.inf)
+        for sel, a, b, c in self._ask("bid", (v, rows)):
+            j1[sel], u1[sel], u2[sel] = a, b, c
+        return j1, u1, u2
+
+    def entries(self, rows, cols):
+        rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+        out = np.empty(rows.size)
+        for sel, vals in self._ask("entries", (rows, cols)):
+            out[sel] = vals
+        return out
 
     def certificate(self, u, v, col4row, delta, eps, cap):
         parts = self._ask("certificate", (u, v, col4row, delta, eps, cap))

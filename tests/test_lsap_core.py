@@ -50,6 +50,22 @@ class HostMatrix:
         self.passes += 1
         return self.U.min(axis=0)
 
+    def bid(self, v, rows):
+        self.passes += 1
+        rows = np.asarray(rows, dtype=np.int64)
+        if rows.size == 0:
+            return np.zeros(0, np.int32), np.zeros(0), np.zeros(0)
+        red = self.U[rows] - v[None, :]
+        j1 = red.argmin(axis=1)                                   # first minimum = lowest column on ties
+        u1 = red[np.arange(rows.size), j1]
+        masked = red.copy()
+        masked[np.arange(rows.size), j1] = np.inf
+        u2 = masked.min(axis=1) if red.shape[1] > 1 else np.full(rows.size, np.inf)
+        return j1.astype(np.int32), u1, u2
+
+    def entries(self, rows, cols):
+        return self.U[np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)]
+
     def certificate(self, u, v, col4row, delta, eps, cap):
         self.passes += 1
         red = (self.U - v[None, :]) - u[:, None]
