@@ -35,6 +35,16 @@ def test_kernels_equal_their_numpy_restatement(dev, shape):
         dc, dcost, dflag = D.row_select(vv, k)
         hc, hcost, hflag = H.row_select(vv, k)
         assert dflag == hflag == 0 and np.array_equal(dc, hc) and np.array_equal(dcost, hcost)
+    rows = rng.choice(W.shape[0], min(W.shape[0], 200), replace=False).astype(np.int32)
+    dj, du1, du2 = D.bid(v, rows)
+    hj, hu1, hu2 = H.bid(v, rows)
+    assert np.array_equal(dj, hj) and np.array_equal(du1, hu1) and np.array_equal(du2, hu2)
+    Wt = W.copy()
+    Wt[:, 1 % W.shape[1]] = Wt[:, 0]                     # two columns tie everywhere: lowest column wins, second = first
+    tj, tu1, tu2 = L.DeviceMatrix(dev(Wt)).bid(np.zeros(W.shape[1]), rows)
+    hj, hu1, hu2 = HostMatrix(Wt).bid(np.zeros(W.shape[1]), rows)
+    assert np.array_equal(tj, hj) and np.array_equal(tu1, hu1) and np.array_equal(tu2, hu2)
+    assert np.array_equal(D.entries(rows, dj), W[rows, dj])
     sol = L.solve_core(D)
     assert sol is not None
     u, v2, c4r = sol
