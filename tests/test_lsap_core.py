@@ -107,6 +107,23 @@ def test_generic_matrices_are_certified_and_equal_scipy(shape):
         assert np.array_equal(got[0], r) and np.array_equal(got[1], c), info
 
 
+@pytest.mark.parametrize("shape", [(300, 300), (257, 300), (64, 900)])
+def test_row_reduction_warm_start_gives_the_same_certified_answer(shape):
+    """lsap.ROW_REDUCTION_ROUNDS > 0 (off by default): the bidding rounds change the starting duals and matching, never the result."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(sum(shape) + 5)
+    U = rng.random(shape)
+    old = L.ROW_REDUCTION_ROUNDS
+    try:
+        L.ROW_REDUCTION_ROUNDS = 12
+        got, info = run(U)
+    finally:
+        L.ROW_REDUCTION_ROUNDS = old
+    assert got is not None, info
+    r, c = scipy_lsa(U)
+    assert np.array_equal(got[0], r) and np.array_equal(got[1], c)
+
+
 def test_structured_costs_need_pricing_rounds_and_still_equal_scipy():
     """A matrix whose optimum avoids most rows' cheapest entries: decoy columns that are cheap for every row."""
     rng = np.random.default_rng(3)
