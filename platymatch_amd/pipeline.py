@@ -672,7 +672,7 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
         return dict(zip(order, ex.map(one, order)))
 
 
-def estimate_transform_batch(pairs, workers=4, seeds=None, group=None, timings=None, **kwargs):
+def estimate_transform_batch(pairs, workers=5, seeds=None, group=None, timings=None, **kwargs):
     """Several independent registrations (BASELINE config 5: "replicas only" — pairs never exchange data).
 
     One GPU (group=None): each worker thread drives its pairs on its own HIP stream, so the GPU stages of different pairs

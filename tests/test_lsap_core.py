@@ -215,3 +215,32 @@ def test_certificate_rejects_a_wrong_assignment_and_perturbed_duals():
     free = np.setdiff1d(np.arange(60), c4r)
     v2[free[0]] -= 0.5                                    # a free column priced below the matched ones: not a rectangular optimum
     assert not L.certify(M, u, v2, c4r)
+
+
+def test_engineered_near_ties_are_certified_only_above_the_margin():
+    """A unique optimum with an alternative exactly `gap` more expensive: two rows' cross entries are set, from the optimal
+    duals, to reduced cost gap/2 each, so that swapping their columns costs +gap and nothing else changes.  Above the margin
+    the route certifies the optimum (and it is SciPy's answer); below it, it must refuse — a refusal is answered by SciPy's
+    own algorithm in the product — and a certified answer must never differ from SciPy's."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(8)
+    n = 120
+    base = rng.random((n, n)) + 0.5
+    M = HostMatrix(base)
+    u, v, c = L.solve_core(M)
+    assert L.certify(M, u, v, c) and np.array_equal(c, scipy_lsa(base)[1])
+    i1, i2 = 3, 77
+    certified = {}
+    for gap in (1e-3, 1e-6, 1e-9, 1e-10, 1e-12, 1e-14, 0.0):
+        U = base.copy()
+        U[i1, c[i2]] = (u[i1] + v[c[i2]]) + gap / 2
+        U[i2, c[i1]] = (u[i2] + v[c[i1]]) + gap / 2
+        got, info = run(U)
+        rs, cs = scipy_lsa(U)
+        if gap >= 1e-9:
+            assert np.array_equal(cs, c)                                       # the engineered alternative really is worse
+        certified[gap] = got is not None
+        if got is not None:
+            assert np.array_equal(got[1], cs), (gap, info)
+    assert certified[1e-3] and certified[1e-6] and certified[1e-9]
+    assert not certified[1e-14] and not certified[0.0]                        # within the margin (floor 1e-11 of the scale): refused
