@@ -42,44 +42,96 @@ __global__ __launch_bounds__(256) void cdist_kernel(const double *__restrict__ a
 }
 
 // ---- label moments -----------------------------------------------------------------------------------------------
-// One thread walks LM_RUN consecutive voxels of one image row and flushes a (count, sum x) pair per run of equal
-// labels: labels are spatially coherent, so a thread issues one or two sets of atomics instead of LM_RUN.
-// All accumulators are 64-bit integers: the sums are exact, the result does not depend on the order of the atomics.
-constexpr int LM_RUN = 16;
+// A workgroup owns a brick of LM_TZ x LM_TY rows x LM_TX chunks of LM_RUN consecutive voxels; one thread walks one chunk
+// and hands a (count, count*z, count*y, sum x) record per run of equal labels to a small open-addressing table in LDS keyed
+// by the label (ds atomics); at the end the table's occupied slots go to the global accumulators — one set of global
+// atomics per label and brick instead of one per run (nuclei are blobs: a brick sees a handful of labels, each in dozens of
+// runs).  A run that finds no slot within LM_PROBES probes goes to the global accumulators directly, so the table's size
+// only affects speed.  All accumulators are 64-bit integers: the sums are exact and do not depend on the order of the atomics.
+constexpr int LM_RUN = 16;          // voxels per thread (four 16-byte loads when the row is aligned)
+constexpr int LM_TX = 8, LM_TY = 8, LM_TZ = 4;      // chunks along x, rows, slices per workgroup (= 256 threads)
+constexpr int LM_SLOTS = 128;
+constexpr int LM_PROBES = 8;
+
+struct LabelTable {
+    int key[LM_SLOTS];
+    unsigned long long acc[LM_SLOTS][4];
+};
+
+__device__ __forceinline__ void label_flush(LabelTable &tab, int n_labels, unsigned long long *__restrict__ counts,
+                                            unsigned long long *__restrict__ sums, int label, unsigned long long cnt,
+                                            unsigned long long sz, unsigned long long sy, unsigned long long sx) {
+    unsigned int h = ((unsigned int)label * 2654435761u) >> 25;           // 7 bits
+    for (int probe = 0; probe < LM_PROBES; ++probe, h = (h + 1) & (LM_SLOTS - 1)) {
+        const int old = atomicCAS(&tab.key[h], 0, label);
+        if (old == 0 || old == label) {
+            atomicAdd(&tab.acc[h][0], cnt);
+            atomicAdd(&tab.acc[h][1], sz);
+            atomicAdd(&tab.acc[h][2], sy);
+            atomicAdd(&tab.acc[h][3], sx);
+            return;
+        }
+    }
+    atomicAdd(&counts[label], cnt);
+    atomicAdd(&sums[label], sz);
+    atomicAdd(&sums[(size_t)n_labels + label], sy);
+    atomicAdd(&sums[2 * (size_t)n_labels + label], sx);
+}
 
 __global__ __launch_bounds__(256) void label_moments_kernel(const int32_t *__restrict__ labels, int nz, int ny, int nx,
                                                             int n_labels, unsigned long long *__restrict__ counts,
                                                             unsigned long long *__restrict__ sums, int *__restrict__ bad) {
-    const int chunks = (nx + LM_RUN - 1) / LM_RUN;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)nz * ny * chunks;
-    if (t >= total) return;
-    const int chunk = (int)(t % chunks);
-    const long long row = t / chunks;                          // z * ny + y
-    const int y = (int)(row % ny), z = (int)(row / ny);
-    const int x0 = chunk * LM_RUN, x1 = min(nx, x0 + LM_RUN);
-    const int32_t *p = labels + row * (long long)nx;
-    int cur = 0;
-    unsigned long long cnt = 0, sx = 0;
-    for (int x = x0; x < x1; ++x) {
-        const int l = p[x];
-        if (l != cur) {
-            if (cur > 0 && cnt) {
-                atomicAdd(&counts[cur], cnt);
-                atomicAdd(&sums[cur], cnt * (unsigned long long)z);
-                atomicAdd(&sums[(size_t)n_labels + cur], cnt * (unsigned long long)y);
-                atomicAdd(&sums[2 * (size_t)n_labels + cur], sx);
-            }
-            cur = l; cnt = 0; sx = 0;
-            if (l < 0 || l >= n_labels) { atomicOr(bad, 1); cur = 0; }
-        }
-        if (cur > 0) { ++cnt; sx += (unsigned long long)x; }
+    __shared__ LabelTable tab;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < LM_SLOTS; k += 256) {
+        tab.key[k] = 0;
+        tab.acc[k][0] = tab.acc[k][1] = tab.acc[k][2] = tab.acc[k][3] = 0ull;
     }
-    if (cur > 0 && cnt) {
-        atomicAdd(&counts[cur], cnt);
-        atomicAdd(&sums[cur], cnt * (unsigned long long)z);
-        atomicAdd(&sums[(size_t)n_labels + cur], cnt * (unsigned long long)y);
-        atomicAdd(&sums[2 * (size_t)n_labels + cur], sx);
+    __syncthreads();
+    const int chunks = (nx + LM_RUN - 1) / LM_RUN;
+    const int bx = (chunks + LM_TX - 1) / LM_TX, by = (ny + LM_TY - 1) / LM_TY;
+    const int tile_x = blockIdx.x % bx, tile_y = (blockIdx.x / bx) % by, tile_z = blockIdx.x / (bx * by);
+    const int chunk = tile_x * LM_TX + (tid % LM_TX);
+    const int y = tile_y * LM_TY + (tid / LM_TX) % LM_TY;
+    const int z = tile_z * LM_TZ + tid / (LM_TX * LM_TY);
+    if (chunk < chunks && y < ny && z < nz) {
+        const int x0 = chunk * LM_RUN, x1 = min(nx, x0 + LM_RUN);
+        const int32_t *p = labels + ((long long)z * ny + y) * (long long)nx;
+        int lab[LM_RUN];
+        if (x1 - x0 == LM_RUN && (((uintptr_t)(p + x0)) & 15) == 0) {
+#pragma unroll
+            for (int q = 0; q < LM_RUN / 4; ++q) {
+                const int4 v = *reinterpret_cast<const int4 *>(p + x0 + 4 * q);
+                lab[4 * q] = v.x; lab[4 * q + 1] = v.y; lab[4 * q + 2] = v.z; lab[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < LM_RUN; ++q) lab[q] = (x0 + q < x1) ? p[x0 + q] : 0;
+        }
+        int cur = 0;
+        unsigned long long cnt = 0, sx = 0;
+#pragma unroll
+        for (int q = 0; q < LM_RUN; ++q) {
+            int l = lab[q];
+            if (l != cur) {
+                if (cur > 0 && cnt) label_flush(tab, n_labels, counts, sums, cur, cnt, cnt * (unsigned long long)z, cnt * (unsigned long long)y, sx);
+                cnt = 0; sx = 0;
+                if (l < 0 || l >= n_labels) { atomicOr(bad, 1); l = 0; }
+                cur = l;
+            }
+            if (cur > 0) { ++cnt; sx += (unsigned long long)(x0 + q); }
+        }
+        if (cur > 0 && cnt) label_flush(tab, n_labels, counts, sums, cur, cnt, cnt * (unsigned long long)z, cnt * (unsigned long long)y, sx);
+    }
+    __syncthreads();
+    for (int k = tid; k < LM_SLOTS; k += 256) {
+        const int label = tab.key[k];
+        if (label > 0) {
+            atomicAdd(&counts[label], tab.acc[k][0]);
+            atomicAdd(&sums[label], tab.acc[k][1]);
+            atomicAdd(&sums[(size_t)n_labels + label], tab.acc[k][2]);
+            atomicAdd(&sums[2 * (size_t)n_labels + label], tab.acc[k][3]);
+        }
     }
 }
 
@@ -157,8 +209,8 @@ int pm_label_moments(const int32_t *labels, int nz, int ny, int nx, int n_labels
     // counts[0] doubles as the out-of-range flag word (label 0 is background and never accumulated)
     if (hipMemsetAsync(counts, 0, sizeof(unsigned long long) * (size_t)n_labels, s) != hipSuccess) return pm::launch_status();
     if (hipMemsetAsync(sums3, 0, sizeof(unsigned long long) * 3 * (size_t)n_labels, s) != hipSuccess) return pm::launch_status();
-    const long long total = (long long)nz * ny * ((nx + pm::LM_RUN - 1) / pm::LM_RUN);
-    const long long blocks = (total + 255) / 256;
+    const long long chunks = (nx + pm::LM_RUN - 1) / pm::LM_RUN;
+    const long long blocks = ((chunks + pm::LM_TX - 1) / pm::LM_TX) * ((ny + pm::LM_TY - 1) / pm::LM_TY) * ((nz + pm::LM_TZ - 1) / pm::LM_TZ);
     if (blocks > 0x7fffffffLL) return PM_ERR_INVALID_ARG;
     pm::label_moments_kernel<<<(unsigned int)blocks, 256, 0, s>>>(labels, nz, ny, nx, n_labels, counts, sums3, (int *)counts);
     return pm::launch_status();

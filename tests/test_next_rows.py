@@ -94,3 +94,36 @@ def test_gpu_label_centroids(oracle, nx):
         label_centroids(np.zeros((4, 4)), 1.0)
     with pytest.raises(ValueError):
         label_centroids(np.full((2, 2, 2), -1, dtype=np.int32), 1.0)
+
+
+@pytest.mark.gpu
+def test_label_moments_exact_on_odd_volumes_blobs_and_noise():
+    """pm_label_moments against NumPy's integer arithmetic (np.bincount with weights is float: use explicit int64 sums):
+    unaligned row lengths, blobs (the per-brick label table's fast path), one label per voxel (the table overflows into the
+    global accumulators), labels at the top of the range."""
+    import torch
+    from platymatch_amd import _kernels as K, _native as nat
+    from platymatch_amd.build import build_native
+    build_native()
+    nat.load()
+    rng = np.random.default_rng(4)
+    for shape, kind in (((9, 13, 37), "noise"), ((20, 33, 130), "blobs"), ((5, 8, 16), "blobs"), ((33, 17, 257), "noise"), ((4, 4, 4), "one")):
+        if kind == "noise":
+            lab = rng.integers(0, 3000, size=shape).astype(np.int32)
+        elif kind == "one":
+            lab = np.full(shape, 7, dtype=np.int32)
+        else:
+            zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+            lab = (((zz // 5) * 100 + (yy // 6)) * 100 + xx // 7 + 1).astype(np.int32)
+            lab[(zz + yy + xx) % 11 == 0] = 0
+        n_labels = int(lab.max()) + 1
+        counts, sums = K.label_moments(torch.as_tensor(lab, device="cuda"), n_labels=n_labels)
+        zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+        want_c = np.bincount(lab.ravel(), minlength=n_labels).astype(np.int64)
+        want_c[0] = 0                                                    # background is not accumulated
+        assert np.array_equal(counts.cpu().numpy(), want_c), (shape, kind)
+        for k, coord in enumerate((zz, yy, xx)):
+            want = np.zeros(n_labels, dtype=np.int64)
+            np.add.at(want, lab.ravel(), coord.ravel().astype(np.int64))
+            want[0] = 0
+            assert np.array_equal(sums[k].cpu().numpy(), want), (shape, kind, k)
