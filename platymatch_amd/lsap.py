@@ -217,7 +217,9 @@ class DeviceMatrix:
 def certify(M, u, v, col4row, info=None):
     """Is (u, v, col4row) a certified UNIQUE optimum of the matrix M (nr <= nc)?  Dual feasibility and complementary
     slackness on every entry (pm_lsap_certificate), the free columns carrying the largest column dual (nr < nc), and no
-    alternating cycle among the entries within eps of tight (pm_lsap_unique)."""
+    alternating cycle among the entries within eps of tight (pm_lsap_unique).  info["optimal"] tells the two failures apart:
+    True = the assignment IS optimal (to the rounding bound) but another one lies within the margin, so which of them
+    SciPy's rounding would return cannot be told without running SciPy's algorithm."""
     lib = nat.load()
     nr, nc = M.shape
     scale = max(float(np.abs(u).max()), float(np.abs(v).max()), 1e-300)
@@ -232,12 +234,10 @@ def certify(M, u, v, col4row, info=None):
     eps = max(REL_EPS_FLOOR * scale, EPS_SAFETY * bound)
     if info is not None:
         info.update(violations=viol, loose=loose, tight=None if tight is None else len(tight), slack_bound=bound, delta=delta, eps=eps)
-    if viol or loose or tight is None or eps > eps_collect:
-        return False
-    keep = red <= eps
-    tight = tight[keep]
     if info is not None:
-        info["tight_within_eps"] = int(keep.sum())
+        info["optimal"] = False            # set below once feasibility, tightness and (nr < nc) the free columns' prices check out
+    if viol or loose:
+        return False
     v_free = 0.0
     if nc > nr:
         free = np.ones(nc, dtype=bool)
@@ -245,6 +245,14 @@ def certify(M, u, v, col4row, info=None):
         v_free = float(v[free].min())
         if float(v.max()) - v_free > delta:           # a matched column priced above a free one: not optimal for nr < nc
             return False
+    if info is not None:
+        info["optimal"] = True             # LP duality: no assignment is cheaper by more than `bound`; uniqueness is the open question
+    if tight is None or eps > eps_collect:
+        return False
+    keep = red <= eps
+    tight = tight[keep]
+    if info is not None:
+        info["tight_within_eps"] = int(keep.sum())
     t = np.ascontiguousarray(tight, dtype=np.int32)
     c4r = np.ascontiguousarray(col4row, dtype=np.int32)
     vv = np.ascontiguousarray(v, dtype=np.float64)
@@ -387,12 +395,14 @@ def solve_on_device(U, info=None, force=False):
 DENSE_FALLBACK_MAX_ENTRIES = 1 << 30      # matrices above this many entries are never handed to the dense host solver (hours)
 
 
-def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=True):
+def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=True, accept_near_ties=False):
     """One hypothesis and its twin (the same terms summed in another order: U11/U22, U12/U21, U13/U24, U14/U23), both float64
     GPU matrices [N, M]: the hypothesis is solved on its sparse core and certified; the twin first tries its sibling's duals —
     accepted only if they are a certified unique optimum of the twin's OWN entries — and is solved on its own otherwise.
     -> [(row_ind, col_ind) or None, (row_ind, col_ind) or None]; None only with allow_host=False (or a matrix too large for
-    the dense solver): the hypothesis could not be certified and the dense host solver was not allowed."""
+    the dense solver): the hypothesis could not be certified and the dense host solver was not allowed.
+    accept_near_ties: where the dense solver is not an option, take an assignment that is certified OPTIMAL but not proven
+    unique (an alternative within ~1e-11 of the total cost exists; SciPy might return either) instead of None."""
     n, m = U_h.shape
     info_h = {} if info_h is None else info_h
     info_twin = {} if info_twin is None else info_twin
@@ -402,6 +412,7 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
         info_h["route"] = info_twin["route"] = "host"
         return [linear_sum_assignment(U_h.cpu().numpy()), linear_sum_assignment(U_twin.cpu().numpy())]
     out = [None, None]
+    near_tie = "device (optimal, a near-tie within the margin: not proven to be SciPy's pick)"
     W = DeviceMatrix(U_h if n <= m else U_h.t().contiguous())
     sol = solve_core(W, info_h)
     if sol is not None and certify(W, *sol, info=info_h):
@@ -415,6 +426,9 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
     elif host_ok:
         info_h["route"] = "host"
         out[0] = linear_sum_assignment(U_h.cpu().numpy())
+    elif accept_near_ties and sol is not None and info_h.get("optimal"):
+        info_h["route"] = near_tie
+        out[0] = _answer(sol[2], n, m)
     else:
         info_h["route"] = refused
     # the twin on its own
@@ -426,12 +440,15 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
     elif host_ok:
         info_twin["route"] = "host"
         out[1] = linear_sum_assignment(U_twin.cpu().numpy())
+    elif accept_near_ties and sol_t is not None and info_twin.get("optimal"):
+        info_twin["route"] = near_tie
+        out[1] = _answer(sol_t[2], n, m)
     else:
         info_twin["route"] = refused
     return out
 
 
-def solve_eight_on_device(U8, info=None, allow_host=True):
+def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False):
     """The widget's eight assignments (_dock_widget.py:604-611) for U8 [8, N, M] on the GPU: hypotheses 11, 12, 13, 14 are
     solved (four host threads drive their core solves and kernels concurrently), each together with its twin (22, 21, 24,
     23: solve_pair_on_device).  -> list of eight (row_ind, col_ind).
@@ -456,7 +473,7 @@ def solve_eight_on_device(U8, info=None, allow_host=True):
         twin = [t for t, s in TWINS.items() if s == h][0]
         stream = torch.cuda.Stream(device=U8.device)
         with torch.cuda.device(U8.device), torch.cuda.stream(stream):
-            out[h], out[twin] = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], allow_host)
+            out[h], out[twin] = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], allow_host, accept_near_ties)
             stream.synchronize()
 
     torch.cuda.current_stream(U8.device).synchronize()      # U8 was produced on the caller's stream

@@ -213,7 +213,7 @@ def build_costs(be, mov, fix, group=None):
     return be.chi2_cost8(sc_m, sc_f), bn
 
 
-def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=None):
+def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=None, accept_near_ties=False):
     """Cost matrices and assignments two matrices at a time, for clouds whose eight matrices (64 N M bytes per rank-block) do not
     fit in HBM together: for each pairing t the hypothesis and its twin are built (be.chi2_cost_pair: a quarter of the
     eight-matrix launch, the same bits), assigned with the matrices resident (one GPU: lsap.solve_pair_on_device; sharded:
@@ -230,7 +230,7 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
         buf = U2
         ih, it = {}, {}
         if world == 1:
-            got = lsap.solve_pair_on_device(U2[0], U2[1], ih, it)
+            got = lsap.solve_pair_on_device(U2[0], U2[1], ih, it, accept_near_ties=accept_near_ties)
             routes[h], routes[twin] = ih.get("route"), it.get("route")
         else:
             from .lsap_sharded import solve_pair_sharded
@@ -245,8 +245,9 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
             routes[twin] = "sharded device (sibling's duals certified)" if c_t is not None else "uncertified"
         for idx, g in zip((h, twin), got):
             if g is None:
-                raise RuntimeError("hypothesis %s: the assignment could not be certified unique (ties or non-finite costs) and the "
-                                   "matrix is too large for the dense solver" % HYPOTHESES[idx])
+                raise RuntimeError("hypothesis %s: the assignment could not be certified unique (an alternative within ~1e-11 of the "
+                                   "optimum, exact ties or non-finite costs) and the matrix is too large for the dense solver; "
+                                   "accept_near_ties=True takes the certified optimum as it is" % HYPOTHESES[idx])
             out[idx] = g
     if info is not None:
         info["routes"] = routes
@@ -292,7 +293,7 @@ def cost_row_argmins(be, mov, fix, rows_per_block=None, group=None):
 SHARDED_ASSIGN_MIN_ROWS = 1024     # below this the gather + dense host solve is quicker than the sharded solve's round trips
 
 
-def assign(U_loc, bounds, group=None, info=None, local_matrix=None):
+def assign(U_loc, bounds, group=None, info=None, local_matrix=None, accept_near_ties=False):
     """linear_sum_assignment on each of the eight matrices (_dock_widget.py:604-611) -> list of
     (row_ind, col_ind) int64 arrays, identical on every rank.  On a GPU the matrices never leave HBM: a sparse core
     of each is solved on the host and certified against every entry on the device (lsap.solve_on_device; tied or small
@@ -309,7 +310,13 @@ def assign(U_loc, bounds, group=None, info=None, local_matrix=None):
         if U_loc.is_cuda:
             # matrices stay in HBM: sparse-core solves driven from four host threads, certified on the device against every
             # entry (lsap.solve_eight_on_device); small or tied matrices take the dense host solver, SciPy's algorithm itself
-            return solve_eight_on_device(U_loc, info=info)
+            out = solve_eight_on_device(U_loc, info=info, accept_near_ties=accept_near_ties)
+            for h, ans in enumerate(out):
+                if ans is None:          # only for matrices beyond the dense solver's reach (lsap.DENSE_FALLBACK_MAX_ENTRIES)
+                    raise RuntimeError("hypothesis %s: the assignment could not be certified unique (an alternative within ~1e-11 of "
+                                       "the optimum, exact ties or non-finite costs) and the matrix is too large for the dense "
+                                       "solver; accept_near_ties=True takes the certified optimum as it is" % HYPOTHESES[h])
+            return out
         return solve_many([U_loc[h].numpy() for h in range(8)])
     dist = _dist()
     n = bounds[-1]
@@ -492,7 +499,8 @@ class _SampleDraws:
 
 def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
                        ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, group=None,
-                       backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS, private_rng=False, stream_hypotheses=None):
+                       backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS, private_rng=False, stream_hypotheses=None,
+                       accept_near_ties=False):
     """Reproduces _dock_widget.py:526-718 -> (A_sc, A_icp, inliers[8]); final transform = A_icp @ A_sc (:428).
 
     moving, fixed   3 x N / 3 x M float64 (rows z, y, x), NumPy or torch
@@ -508,6 +516,9 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     icp_shard_min_points  moving-cloud size from which ICP is sharded too (below it every rank runs it whole)
     stream_hypotheses     None: build all eight cost matrices at once if they fit in HBM (64 N M bytes), else two at a time
                           (assign_streamed); True / False force one or the other
+    accept_near_ties      for matrices beyond the reach of SciPy's dense algorithm (> 2^30 entries): if a hypothesis has a second
+                          assignment within ~1e-11 of the optimal cost, which of the two SciPy's rounding would return cannot be
+                          told; False raises, True takes the certified optimum (details['assignment']['routes'] says so)
     details         optional dict filled with intermediate results (lsa, ransac_A, residuals)
     """
     import time
@@ -543,9 +554,10 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         t0 = mark("gpu_descriptors_costs", t0)
         try:
             if streamed:
-                lsa = assign_streamed(be, sc_m, sc_f, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None))
+                lsa = assign_streamed(be, sc_m, sc_f, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None),
+                                      accept_near_ties=accept_near_ties)
             else:
-                lsa = assign(U, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None))
+                lsa = assign(U, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None), accept_near_ties=accept_near_ties)
         finally:
             del U, sc_m, sc_f
             t0 = mark("host_assignment", t0)

@@ -36,7 +36,8 @@ mv, fx, A_gt = synth_pair(n, 42)
 P.estimate_transform(mv[:, :400], fx[:, :400], ransac_trials=50, icp_iterations=2)          # warm-up
 det = {"timing": True}
 t = time.perf_counter()
-A_sc, A_icp, inl = P.estimate_transform(mv, fx, ransac_trials=trials, ransac_error=16, icp_iterations=iters, seed=0, details=det)
+A_sc, A_icp, inl = P.estimate_transform(mv, fx, ransac_trials=trials, ransac_error=16, icp_iterations=iters, seed=0, details=det,
+                                        accept_near_ties=True)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t
 stop.set()
