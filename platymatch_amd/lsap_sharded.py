@@ -125,27 +125,43 @@ def serve(locals_, bounds, group, root):
         dist.gather_object(_answer(locals_[which], row0, rows, op, args), None, dst=_global(group, root), group=group)
 
 
-def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=None):
+def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=None, accept_near_ties=False):
     """One hypothesis and (optionally) its twin, rows sharded: the root solves the first on its sparse core and certifies the
-    result on both matrices.  -> (col4row of the hypothesis or None, col4row of the twin or None) on EVERY rank; None = not
-    certified (the caller takes another route for that matrix).  N <= M required."""
+    result on both matrices; a twin that does not accept its sibling's duals is solved on its own core.  -> (col4row of the
+    hypothesis or None, col4row of the twin or None) on EVERY rank; None = not certified (the caller takes another route
+    for that matrix).  N <= M required.  accept_near_ties: an assignment certified optimal but not proven unique
+    (lsap.certify: info["optimal"]) is returned instead of None; info["near_tie"] lists which (0 = hypothesis, 1 = twin)."""
     dist = _dist()
     rank = dist.get_rank(group)
     locals_ = [local_h] + ([local_twin] if local_twin is not None else [])
     out = [None, None, None]                              # col4row, twin's col4row, error message
     if rank == root:
         try:
+            info = {} if info is None else info
+            near = info["near_tie"] = []
             M = ShardedMatrix(locals_, 0, bounds, group, root, n_cols)
             sol = lsap.solve_core(M, info)
-            if sol is not None and lsap.certify(M, *sol, info=info):
+            certified = sol is not None and lsap.certify(M, *sol, info=info)
+            if certified:
                 out[0] = sol[2]
-                if local_twin is not None:
-                    Mt = ShardedMatrix(locals_, 1, bounds, group, root, n_cols)
-                    tinfo = {} if info is not None else None
-                    if lsap.certify(Mt, *sol, info=tinfo):
-                        out[1] = sol[2]
-                    if info is not None:
-                        info["twin"] = tinfo
+            elif accept_near_ties and sol is not None and info.get("optimal"):
+                out[0] = sol[2]
+                near.append(0)
+            if local_twin is not None:
+                Mt = ShardedMatrix(locals_, 1, bounds, group, root, n_cols)
+                tinfo = info["twin"] = {}
+                if certified and lsap.certify(Mt, *sol, info=tinfo):
+                    out[1] = sol[2]
+                    tinfo["route"] = "sibling's duals certified"
+                else:                                     # the twin on its own
+                    tinfo.clear()
+                    sol_t = lsap.solve_core(Mt, tinfo)
+                    if sol_t is not None and lsap.certify(Mt, *sol_t, info=tinfo):
+                        out[1] = sol_t[2]
+                    elif accept_near_ties and sol_t is not None and tinfo.get("optimal"):
+                        out[1] = sol_t[2]
+                        near.append(1)
+                    tinfo["route"] = "own core"
         except Exception as e:                            # the workers are waiting for queries: release them, then raise everywhere
             out[2] = "%s: %s" % (type(e).__name__, e)
         finally:

@@ -237,12 +237,12 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
             lm = local_matrix or lsap.DeviceMatrix
             if n > m:
                 raise NotImplementedError("sharded streamed assignment needs N <= M (rows are the sharded side)")
-            c_h, c_t = solve_pair_sharded(lm(U2[0]), lm(U2[1]), bounds, m, group, h % world, ih)
+            c_h, c_t = solve_pair_sharded(lm(U2[0]), lm(U2[1]), bounds, m, group, h % world, ih, accept_near_ties=accept_near_ties)
             rows = np.arange(n, dtype=np.int64)
             got = [None if c_h is None else (rows, np.asarray(c_h, dtype=np.int64)),
                    None if c_t is None else (rows, np.asarray(c_t, dtype=np.int64))]
-            routes[h] = "sharded device" if c_h is not None else "uncertified"
-            routes[twin] = "sharded device (sibling's duals certified)" if c_t is not None else "uncertified"
+            routes[h] = "sharded device" if c_h is not None else "uncertified"          # (details of the route: on the root only)
+            routes[twin] = "sharded device" if c_t is not None else "uncertified"
         for idx, g in zip((h, twin), got):
             if g is None:
                 raise RuntimeError("hypothesis %s: the assignment could not be certified unique (an alternative within ~1e-11 of the "
@@ -336,7 +336,7 @@ def assign(U_loc, bounds, group=None, info=None, local_matrix=None, accept_near_
                 routes[h] = "sharded device"
             if c_t is not None:
                 done[twin] = (rows, np.asarray(c_t, dtype=np.int64))
-                routes[twin] = "sharded device (sibling's duals certified)"
+                routes[twin] = "sharded device"
         if info is not None:
             info["routes"] = [routes.get(h, "gathered") for h in range(8)]
     biggest = max(bounds[g + 1] - bounds[g] for g in range(world))

@@ -221,3 +221,43 @@ def test_streamed_hypotheses_give_the_same_registration(dev):
         for h in range(8):
             assert np.array_equal(d0["lsa"][h][0], d1["lsa"][h][0]) and np.array_equal(d0["lsa"][h][1], d1["lsa"][h][1]), h
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_near_tie_beyond_the_dense_solvers_reach_raises_unless_accepted(dev, monkeypatch):
+    """Where SciPy's dense algorithm is no fallback (lsap.DENSE_FALLBACK_MAX_ENTRIES; lowered here), a hypothesis whose optimum
+    is certified but has an alternative inside the margin comes back None (the driver raises) — or, with
+    accept_near_ties=True, as the certified optimum, labelled as such.  The engineered matrix has one 2-cycle worth 1e-14."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(21)
+    n = 1100
+    base = rng.random((n, n)) + 0.5
+    u, v, c = L.solve_core(L.DeviceMatrix(dev(base)))
+    U = base.copy()
+    i1, i2 = 5, 900
+    U[i1, c[i2]] = (u[i1] + v[c[i2]]) + 0.5e-14
+    U[i2, c[i1]] = (u[i2] + v[c[i1]]) + 0.5e-14
+    Ud = dev(U)
+    monkeypatch.setattr(L, "DENSE_FALLBACK_MAX_ENTRIES", 0)
+    ih, it = {}, {}
+    out = L.solve_pair_on_device(Ud, Ud, ih, it)
+    assert out == [None, None] and ih["optimal"] and ih["route"].startswith("uncertified (too large")
+    ih, it = {}, {}
+    out = L.solve_pair_on_device(Ud, Ud, ih, it, accept_near_ties=True)
+    assert "near-tie" in ih["route"] and "near-tie" in it["route"]
+    rs, cs = scipy_lsa(U)
+    for r_, c_ in out:
+        assert np.array_equal(r_, rs) and sorted(c_) == list(range(n))
+        assert abs(U[r_, c_].sum() - U[rs, cs].sum()) <= 1e-12 * n                   # optimal; which of the two near-equal ones is open
+    # the driver's eight-matrix path raises rather than returning a hole
+    from platymatch_amd import pipeline as P
+    import torch
+    U8 = torch.stack([Ud] * 8)
+    with pytest.raises(RuntimeError, match="accept_near_ties"):
+        P.assign(U8, [0, n])
+    lsa = P.assign(U8, [0, n], accept_near_ties=True)
+    assert all(a is not None for a in lsa)
+    # with the dense solver allowed again the same matrix takes SciPy's own algorithm: identical indices
+    monkeypatch.undo()
+    ih = {}
+    out = L.solve_pair_on_device(Ud, Ud, ih, {})
+    assert ih["route"] == "host" and np.array_equal(out[0][1], cs)

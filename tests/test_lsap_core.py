@@ -214,7 +214,8 @@ def test_certificate_rejects_a_wrong_assignment_and_perturbed_duals():
     v2 = v.copy()
     free = np.setdiff1d(np.arange(60), c4r)
     v2[free[0]] -= 0.5                                    # a free column priced below the matched ones: not a rectangular optimum
-    assert not L.certify(M, u, v2, c4r)
+    info = {}
+    assert not L.certify(M, u, v2, c4r, info=info) and info["optimal"] is False         # not a near-tie: no optimality claim
 
 
 def test_engineered_near_ties_are_certified_only_above_the_margin():
@@ -242,5 +243,11 @@ def test_engineered_near_ties_are_certified_only_above_the_margin():
         certified[gap] = got is not None
         if got is not None:
             assert np.array_equal(got[1], cs), (gap, info)
+        else:
+            # refused for uniqueness only: the certificate still says OPTIMAL (what accept_near_ties builds on), and the
+            # solver's assignment indeed costs what SciPy's does, to rounding
+            assert info["optimal"] and info.get("unique") is False, info
+            sol = L.solve_core(HostMatrix(U))
+            assert abs(U[np.arange(n), sol[2]].sum() - U[rs, cs].sum()) <= 1e-12 * n
     assert certified[1e-3] and certified[1e-6] and certified[1e-9]
     assert not certified[1e-14] and not certified[0.0]                        # within the margin (floor 1e-11 of the scale): refused

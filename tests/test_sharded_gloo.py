@@ -356,3 +356,53 @@ def test_sharded_assign_raises_on_every_rank_instead_of_hanging(tmp_path, oracle
     mp.spawn(_assign_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     m0, m1 = str(np.load(out % 0)), str(np.load(out % 1))
     assert m0 == m1 and "hypothesis 22" in m0 and "invalid numeric" in m0
+
+
+def _pair_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from platymatch_amd import lsap as L, pipeline as P
+        from platymatch_amd.lsap_sharded import solve_pair_sharded
+        from test_lsap_core import HostMatrix
+        rng = np.random.default_rng(17)
+        n, m = 150, 170
+        A = rng.random((n, m)) + 0.5
+        B = rng.random((n, m)) + 0.5                          # a "twin" with another optimum: its sibling's duals cannot certify it
+        u, v, c = L.solve_core(HostMatrix(A))
+        T = A.copy()                                          # A with a 2-cycle worth 1e-14: optimal, not provably unique
+        T[3, c[90]] = u[3] + v[c[90]] + 0.5e-14
+        T[90, c[3]] = u[90] + v[c[3]] + 0.5e-14
+        b = P.shard_bounds(n, world)
+        blk = lambda X: HostMatrix(X[b[rank]:b[rank + 1]])
+        res = {}
+        info = {}
+        res["AB"] = solve_pair_sharded(blk(A), blk(B), b, m, dist.group.WORLD, 1, info)
+        if rank == 1:
+            assert info["twin"]["route"] == "own core" and info["near_tie"] == []
+        res["AT"] = solve_pair_sharded(blk(A), blk(T), b, m, dist.group.WORLD, 0)
+        info = {}
+        res["AT_accept"] = solve_pair_sharded(blk(A), blk(T), b, m, dist.group.WORLD, 0, info, accept_near_ties=True)
+        if rank == 0:
+            assert info["near_tie"] == [1]
+        np.savez(out_path % rank, A=A, B=B, T=T, **{k + str(i): (np.array([-1]) if x is None else np.asarray(x))
+                                                    for k, pair in res.items() for i, x in enumerate(pair)})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_pair_solves_an_unrelated_twin_on_its_own_core_and_flags_near_ties(tmp_path):
+    from scipy.optimize import linear_sum_assignment as scipy_lsa
+    out = str(tmp_path / "p%d.npz")
+    mp.spawn(_pair_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), k                                  # every rank holds the same answers
+    A, B, T = r0["A"], r0["B"], r0["T"]
+    assert np.array_equal(r0["AB0"], scipy_lsa(A)[1]) and np.array_equal(r0["AB1"], scipy_lsa(B)[1])
+    assert np.array_equal(r0["AT0"], scipy_lsa(A)[1]) and np.array_equal(r0["AT1"], [-1])       # near-tie: refused by default
+    rows = np.arange(A.shape[0])
+    assert abs(T[rows, r0["AT_accept1"]].sum() - T[scipy_lsa(T)].sum()) < 1e-12 * len(rows)      # accepted: optimal to rounding
