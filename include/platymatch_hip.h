@@ -153,6 +153,18 @@ int pm_chi2_cost8_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, 
 int pm_chi2_cost_pair_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out2, size_t ld,
                           size_t matrix_stride, void *stream);
 
+/* The same two calls with a caller-provided workspace (pm_chi2_sym_workspace_bytes, 16-byte aligned device memory), which lets
+ * the kernel take most terms of the sparsely filled inner shells from a table: a descriptor value is count / total
+ * (get_shape_context's sc / sc.sum(), shape_context.py:40-43), so (a-b)^2/(a+b) is a function of two small integers.  The
+ * calls recover the counts from the doubles and verify bit for bit that every value is fl(count / total); the table is filled
+ * by the same operations on the same operands, so the result has the bits of pm_chi2_cost8_sym / pm_chi2_cost_pair_sym for ANY
+ * input (descriptors that are not count / total, or shells with counts of 88 and more, are computed term by term). */
+size_t pm_chi2_sym_workspace_bytes(int nM, int nF);
+int pm_chi2_cost8_sym_ws(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
+                         size_t matrix_stride, void *ws, size_t ws_bytes, void *stream);
+int pm_chi2_cost_pair_sym_ws(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out2, size_t ld,
+                             size_t matrix_stride, void *ws, size_t ws_bytes, void *stream);
+
 /* np.argmin(U_h, axis=1) for n_mat stacked cost matrices (U_h = U + h*matrix_stride, rows x cols, leading
  * dimension ld): idx[h*rows + i] = first index of the minimum of row i, or of the first NaN if the row holds one
  * (NumPy's rule); val (may be NULL) receives the minimum itself.  This is the per-row check BASELINE.json's

@@ -255,8 +255,15 @@ def chi2_cost8_frame1(sc_m1, sc_f1, out=None):
     a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
     nM, nF = a.shape[0], b.shape[0]
     out = _out8(out, nM, nF, a.device)
-    check(nat.load().pm_chi2_cost8_sym(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), nat.stream_ptr()))
+    lib = nat.load()
+    ws = _sym_workspace(lib, nM, nF, a.device)
+    check(lib.pm_chi2_cost8_sym_ws(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(), nat.stream_ptr()))
     return out
+
+
+def _sym_workspace(lib, nM, nF, device):
+    """Device scratch of the half-cost kernel's term table (the integer counts behind the descriptor values; include/platymatch_hip.h)."""
+    return _t().empty(int(lib.pm_chi2_sym_workspace_bytes(nM, nF)), dtype=_t().uint8, device=device)
 
 
 PAIRINGS = ((0, 5), (1, 4), (2, 7), (3, 6))      # pairing t -> (hypothesis summed in natural order, its twin), widget numbering
@@ -278,7 +285,10 @@ def chi2_cost_pair(sc_m, sc_f, pairing, symmetric, out=None):
         raise ValueError("out must be a contiguous float64 GPU tensor [2, nM, nF]")
     if symmetric:
         a, b = _desc(sc_m[0], "sc_m[0]"), _desc(sc_f[0], "sc_f[0]")
-        check(nat.load().pm_chi2_cost_pair_sym(ptr(a), nM, ptr(b), nF, t, ptr(out), out.stride(1), out.stride(0), nat.stream_ptr()))
+        lib = nat.load()
+        ws = _sym_workspace(lib, nM, nF, a.device)
+        check(lib.pm_chi2_cost_pair_sym_ws(ptr(a), nM, ptr(b), nF, t, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(),
+                                           nat.stream_ptr()))
     else:
         if sc_f.shape[0] != 4 or sc_m.shape[0] != 2:
             raise ValueError("the general path needs all frames: sc_m [2, nM, 360], sc_f [4, nF, 360]")
@@ -301,7 +311,8 @@ def _out8(out, nM, nF, device):
 def chi2_cost8(sc_m, sc_f, out=None, path="auto"):
     """sc_m: [2, nM, 360], sc_f: [4, nF, 360] -> out [8, nM, nF] in the widget's order 11..14, 21..24.
     path: 'auto' (verify the frame-permutation relation on the device, then take the half-cost kernel if it
-    holds), 'general' (never assume it) or 'symmetric' (caller has verified it).  All paths give identical bits."""
+    holds), 'general' (never assume it), 'symmetric' (caller has verified it) or 'symmetric-computed' (the same without the
+    term table).  All paths give identical bits."""
     torch = _t()
     if not (nat.is_torch(sc_m) and sc_m.dim() == 3 and sc_m.shape[0] == 2 and nat.is_torch(sc_f) and sc_f.dim() == 3
             and sc_f.shape[0] == 4):
@@ -310,11 +321,13 @@ def chi2_cost8(sc_m, sc_f, out=None, path="auto"):
     f = [_desc(sc_f[k], "sc_f[%d]" % k) for k in range(4)]
     nM, nF = m[0].shape[0], f[0].shape[0]
     out = _out8(out, nM, nF, sc_m.device)
-    if path not in ("auto", "general", "symmetric"):
-        raise ValueError("path must be 'auto', 'general' or 'symmetric'")
-    sym = path == "symmetric" or (path == "auto" and chi2_symmetric(sc_m, sc_f))
-    if sym:
+    if path not in ("auto", "general", "symmetric", "symmetric-computed"):
+        raise ValueError("path must be 'auto', 'general', 'symmetric' or 'symmetric-computed'")
+    sym = path.startswith("symmetric") or (path == "auto" and chi2_symmetric(sc_m, sc_f))
+    if sym and path == "symmetric-computed":       # the half-cost kernel without its term table (every term divided out): a yardstick
         check(nat.load().pm_chi2_cost8_sym(ptr(m[0]), nM, ptr(f[0]), nF, ptr(out), out.stride(1), out.stride(0), nat.stream_ptr()))
+    elif sym:
+        chi2_cost8_frame1(m[0], f[0], out=out)
     else:
         check(nat.load().pm_chi2_cost8(ptr(m[0]), ptr(m[1]), nM, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), nF, ptr(out),
                                        out.stride(1), out.stride(0), nat.stream_ptr()))

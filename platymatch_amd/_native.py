@@ -64,6 +64,10 @@ SIGNATURES = {
                                         _c_void_p, _c_void_p]),
     "pm_chi2_cost8_sym": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_size_t, _c_size_t, _c_void_p]),
     "pm_chi2_cost_pair_sym": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_size_t, _c_size_t, _c_void_p]),
+    "pm_chi2_sym_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "pm_chi2_cost8_sym_ws": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_size_t, _c_size_t, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_chi2_cost_pair_sym_ws": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_size_t, _c_size_t, _c_void_p,
+                                          _c_size_t, _c_void_p]),
     "pm_ransac_affine": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int,
                                   _c_double, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "pm_ransac_score": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int,

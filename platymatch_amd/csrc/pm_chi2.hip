@@ -157,14 +157,38 @@ int chi2_launch(const Chi2Args<NFA, NFB> &args, int nA, int nB, double *out, siz
 // TSEL = -1: all four pairings -> eight matrices in the widget's order; TSEL = t: pairing t alone -> its two matrices
 // (natural order first, rolled order second): the cost build of ONE hypothesis and its twin, for clouds whose eight
 // matrices do not fit in HBM together (each pairing's terms are exactly a quarter of the eight-matrix launch).
-template <int SY_RI, int MINW, int TSEL = -1>   // rows per wave; minimum waves per SIMD asked of the register allocator; pairing
+//
+// Term table (TL > 0).  A descriptor value is count / total (get_shape_context: sc / sc.sum(), shape_context.py:40-43), so a
+// term (a-b)^2/(a+b) is a function of two small integers and the two totals.  counts_* below recover the counts from the
+// doubles and VERIFY, bit for bit, that every value is fl(count / total) — nothing is assumed; one failure and the launch
+// computes every term as before.  Where all counts of a shell (both clouds) are below TL, the shell's 48 terms per pair
+// come out of a TL x TL table in LDS, filled at the start of the workgroup by the SAME operations on the SAME operands
+// (fl(ca/totA), fl(cb/totB) or 1e-300, div_pos) — identical bits by construction — at one ds_read_b64 + one address add per
+// term instead of a 13-slot division.  The moving count is wave-uniform (a scalar row offset), the fixed count per lane,
+// so a wave reads one table row: lanes with equal counts broadcast, counts 32 apart conflict.  Shells with larger counts
+// (the outer ones of a large cloud) are computed.
+constexpr int CH_NSHELL = CH_STAGES;
+constexpr int CH_TL = 94;              // 94 x 94 doubles + the staging tiles = 79 392 B: two workgroups per CU (160 KiB), as the registers allow
+struct SymMeta {
+    unsigned long long minbits[2];     // smallest positive descriptor value of each cloud (bit pattern; +inf if none)
+    double tot[2];                     // its reciprocal rounded to an integer: the candidate total
+    int bad;                           // some value is not fl(count / total): no table
+    int pad;
+    int maxc[2][CH_NSHELL];            // largest count per (r, theta) shell, saturated at 255
+};
+
+template <int SY_RI, int MINW, int TSEL = -1, int TL = 0>   // rows per wave; min waves per SIMD for the register allocator; pairing; table size
 __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double *__restrict__ scA, int nA,
                                                                  const double *__restrict__ scB, int nB,
                                                                  double *__restrict__ out, size_t ld, size_t mstride,
-                                                                 int nTi, unsigned int nblocks) {
+                                                                 int nTi, unsigned int nblocks,
+                                                                 const unsigned char *__restrict__ cntA = nullptr,
+                                                                 const unsigned char *__restrict__ cntB = nullptr,
+                                                                 const SymMeta *__restrict__ meta = nullptr) {
     constexpr int SY_TI = 4 * SY_RI;      // rows per tile
     __shared__ __attribute__((aligned(16))) double A_s[SY_TI][CH_K];
     __shared__ __attribute__((aligned(16))) double B_s[CH_TJ][CH_BPITCH];
+    __shared__ __attribute__((aligned(16))) double tab[TL > 0 ? TL * TL : 1];
 
     unsigned int bid = blockIdx.x;
     const unsigned int full = nblocks / 8u * 8u;
@@ -182,7 +206,111 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
 #pragma unroll
         for (int h = 0; h < NH; ++h) acc[r][h] = 0.0;
 
+    unsigned int tabmask = 0;             // shells served from the table (uniform)
+    if constexpr (TL > 0) {
+        if (meta->bad == 0) {
+            for (int g = 0; g < CH_STAGES; ++g)
+                if (meta->maxc[0][g] < TL && meta->maxc[1][g] < TL) tabmask |= 1u << g;
+        }
+        tabmask = __builtin_amdgcn_readfirstlane(tabmask);
+        if (tabmask) {
+            const double totA = meta->tot[0], totB = meta->tot[1];
+            for (int e = tid; e < TL * TL; e += CH_THREADS) {
+                const int ca = e / TL, cb = e - ca * TL;
+                const double a = (double)ca / totA, b = cb ? (double)cb / totB : CH_TINY;
+                const double df = a - b;
+                tab[e] = div_pos(df * df, a + b);
+            }
+            __syncthreads();
+        }
+    }
+
+    // counts of the next tabled shell, fetched one tabled shell ahead (an L2 round trip is about as long as a tabled shell):
+    // the lane's twelve fixed counts (3 dwords) and, per row of the wave, the twelve moving counts (3 dwords, wave-uniform)
+    unsigned int nb[3] = {0, 0, 0}, na[SY_RI][3];
+#pragma unroll
+    for (int r = 0; r < SY_RI; ++r) na[r][0] = na[r][1] = na[r][2] = 0;
+    const unsigned int *pb0 = nullptr, *pa0[SY_RI];
+    if constexpr (TL > 0) {
+        pb0 = reinterpret_cast<const unsigned int *>(cntB + (size_t)min(j0 + lane, nB - 1) * PM_NBINS);
+#pragma unroll
+        for (int r = 0; r < SY_RI; ++r)
+            pa0[r] = reinterpret_cast<const unsigned int *>(cntA + (size_t)min(i0 + wave * SY_RI + r, nA - 1) * PM_NBINS);
+        if (tabmask) {
+            const int g0 = __builtin_ctz(tabmask);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) nb[k] = pb0[g0 * 3 + k];
+#pragma unroll
+            for (int r = 0; r < SY_RI; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) na[r][k] = pa0[r][g0 * 3 + k];
+        }
+    }
+
     for (int g = 0; g < CH_STAGES; ++g) {
+        if constexpr (TL > 0) {
+            if ((tabmask >> g) & 1u) {
+                // this lane's twelve fixed counts of the shell, as byte offsets into a table row
+                const unsigned int wb[3] = {nb[0], nb[1], nb[2]};
+                unsigned int wav[SY_RI][3];
+#pragma unroll
+                for (int r = 0; r < SY_RI; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wav[r][k] = na[r][k];
+                const unsigned int later = tabmask >> g >> 1;
+                if (later) {
+                    const int gn = g + 1 + __builtin_ctz(later);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) nb[k] = pb0[gn * 3 + k];
+#pragma unroll
+                    for (int r = 0; r < SY_RI; ++r)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) na[r][k] = pa0[r][gn * 3 + k];
+                }
+                unsigned int cb8[CH_K];
+#pragma unroll
+                for (int k = 0; k < CH_K; ++k) cb8[k] = ((wb[k >> 2] >> (8 * (k & 3))) & 255u) << 3;
+                const char *tbase = reinterpret_cast<const char *>(tab);
+                unsigned int wa[SY_RI][3];
+#pragma unroll
+                for (int r = 0; r < SY_RI; ++r)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) wa[r][k] = __builtin_amdgcn_readfirstlane(wav[r][k]);
+                // (row, pairing) groups of twelve lookups, software-pipelined by hand: the reads of group i + 1 are issued
+                // before the 24 additions of group i, so that the LDS round trip hides behind them (the scheduler, left alone,
+                // keeps four reads in flight and waits on each)
+                constexpr int NT = (TSEL < 0) ? 4 : 1, NG = SY_RI * NT;
+                double Tc[CH_K], Tn[CH_K];
+                auto lookups = [&](int i, double (&T)[CH_K]) {
+                    const int r = i / NT, t = (TSEL < 0) ? i % NT : TSEL;
+#pragma unroll
+                    for (int p = 0; p < CH_K; ++p) {
+                        const int q = (t == 0) ? p : (t == 1) ? (p + 6) % 12 : (t == 2) ? 11 - p : (17 - p) % 12;
+                        const unsigned int row = ((wa[r][p >> 2] >> (8 * (p & 3))) & 255u) * (unsigned int)(TL * 8);   // scalar
+                        T[p] = *reinterpret_cast<const double *>(tbase + row + cb8[q]);
+                    }
+                };
+                lookups(0, Tc);
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    if (i + 1 < NG) lookups(i + 1, Tn);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int r = i / NT, t = (TSEL < 0) ? i % NT : TSEL;
+                    const int hn = (TSEL < 0) ? t : 0, hr = (TSEL >= 0) ? 1 : (t == 0) ? 5 : (t == 1) ? 4 : (t == 2) ? 7 : 6;
+                    double sn = acc[r][hn], sr = acc[r][hr];
+#pragma unroll
+                    for (int p = 0; p < CH_K; ++p) sn = sn + Tc[p];
+#pragma unroll
+                    for (int p = 0; p < CH_K; ++p) sr = sr + Tc[(p + 6) % 12];
+                    acc[r][hn] = sn;
+                    acc[r][hr] = sr;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int p = 0; p < CH_K; ++p) Tc[p] = Tn[p];
+                }
+                continue;                 // uniform over the workgroup: nothing staged, no barrier
+            }
+        }
         __syncthreads();
         for (int e = tid; e < SY_TI * CH_K; e += CH_THREADS) {
             const int r = e / CH_K, k = e - r * CH_K;
@@ -277,16 +405,153 @@ extern "C" int pm_chi2_symmetry_check(const double *sc_m1, const double *sc_m2, 
 }
 
 namespace pm {
-template <int RI, int MINW, int TSEL = -1>
-int chi2_sym_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld, size_t mstride, hipStream_t s) {
+template <int RI, int MINW, int TSEL = -1, int TL = 0>
+int chi2_sym_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld, size_t mstride, hipStream_t s,
+                    const unsigned char *cntA = nullptr, const unsigned char *cntB = nullptr, const SymMeta *meta = nullptr) {
     const long nTi = ((long)nM + 4 * RI - 1) / (4 * RI), nTj = ((long)nF + CH_TJ - 1) / CH_TJ;
     const long nblocks = nTi * nTj;
     if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
-    chi2_sym_kernel<RI, MINW, TSEL><<<(unsigned int)nblocks, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, mstride, (int)nTi,
-                                                                                (unsigned int)nblocks);
+    if (TL > 0 && (!cntA || !cntB || !meta)) return PM_ERR_INVALID_ARG;
+    chi2_sym_kernel<RI, MINW, TSEL, TL><<<(unsigned int)nblocks, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, mstride, (int)nTi,
+                                                                                    (unsigned int)nblocks, cntA, cntB, meta);
+    return launch_status();
+}
+
+// ---- counts behind the descriptor values (for the term table) -------------------------------------
+__global__ void sym_meta_init_kernel(SymMeta *m) {
+    const int t = threadIdx.x;
+    if (t < 2) {
+        m->minbits[t] = 0x7ff0000000000000ull;
+        m->tot[t] = 0.0;
+    }
+    if (t == 0) m->bad = 0, m->pad = 0;
+    if (t < CH_NSHELL) m->maxc[0][t] = m->maxc[1][t] = 0;
+}
+
+// smallest positive value (count 1 of some bin, in any cloud with a singly occupied bin: 1 / total); anything that is not a
+// finite value >= 0 rules the table out
+__global__ __launch_bounds__(256) void counts_min_kernel(const double *__restrict__ sc, size_t n_entries, SymMeta *m, int which) {
+    unsigned long long best = 0x7ff0000000000000ull;
+    bool bad = false;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n_entries; e += (size_t)gridDim.x * 256) {
+        const double v = sc[e];
+        if (!(v >= 0.0) || v > 1.0) bad = true;
+        else if (v > 0.0) best = min(best, (unsigned long long)__double_as_longlong(v));   // positive doubles order like their bits
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (unsigned long long)__shfl_down((unsigned long long)best, off, PM_WAVE));
+    if ((threadIdx.x & 63) == 0) atomicMin(&m->minbits[which], best);
+    if (bad) atomicOr(&m->bad, 1);
+}
+
+__global__ void counts_total_kernel(SymMeta *m) {
+    const int w = threadIdx.x;
+    if (w >= 2) return;
+    const double v = __longlong_as_double((long long)m->minbits[w]);
+    double tot = 0.0;
+    if (v > 0.0 && v <= 1.0) tot = rint(1.0 / v);
+    if (!(tot >= 1.0 && tot <= 2147483647.0)) {
+        tot = 1.0;
+        atomicOr(&m->bad, 1);
+    }
+    m->tot[w] = tot;
+}
+
+// count = rint(value * total), accepted only if fl(count / total) IS the value; per-shell maxima for the kernel's choice
+__global__ __launch_bounds__(256) void counts_extract_kernel(const double *__restrict__ sc, size_t n_entries, unsigned char *__restrict__ cnt,
+                                                             SymMeta *m, int which) {
+    __shared__ int smax[CH_NSHELL];
+    if (threadIdx.x < CH_NSHELL) smax[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n_entries) {
+        const double tot = m->tot[which], v = sc[e];
+        const double c = rint(v * tot);
+        const bool ok = c >= 0.0 && c <= 2147483647.0 && c / tot == v;
+        if (!ok) atomicOr(&m->bad, 1);
+        const int cc = ok ? (int)min(c, 255.0) : 255;
+        cnt[e] = (unsigned char)cc;
+        atomicMax(&smax[(int)(e % PM_NBINS) / CH_K], cc);
+    }
+    __syncthreads();
+    if (threadIdx.x < CH_NSHELL && smax[threadIdx.x] > 0) atomicMax(&m->maxc[which][threadIdx.x], smax[threadIdx.x]);
+}
+
+constexpr size_t SYM_META_BYTES = 512;
+static_assert(sizeof(SymMeta) <= SYM_META_BYTES, "workspace header");
+
+struct SymWs {
+    SymMeta *meta;
+    unsigned char *cntA, *cntB;
+};
+
+int sym_prepare(const double *sc_m1, int nM, const double *sc_f1, int nF, void *ws, size_t ws_bytes, hipStream_t s, SymWs &w) {
+    if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < pm_chi2_sym_workspace_bytes(nM, nF)) return PM_ERR_WORKSPACE;
+    char *base = (char *)ws;
+    w.meta = (SymMeta *)base;
+    w.cntA = (unsigned char *)(base + SYM_META_BYTES);
+    w.cntB = w.cntA + align_up((size_t)nM * PM_NBINS, 16);
+    const size_t eA = (size_t)nM * PM_NBINS, eB = (size_t)nF * PM_NBINS;
+    sym_meta_init_kernel<<<1, 64, 0, s>>>(w.meta);
+    counts_min_kernel<<<(unsigned int)min((eA + 255) / 256, (size_t)4096), 256, 0, s>>>(sc_m1, eA, w.meta, 0);
+    counts_min_kernel<<<(unsigned int)min((eB + 255) / 256, (size_t)4096), 256, 0, s>>>(sc_f1, eB, w.meta, 1);
+    counts_total_kernel<<<1, 64, 0, s>>>(w.meta);
+    counts_extract_kernel<<<(unsigned int)((eA + 255) / 256), 256, 0, s>>>(sc_m1, eA, w.cntA, w.meta, 0);
+    counts_extract_kernel<<<(unsigned int)((eB + 255) / 256), 256, 0, s>>>(sc_f1, eB, w.cntB, w.meta, 1);
     return launch_status();
 }
 }  // namespace pm
+
+extern "C" size_t pm_chi2_sym_workspace_bytes(int nM, int nF) {
+    if (nM <= 0 || nF <= 0) return 0;
+    return pm::SYM_META_BYTES + pm::align_up((size_t)nM * PM_NBINS, 16) + pm::align_up((size_t)nF * PM_NBINS, 16);
+}
+
+// variant: 0 = 64 x 64 table, 1 = CH_TL x CH_TL (the product's), 2 = no table (the plain kernel; the workspace is still prepared)
+extern "C" int pm_chi2_cost8_sym_ws_variant(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
+                                            size_t matrix_stride, void *ws, size_t ws_bytes, int variant, void *stream) {
+    if (!sc_m1 || !sc_f1 || !out || nM <= 0 || nF <= 0 || ld < (size_t)nF || matrix_stride < (size_t)nM * ld)
+        return PM_ERR_INVALID_ARG;
+    if (((uintptr_t)sc_f1 & 15) != 0 || ((uintptr_t)sc_m1 & 15) != 0) return PM_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    pm::SymWs w;
+    const int rc = pm::sym_prepare(sc_m1, nM, sc_f1, nF, ws, ws_bytes, s, w);
+    if (rc != PM_OK) return rc;
+    switch (variant) {
+        case 0: return pm::chi2_sym_launch<4, 2, -1, 64>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta);
+        case 1: return pm::chi2_sym_launch<4, 2, -1, pm::CH_TL>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta);
+        case 2: return pm::chi2_sym_launch<4, 2>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s);
+        case 3: return pm::chi2_sym_launch<4, 3, -1, 64>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta);
+        case 4: return pm::chi2_sym_launch<4, 3, -1, 48>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta);
+        case 5:      // the 88-table kernel with the table ruled out: what its computed shells cost at its occupancy
+            if (hipMemsetAsync(&w.meta->bad, 1, 1, s) != hipSuccess) return pm::launch_status();
+            return pm::chi2_sym_launch<4, 2, -1, pm::CH_TL>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta);
+        default: return PM_ERR_INVALID_ARG;
+    }
+}
+
+extern "C" int pm_chi2_cost8_sym_ws(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
+                                    size_t matrix_stride, void *ws, size_t ws_bytes, void *stream) {
+    return pm_chi2_cost8_sym_ws_variant(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, ws, ws_bytes, 1, stream);
+}
+
+extern "C" int pm_chi2_cost_pair_sym_ws(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out2, size_t ld,
+                                        size_t matrix_stride, void *ws, size_t ws_bytes, void *stream) {
+    if (!sc_m1 || !sc_f1 || !out2 || nM <= 0 || nF <= 0 || ld < (size_t)nF || matrix_stride < (size_t)nM * ld)
+        return PM_ERR_INVALID_ARG;
+    if (((uintptr_t)sc_f1 & 15) != 0 || ((uintptr_t)sc_m1 & 15) != 0) return PM_ERR_INVALID_ARG;
+    if (pairing < 0 || pairing > 3) return PM_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    pm::SymWs w;
+    const int rc = pm::sym_prepare(sc_m1, nM, sc_f1, nF, ws, ws_bytes, s, w);
+    if (rc != PM_OK) return rc;
+    switch (pairing) {
+        case 0: return pm::chi2_sym_launch<4, 2, 0, pm::CH_TL>(sc_m1, nM, sc_f1, nF, out2, ld, matrix_stride, s, w.cntA, w.cntB, w.meta);
+        case 1: return pm::chi2_sym_launch<4, 2, 1, pm::CH_TL>(sc_m1, nM, sc_f1, nF, out2, ld, matrix_stride, s, w.cntA, w.cntB, w.meta);
+        case 2: return pm::chi2_sym_launch<4, 2, 2, pm::CH_TL>(sc_m1, nM, sc_f1, nF, out2, ld, matrix_stride, s, w.cntA, w.cntB, w.meta);
+        default: return pm::chi2_sym_launch<4, 2, 3, pm::CH_TL>(sc_m1, nM, sc_f1, nF, out2, ld, matrix_stride, s, w.cntA, w.cntB, w.meta);
+    }
+}
 
 extern "C" int pm_chi2_cost_pair_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out2, size_t ld,
                                      size_t matrix_stride, void *stream) {

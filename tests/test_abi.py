@@ -75,6 +75,9 @@ def test_every_entry_point_rejects_bad_arguments_before_touching_the_device(lib_
     assert lib.pm_fit_affine(fake, 10, fake, 10, None, fake, None, None, 0, None) == -2
     assert lib.pm_ransac_affine(fake, 10, fake, 10, None, None, 10, fake, 3, 5, 1.0, fake, fake, None, None) == -4      # < 4 pairs: host pinv
     assert lib.pm_get_error(fake, fake, 10, fake, None, 0, None) == -2
+    assert lib.pm_chi2_cost8_sym_ws(fake, 10, fake, 10, fake, 10, 100, None, 0, None) == -2
+    assert lib.pm_chi2_cost_pair_sym_ws(fake, 10, fake, 10, 1, fake, 10, 100, fake, 64, None) == -2     # workspace too small
+    assert lib.pm_chi2_sym_workspace_bytes(10, 20) == 512 + 3600 + 7200
     assert lib.pm_shape_context(fake, 10, 8, 5, fake, fake, fake, 4, fake, None, None, None) == -1     # row block outside the cloud
     assert lib.pm_shape_context(fake, 10, 0, 5, fake, fake, fake, 3, fake, None, None, None) == -1     # 3 frames do not exist
     assert lib.pm_chi2_cost(fake, 4, fake, 4, fake, 3, None) == -1                                     # ld < columns

@@ -761,3 +761,82 @@ def test_argument_errors_raise(gpu):
     with pytest.raises(IndexError):
         gpu.K.fit_affine(t.zeros((3, 5), dtype=t.float64, device=gpu.dev), t.zeros((3, 5), dtype=t.float64, device=gpu.dev),
                          nn=t.full((5,), 7, dtype=t.int32, device=gpu.dev))
+
+
+def _table_launch(gpu, a, b, ws=None):
+    """pm_chi2_cost8_sym_ws called directly -> (U [8, nA, nB], meta dict read back from the workspace header)."""
+    import ctypes
+    from platymatch_amd import _native as nat
+    lib = nat.load()
+    nA, nB = a.shape[0], b.shape[0]
+    need = int(lib.pm_chi2_sym_workspace_bytes(nA, nB))
+    ws = gpu.t.empty(need, dtype=gpu.t.uint8, device=a.device) if ws is None else ws
+    out = gpu.t.empty((8, nA, nB), dtype=gpu.t.float64, device=a.device)
+    rc = lib.pm_chi2_cost8_sym_ws(a.data_ptr(), nA, b.data_ptr(), nB, out.data_ptr(), nB, nA * nB, ws.data_ptr(), ws.numel(), 0)
+    gpu.t.cuda.synchronize()
+    if rc != 0:
+        return rc, None
+    head = ws[:512].cpu().numpy().tobytes()
+    meta = {"tot": np.frombuffer(head[16:32], dtype=np.float64).tolist(), "bad": int(np.frombuffer(head[32:36], dtype=np.int32)[0]),
+            "maxc": np.frombuffer(head[40:40 + 240], dtype=np.int32).reshape(2, 30)}
+    meta["counts_a"] = ws[512:512 + nA * 360].cpu().numpy().reshape(nA, 360)
+    return out, meta
+
+
+@pytest.mark.parametrize("n,m,seed", [(331, 331, 0), (1000, 777, 1), (3000, 3000, 2), (9000, 6000, 3)])
+def test_term_table_gives_the_computed_bits(gpu, n, m, seed):
+    """The half-cost kernel takes the terms of sparsely filled shells from a table indexed by the two bin COUNTS (a
+    descriptor value is count / total, shape_context.py:40-43).  Same bits as with every term divided out, for real
+    descriptors (table used: counts recovered and verified), for clouds of different sizes (two totals), with shells above
+    the table size and above the 8-bit count range (9000 points: outer bins hold hundreds of neighbours)."""
+    mv, fx, _ = synth_pair(max(n, m), seed)
+    mv, fx = np.ascontiguousarray(mv[:, :n]), np.ascontiguousarray(fx[:, :m])
+    x, y = gpu.d(mv), gpu.d(fx)
+    hm = gpu.K.shape_context(x, gpu.K.centroid(x), gpu.K.pca_axis(x), gpu.K.mean_distance(x), 2)["hist"]
+    hf = gpu.K.shape_context(y, gpu.K.centroid(y), gpu.K.pca_axis(y), gpu.K.mean_distance(y), 4)["hist"]
+    computed = gpu.K.chi2_cost8(hm, hf, path="symmetric-computed")
+    U, meta = _table_launch(gpu, hm[0], hf[0])
+    assert gpu.t.equal(U, computed)
+    assert gpu.t.equal(gpu.K.chi2_cost8(hm, hf, path="symmetric"), computed)
+    assert meta["bad"] == 0 and meta["tot"] == [n - 1.0, m - 1.0]
+    counts = np.rint(hm[0].cpu().numpy() * (n - 1)).astype(np.int64)
+    assert np.array_equal(meta["counts_a"], np.minimum(counts, 255))
+    shell_max = counts.reshape(n, 30, 12).max(axis=(0, 2))
+    assert np.array_equal(meta["maxc"][0], np.minimum(shell_max, 255))
+    tabled = (meta["maxc"] < 94).all(axis=0)
+    assert tabled.any() and (n < 3000 or not tabled.all())             # the table is in use; large clouds also compute
+
+
+def test_term_table_is_ruled_out_for_anything_but_count_over_total(gpu):
+    """Values that are not fl(count / total) — arbitrary histograms, one value an ulp off, a NaN row — make the launch compute
+    every term: still the computed kernel's bits."""
+    rng = np.random.default_rng(12)
+    n, m = 300, 280
+    a = rng.random((n, 360)); a /= a.sum(1, keepdims=True)
+    b = rng.random((m, 360)); b /= b.sum(1, keepdims=True)
+    da, db = gpu.d(a), gpu.d(b)
+    lib_out = gpu.t.empty((8, n, m), dtype=gpu.t.float64, device=da.device)
+    from platymatch_amd import _native as nat
+    nat.check(nat.load().pm_chi2_cost8_sym(da.data_ptr(), n, db.data_ptr(), m, lib_out.data_ptr(), m, n * m, 0))
+    U, meta = _table_launch(gpu, da, db)
+    assert meta["bad"] == 1 and gpu.t.equal(U, lib_out)
+    # genuine count / total descriptors, then one value nudged by an ulp / a row of NaN
+    ca, cb = rng.integers(0, 7, (n, 360)), rng.integers(0, 120, (m, 360))
+    ca[:, 0], cb[:, 0] = 1, 1
+    a, b = ca / ca.sum(1, keepdims=True).max(), cb / cb.sum(1, keepdims=True).max()           # one common total per cloud
+    for kind in ("clean", "ulp", "nan"):
+        b2 = b.copy()
+        if kind == "ulp":
+            b2[7, 100] = np.nextafter(b2[7, 100], 1.0)
+        if kind == "nan":
+            b2[9] = np.nan
+        da, db = gpu.d(a), gpu.d(b2)
+        nat.check(nat.load().pm_chi2_cost8_sym(da.data_ptr(), n, db.data_ptr(), m, lib_out.data_ptr(), m, n * m, 0))
+        U, meta = _table_launch(gpu, da, db)
+        assert meta["bad"] == (0 if kind == "clean" else 1), kind
+        assert np.array_equal(U.cpu().numpy(), lib_out.cpu().numpy(), equal_nan=True), kind
+    # workspace too small or misaligned: refused
+    small = gpu.t.empty(600, dtype=gpu.t.uint8, device=da.device)
+    assert _table_launch(gpu, da, db, ws=small)[0] == -2
+    big = gpu.t.empty(1 << 20, dtype=gpu.t.uint8, device=da.device)
+    assert _table_launch(gpu, da, db, ws=big[8:])[0] == -2
