@@ -164,6 +164,9 @@ int pm_chi2_cost8_sym_ws(const double *sc_m1, int nM, const double *sc_f1, int n
                          size_t matrix_stride, void *ws, size_t ws_bytes, void *stream);
 int pm_chi2_cost_pair_sym_ws(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out2, size_t ld,
                              size_t matrix_stride, void *ws, size_t ws_bytes, void *stream);
+/* Report (benchmarks, tests): tabled30[g] = 1 if the last *_ws launch on this workspace took shell g = 6*ring + theta sector from
+ * the table, table_size = its side.  Copies 300 bytes to the host and synchronises the stream. */
+int pm_chi2_sym_table_info(const void *ws, int32_t *tabled30, int32_t *table_size, void *stream);
 
 /* np.argmin(U_h, axis=1) for n_mat stacked cost matrices (U_h = U + h*matrix_stride, rows x cols, leading
  * dimension ld): idx[h*rows + i] = first index of the minimum of row i, or of the first NaN if the row holds one

@@ -248,9 +248,10 @@ def chi2_symmetric(sc_m, sc_f):
     return int(chi2_symmetry_flag(sc_m, sc_f).item()) == 0
 
 
-def chi2_cost8_frame1(sc_m1, sc_f1, out=None):
+def chi2_cost8_frame1(sc_m1, sc_f1, out=None, info=None):
     """The eight matrices from the frame-1 descriptors alone ([nM, 360], [nF, 360]) by the half-cost kernel.  Only for
-    descriptor sets whose frames 2..4 were verified (chi2_symmetry_flag == 0) to be permutations of frame 1."""
+    descriptor sets whose frames 2..4 were verified (chi2_symmetry_flag == 0) to be permutations of frame 1.
+    info (dict): receives which of the 30 (ring, theta) shells were served from the term table (synchronises)."""
     torch = _t()
     a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
     nM, nF = a.shape[0], b.shape[0]
@@ -258,6 +259,12 @@ def chi2_cost8_frame1(sc_m1, sc_f1, out=None):
     lib = nat.load()
     ws = _sym_workspace(lib, nM, nF, a.device)
     check(lib.pm_chi2_cost8_sym_ws(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(), nat.stream_ptr()))
+    if info is not None:
+        import ctypes
+        tabled, size = (ctypes.c_int32 * 30)(), ctypes.c_int32(0)
+        check(lib.pm_chi2_sym_table_info(ptr(ws), ctypes.addressof(tabled), ctypes.addressof(size), nat.stream_ptr()))
+        info["tabled_shells"] = [int(x) for x in tabled]
+        info["table_size"] = int(size.value)
     return out
 
 

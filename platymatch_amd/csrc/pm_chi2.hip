@@ -530,6 +530,22 @@ extern "C" int pm_chi2_cost8_sym_ws_variant(const double *sc_m1, int nM, const d
     }
 }
 
+// which shells the last *_ws launch on this workspace served from its table (a report for benchmarks and tests; synchronises)
+extern "C" int pm_chi2_sym_table_info(const void *ws, int32_t *tabled30, int32_t *table_size, void *stream) {
+    if (!ws || !tabled30 || !table_size) return PM_ERR_INVALID_ARG;
+    pm::SymMeta m;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(&m, ws, sizeof(m), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+    {
+        pm::launch_status();
+        return PM_ERR_LAUNCH;
+    }
+    for (int g = 0; g < pm::CH_NSHELL; ++g)
+        tabled30[g] = (m.bad == 0 && m.maxc[0][g] < pm::CH_TL && m.maxc[1][g] < pm::CH_TL) ? 1 : 0;
+    *table_size = pm::CH_TL;
+    return PM_OK;
+}
+
 extern "C" int pm_chi2_cost8_sym_ws(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
                                     size_t matrix_stride, void *ws, size_t ws_bytes, void *stream) {
     return pm_chi2_cost8_sym_ws_variant(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, ws, ws_bytes, 1, stream);
