@@ -4,6 +4,8 @@ Every function validates shapes, dtypes and index ranges on the host before a ke
 enqueued (a faulting kernel can take the whole node down), allocates outputs/workspace with
 torch, and launches on torch's current stream.  Clouds are float64 [3, N] contiguous.
 """
+import os
+
 from . import _native as nat
 from ._native import NBINS, ICP_NSUMS, check, ptr
 
@@ -248,6 +250,10 @@ def chi2_symmetric(sc_m, sc_f):
     return int(chi2_symmetry_flag(sc_m, sc_f).item()) == 0
 
 
+# Measurement knob (tools/): False = the half-cost kernel divides every term (no term table).  Same bits either way.
+TERM_TABLE = os.environ.get("PM_CHI2_TERM_TABLE", "1") != "0"
+
+
 def chi2_cost8_frame1(sc_m1, sc_f1, out=None, info=None):
     """The eight matrices from the frame-1 descriptors alone ([nM, 360], [nF, 360]) by the half-cost kernel.  Only for
     descriptor sets whose frames 2..4 were verified (chi2_symmetry_flag == 0) to be permutations of frame 1.
@@ -257,6 +263,9 @@ def chi2_cost8_frame1(sc_m1, sc_f1, out=None, info=None):
     nM, nF = a.shape[0], b.shape[0]
     out = _out8(out, nM, nF, a.device)
     lib = nat.load()
+    if not TERM_TABLE:
+        check(lib.pm_chi2_cost8_sym(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), nat.stream_ptr()))
+        return out
     ws = _sym_workspace(lib, nM, nF, a.device)
     check(lib.pm_chi2_cost8_sym_ws(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(), nat.stream_ptr()))
     if info is not None:
@@ -274,6 +283,26 @@ def _sym_workspace(lib, nM, nF, device):
 
 
 PAIRINGS = ((0, 5), (1, 4), (2, 7), (3, 6))      # pairing t -> (hypothesis summed in natural order, its twin), widget numbering
+
+
+def chi2_cost8_frame1_by_pairings(sc_m1, sc_f1, out=None):
+    """chi2_cost8_frame1 as four launches, one per pairing (each writes its hypothesis and its twin into the eight-matrix
+    buffer: the same bits), with an event after each -> (out [8, nM, nF], [event] * 4).  The assignment of pairing t can start
+    when event t has fired, while the later pairings are still being built (lsap.solve_eight_on_device(ready=...))."""
+    torch = _t()
+    a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
+    nM, nF = a.shape[0], b.shape[0]
+    out = _out8(out, nM, nF, a.device)
+    lib = nat.load()
+    ws = _sym_workspace(lib, nM, nF, a.device)          # one workspace: the launches are ordered on the stream
+    events = []
+    for t, (h, twin) in enumerate(PAIRINGS):
+        check(lib.pm_chi2_cost_pair_sym_ws(ptr(a), nM, ptr(b), nF, t, ptr(out[h]), out.stride(1), (twin - h) * out.stride(0), ptr(ws),
+                                           ws.numel(), nat.stream_ptr()))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(a.device))
+        events.append(ev)
+    return out, events
 
 
 def chi2_cost_pair(sc_m, sc_f, pairing, symmetric, out=None):

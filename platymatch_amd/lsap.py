@@ -448,12 +448,16 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
     return out
 
 
-def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False):
+def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False, ready=None):
     """The widget's eight assignments (_dock_widget.py:604-611) for U8 [8, N, M] on the GPU: hypotheses 11, 12, 13, 14 are
     solved (four host threads drive their core solves and kernels concurrently), each together with its twin (22, 21, 24,
     23: solve_pair_on_device).  -> list of eight (row_ind, col_ind).
     allow_host=False: never take the dense host solver (hours at 50 000 nuclei); a hypothesis that cannot be certified comes
-    back as None instead (bench.py's bounded extra leg)."""
+    back as None instead (bench.py's bounded extra leg).
+    ready: four events, one per pairing (U11/U22, U12/U21, U13/U24, U14/U23), recorded when that pairing's two matrices have
+    been written (_kernels.chi2_cost8_frame1_by_pairings): its solve starts then, while later pairings are still being built.
+    (Measured at 50 000 nuclei: no gain — the three wrong-frame hypotheses need the same ~2.8 s each, so the last one built
+    decides, and the solver's matrix queries queue behind the cost kernel: 4.5 s against 4.0 s.  The driver does not use it.)"""
     torch = nat.torch_mod()
     n, m = U8.shape[1], U8.shape[2]
     out = [None] * 8
@@ -473,10 +477,13 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
         twin = [t for t, s in TWINS.items() if s == h][0]
         stream = torch.cuda.Stream(device=U8.device)
         with torch.cuda.device(U8.device), torch.cuda.stream(stream):
+            if ready is not None:
+                stream.wait_event(ready[h])
             out[h], out[twin] = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], allow_host, accept_near_ties)
             stream.synchronize()
 
-    torch.cuda.current_stream(U8.device).synchronize()      # U8 was produced on the caller's stream
+    if ready is None:
+        torch.cuda.current_stream(U8.device).synchronize()  # U8 was produced on the caller's stream
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(pair, range(4)))
     if info is not None:

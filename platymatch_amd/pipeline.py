@@ -71,8 +71,12 @@ class GpuBackend:
         return self.K.chi2_cost_pair(sc_m, sc_f, pairing, sym, out=out)
 
     def free_bytes(self):
+        """Device memory a new allocation can draw on: what the driver reports free plus what torch's caching allocator holds
+        without using (the eight matrices of a previous registration sit there: counting them as taken would send the next
+        registration of the same size into the streamed mode)."""
         import torch
-        return torch.cuda.mem_get_info(self.device)[0]
+        cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        return torch.cuda.mem_get_info(self.device)[0] + max(int(cached), 0)
 
     def row_argmin(self, U):
         return self.K.row_argmin(U)
@@ -293,7 +297,7 @@ def cost_row_argmins(be, mov, fix, rows_per_block=None, group=None):
 SHARDED_ASSIGN_MIN_ROWS = 1024     # below this the gather + dense host solve is quicker than the sharded solve's round trips
 
 
-def assign(U_loc, bounds, group=None, info=None, local_matrix=None, accept_near_ties=False):
+def assign(U_loc, bounds, group=None, info=None, local_matrix=None, accept_near_ties=False, ready=None):
     """linear_sum_assignment on each of the eight matrices (_dock_widget.py:604-611) -> list of
     (row_ind, col_ind) int64 arrays, identical on every rank.  On a GPU the matrices never leave HBM: a sparse core
     of each is solved on the host and certified against every entry on the device (lsap.solve_on_device; tied or small
@@ -310,7 +314,7 @@ def assign(U_loc, bounds, group=None, info=None, local_matrix=None, accept_near_
         if U_loc.is_cuda:
             # matrices stay in HBM: sparse-core solves driven from four host threads, certified on the device against every
             # entry (lsap.solve_eight_on_device); small or tied matrices take the dense host solver, SciPy's algorithm itself
-            out = solve_eight_on_device(U_loc, info=info, accept_near_ties=accept_near_ties)
+            out = solve_eight_on_device(U_loc, info=info, accept_near_ties=accept_near_ties, ready=ready)
             for h, ans in enumerate(out):
                 if ans is None:          # only for matrices beyond the dense solver's reach (lsap.DENSE_FALLBACK_MAX_ENTRIES)
                     raise RuntimeError("hypothesis %s: the assignment could not be certified unique (an alternative within ~1e-11 of "
@@ -645,8 +649,8 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
     in_flight = [0.0]
     budget = 0.0
     if on_gpu:
-        free_b, total_b = torch.cuda.mem_get_info(dev)
-        budget = 0.8 * free_b
+        free_b = torch.cuda.mem_get_info(dev)[0] + max(int(torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)), 0)
+        budget = 0.8 * free_b                # (what torch's allocator holds unused is there to be drawn on, as in GpuBackend.free_bytes)
 
     def need(k):
         n, m = _pair_size(pairs[k])

@@ -261,3 +261,24 @@ def test_near_tie_beyond_the_dense_solvers_reach_raises_unless_accepted(dev, mon
     ih = {}
     out = L.solve_pair_on_device(Ud, Ud, ih, {})
     assert ih["route"] == "host" and np.array_equal(out[0][1], cs)
+
+
+def test_cost_build_by_pairings_writes_the_same_eight_matrices(dev):
+    """The pipelined build (one launch per pairing into the eight-matrix buffer, an event each) against the single launch,
+    and the assignment started from the events against the one started after a full synchronise."""
+    import torch
+    from platymatch_amd import _kernels as K, lsap as L
+    mv, fx, _ = synth_pair(1500, 5)
+    x, y = dev(mv), dev(np.ascontiguousarray(fx[:, :1400]))
+    hm = K.shape_context(x, K.centroid(x), K.pca_axis(x), K.mean_distance(x), 2)["hist"]
+    hf = K.shape_context(y, K.centroid(y), K.pca_axis(y), K.mean_distance(y), 4)["hist"]
+    assert K.chi2_symmetric(hm, hf)
+    U = K.chi2_cost8_frame1(hm[0], hf[0])
+    U2, events = K.chi2_cost8_frame1_by_pairings(hm[0], hf[0])
+    a = L.solve_eight_on_device(U2, ready=events)                 # starts while later pairings may still be in flight
+    torch.cuda.synchronize()
+    assert len(events) == 4 and torch.equal(U, U2)
+    b = L.solve_eight_on_device(U)
+    for h in range(8):
+        assert np.array_equal(a[h][0], b[h][0]) and np.array_equal(a[h][1], b[h][1])
+        assert np.array_equal(a[h][1], scipy_lsa(U[h].cpu().numpy())[1])
