@@ -115,7 +115,37 @@ __attribute__((target("avx512f,avx512bw,avx512vl,bmi2,popcnt"))) static long con
     long used = 0, i = *pi, wp = *pw;
     const __m512i vmask = _mm512_set1_epi32((int)mask);
     const __m512i lane = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-    while (avail - used >= 16 && i - 16 >= lo) {
+    for (;;) {
+        // 64 draws at once, free of the count-to-threshold dependency: over these draws i stays within [i0 - 63, i0], so a value
+        // <= i0 - 63 is accepted and one > i0 rejected whatever the counts are; only a value inside that band needs them.
+        if (avail - used >= 64 && i - 64 >= lo) {
+            const __m512i hi = _mm512_set1_epi32((int)i), below = _mm512_set1_epi32((int)(i - 63));
+            const __m512i v0 = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used)), vmask);
+            const __m512i v1 = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used + 16)), vmask);
+            const __m512i v2 = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used + 32)), vmask);
+            const __m512i v3 = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used + 48)), vmask);
+            const __mmask16 h0 = _mm512_cmple_epu32_mask(v0, hi), h1 = _mm512_cmple_epu32_mask(v1, hi);
+            const __mmask16 h2 = _mm512_cmple_epu32_mask(v2, hi), h3 = _mm512_cmple_epu32_mask(v3, hi);
+            const __mmask16 l0 = _mm512_cmple_epu32_mask(v0, below), l1 = _mm512_cmple_epu32_mask(v1, below);
+            const __mmask16 l2 = _mm512_cmple_epu32_mask(v2, below), l3 = _mm512_cmple_epu32_mask(v3, below);
+            if ((((unsigned)h0 ^ (unsigned)l0) | ((unsigned)h1 ^ (unsigned)l1) | ((unsigned)h2 ^ (unsigned)l2) | ((unsigned)h3 ^ (unsigned)l3)) == 0) {
+                // (compress in registers + a full-width store: what lies beyond the accepted values is overwritten by the next store;
+                // w has 64 entries of slack)
+                const int c0 = __builtin_popcount((unsigned)h0), c1 = __builtin_popcount((unsigned)h1);
+                const int c2 = __builtin_popcount((unsigned)h2), c3 = __builtin_popcount((unsigned)h3);
+                _mm512_storeu_si512((void *)(w + wp), _mm512_maskz_compress_epi32(h0, v0));
+                _mm512_storeu_si512((void *)(w + wp + c0), _mm512_maskz_compress_epi32(h1, v1));
+                _mm512_storeu_si512((void *)(w + wp + c0 + c1), _mm512_maskz_compress_epi32(h2, v2));
+                _mm512_storeu_si512((void *)(w + wp + c0 + c1 + c2), _mm512_maskz_compress_epi32(h3, v3));
+                const int acc = c0 + c1 + c2 + c3;
+                wp += acc;
+                i -= acc;
+                used += 64;
+                continue;
+            }
+        }
+        // 16 draws: the acceptance pattern as the fixed point of a_t = [v_t <= i0 - #{s < t: a_s}] (see above)
+        if (!(avail - used >= 16 && i - 16 >= lo)) break;
         const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used)), vmask);
         const __m512i thr0 = _mm512_sub_epi32(_mm512_set1_epi32((int)i), lane);                  // every earlier draw accepted
         const __mmask16 a0 = _mm512_cmple_epu32_mask(v, thr0);
@@ -132,7 +162,7 @@ __attribute__((target("avx512f,avx512bw,avx512vl,bmi2,popcnt"))) static long con
         const __m512i thr1 = _mm512_sub_epi32(_mm512_set1_epi32((int)i), cnt);
         const __mmask16 a1 = _mm512_cmple_epu32_mask(v, thr1);
         if (a0 != a1) break;                                                                      // a draw in the band: scalar decides
-        _mm512_mask_compressstoreu_epi32((void *)(w + wp), a0, v);
+        _mm512_storeu_si512((void *)(w + wp), _mm512_maskz_compress_epi32(a0, v));
         const int acc = __builtin_popcount(m0);
         wp += acc;
         i -= acc;
