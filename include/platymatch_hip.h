@@ -239,6 +239,12 @@ int pm_lsap_core_init_duals(void *core, const double *u, const double *v, const 
 int pm_lsap_core_init_state(void *core, const double *u, const double *v, const int32_t *col4row);
 void pm_lsap_core_destroy(void *core);
 int pm_lsap_core_add(void *core, int k, const int32_t *cols, const double *costs);
+/* Optional warm start of the first solve (after the edges and, for square problems, pm_lsap_core_init_duals): a forward auction
+ * with eps-scaling from eps0 down to eps_min (divided by factor per round) over the core's edges.  Leaves feasible duals
+ * close to the optimum's and the tight part of the auction's assignment; pm_lsap_core_solve completes it exactly as it
+ * would any other feasible start.  May be called repeatedly (e.g. after pm_lsap_core_reprice added edges) as long as
+ * pm_lsap_core_solve has not run.  max_bids > 0 bounds the work of this call; bids (may be NULL): bids placed so far. */
+int pm_lsap_core_auction(void *core, double eps0, double eps_min, double factor, long max_bids, long *bids);
 int pm_lsap_core_solve(void *core);
 int pm_lsap_core_reprice(void *core, int k, const int32_t *cand_col, const double *cand_cost, double delta, int *n_violated);
 int pm_lsap_core_get(void *core, double *u, double *v, int32_t *col4row, long *stats4);

@@ -16,13 +16,20 @@ from platymatch_amd import lsap as L, pipeline as P  # noqa: E402
 
 n, seed = int(sys.argv[1]), int(sys.argv[2])
 mv, fx, _ = synth_pair(n, seed)
+if os.environ.get("PM_LSAP_M"):                      # a rectangular problem: fewer fixed points
+    fx = np.ascontiguousarray(fx[:, :int(os.environ["PM_LSAP_M"])])
+if os.environ.get("PM_LSAP_N"):
+    mv = np.ascontiguousarray(mv[:, :int(os.environ["PM_LSAP_N"])])
 be = P.GpuBackend()
 U, _ = P.build_costs(be, be.cloud(mv), be.cloud(fx))
 torch.cuda.synchronize()
-for h in range(8):
+if os.environ.get("PM_LSAP_AUCTION") == "0":
+    L.AUCTION = None
+hyps = [int(x) for x in os.environ.get("PM_LSAP_HYPS", "0,1,2,3,4,5,6,7").split(",")]
+for h in hyps:
     info = {}
     t = time.perf_counter()
-    W = L.DeviceMatrix(U[h])
+    W = L.DeviceMatrix(U[h] if U.shape[1] <= U.shape[2] else U[h].t().contiguous())       # rows are the short side
     sol = L.solve_core(W, info)
     t1 = time.perf_counter() - t
     t = time.perf_counter()
