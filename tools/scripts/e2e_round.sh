@@ -5,5 +5,5 @@ while kill -0 $PID 2>/dev/null; do sleep 30; echo "[suite running]"; done
 tail -3 gpurun_out/gpu_suite.log
 for n in 5000 20000 50000; do
   timeout -k 10 300 python tools/e2e_timing.py $n > gpurun_out/e2e_$n.log 2>&1
-  grep -v amdgpu gpurun_out/e2e_$n.log | tail -3 | cut -c1-330
+  grep -v amdgpu gpurun_out/e2e_$n.log | tail -2 | cut -c1-330
 done
