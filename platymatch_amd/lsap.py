@@ -285,7 +285,7 @@ ROW_REDUCTION_ROUNDS = 0
 # row freed after the auction strands its column below the dual a free column must carry, and each of those costs a dummy row a
 # long search; near-square problems still gain (20 000 x 19 800: 0.67 s -> 0.54 s), clearly rectangular ones lose
 # (20 000 x 18 000: 0.20 s -> 0.65 s) and are quick without it, because spare columns keep the searches short.
-AUCTION = dict(eps0=0.25, eps_min=1e-6, factor=5.0, rounds=3, later_eps0=0.01, bids_per_row=40, stop_below=0.02, max_free_columns=0.02)
+AUCTION = None if os.environ.get("PM_LSAP_AUCTION") == "0" else dict(eps0=0.25, eps_min=1e-6, factor=5.0, rounds=3, later_eps0=0.01, bids_per_row=40, stop_below=0.02, max_free_columns=0.02)
 
 
 def _row_reduction(M, v, rounds):
