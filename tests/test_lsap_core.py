@@ -251,3 +251,41 @@ def test_engineered_near_ties_are_certified_only_above_the_margin():
             assert abs(U[np.arange(n), sol[2]].sum() - U[rs, cs].sum()) <= 1e-12 * n
     assert certified[1e-3] and certified[1e-6] and certified[1e-9]
     assert not certified[1e-14] and not certified[0.0]                        # within the margin (floor 1e-11 of the scale): refused
+
+
+@pytest.mark.parametrize("shape", [(400, 400), (990, 1000), (257, 300), (64, 900), (1200, 1200)])
+def test_auction_warm_start_never_changes_the_certified_answer(shape, monkeypatch):
+    """lsap.AUCTION (eps-scaling forward auction over the core before the first shortest-path solve; reverse steps for spare
+    columns): off, on, forced on for clearly rectangular problems, starved of bids (the budget stops it mid-round) and with a
+    coarse final eps — the certified assignment is SciPy's every time; only the amount of search left differs."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    U = rng.random(shape) * rng.random((1, shape[1])) + 0.3 * rng.random((shape[0], 1)) + 0.05 * rng.random(shape)
+    r, c = scipy_lsa(U)
+    base = dict(L.AUCTION)
+    steps = {}
+    for name, setting in (("off", None), ("on", base), ("always", dict(base, max_free_columns=1.0)),
+                          ("starved", dict(base, max_free_columns=1.0, bids_per_row=1)),
+                          ("coarse", dict(base, max_free_columns=1.0, eps_min=0.05, rounds=1))):
+        monkeypatch.setattr(L, "AUCTION", setting)
+        got, info = run(U)
+        assert got is not None, (name, info)
+        assert np.array_equal(got[0], r) and np.array_equal(got[1], c), (name, info)
+        steps[name] = info["steps"]
+        assert ("auction_bids" in info) == (name != "off" and (name != "on" or shape[1] - shape[0] <= 0.02 * shape[1])), (name, info)
+    if shape[0] == shape[1]:
+        assert steps["on"] < steps["off"], steps                     # the point of it: less search left
+
+
+def test_rectangular_cores_do_not_scan_dummy_rows_densely():
+    """With spare columns the squared problem's dummy rows hold columns too; a search must not pay a dense scan for each one
+    it meets (pm_lsap_core.cpp: scan_row), nor a phase spoil the duals of spare columns.  The counters say so: at most a few
+    dummy scans per dummy row."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(77)
+    n, m = 700, 1000
+    U = rng.random((n, m)) * rng.random((1, m)) + 0.2 * rng.random((n, 1))
+    got, info = run(U)
+    assert got is not None and np.array_equal(got[1], scipy_lsa(U)[1])
+    dummy_scans = info["dummy_scans"] % 1000000
+    assert dummy_scans <= 3 * (m - n), info
