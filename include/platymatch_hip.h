@@ -222,6 +222,9 @@ int pm_lsap_col_min(const double *U, int nr, int nc, size_t ld, double *v, void 
 int pm_lsap_certificate(const double *U, int nr, int nc, size_t ld, const double *u, const double *v,
                         const int32_t *col4row, double delta, double eps, int32_t *summary4, double *stats2,
                         int32_t *tight, double *tight_red, int cap, double *row_slack, double *row_neg, void *stream);
+/* dst[j*ld_dst + i] = src[i*ld_src + j] for a rows x cols matrix (dst: cols x rows): the solver takes the short side of a cost
+ * matrix as its rows (as SciPy does); with more moving than fixed nuclei that is the transpose of what the cost kernels write. */
+int pm_transpose_f64(const double *src, int rows, int cols, size_t ld_src, double *dst, size_t ld_dst, void *stream);
 
 /* HOST: the sparse core solver, one instance per matrix (nr <= nc; nc - nr implicit zero-cost dummy rows square the
  * problem).  add: k candidate edges per real row (cols [nr][k], -1 skipped, duplicates skipped).  solve: augment every

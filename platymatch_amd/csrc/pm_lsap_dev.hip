@@ -185,6 +185,27 @@ __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *_
     }
 }
 
+
+// dst[j][i] = src[i][j]: 64 x 64 tiles through LDS (pitch 65: the column-wise reads of the tile hit distinct banks), both
+// sides coalesced.  The solver wants the short side of a matrix as rows (SciPy transposes likewise); with more moving than
+// fixed nuclei that is the transpose of what the cost kernel writes.
+constexpr int TR_TILE = 64;
+__global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict__ src, int rows, int cols, size_t ld_src,
+                                                        double *__restrict__ dst, size_t ld_dst) {
+    __shared__ double tile[TR_TILE][TR_TILE + 1];
+    const int j0 = blockIdx.x * TR_TILE, i0 = blockIdx.y * TR_TILE;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4 threads
+    for (int r = ty; r < TR_TILE; r += 4) {
+        const int i = i0 + r, j = j0 + tx;
+        if (i < rows && j < cols) tile[r][tx] = src[(size_t)i * ld_src + j];
+    }
+    __syncthreads();
+    for (int r = ty; r < TR_TILE; r += 4) {
+        const int j = j0 + r, i = i0 + tx;
+        if (j < cols && i < rows) dst[(size_t)j * ld_dst + i] = tile[tx][r];
+    }
+}
+
 }  // namespace pm
 
 extern "C" {
@@ -233,6 +254,14 @@ int pm_lsap_certificate(const double *U, int nr, int nc, size_t ld, const double
     if (hipMemsetAsync(stats2, 0, 2 * sizeof(double), s) != hipSuccess) return pm::launch_status();
     pm::certificate_kernel<<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, u, v, col4row, delta, eps, summary4, (unsigned long long *)stats2,
                                                           tight, tight_red, cap, row_slack, row_neg);
+    return pm::launch_status();
+}
+
+int pm_transpose_f64(const double *src, int rows, int cols, size_t ld_src, double *dst, size_t ld_dst, void *stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || ld_src < (size_t)cols || ld_dst < (size_t)rows) return PM_ERR_INVALID_ARG;
+    const dim3 grid((cols + pm::TR_TILE - 1) / pm::TR_TILE, (rows + pm::TR_TILE - 1) / pm::TR_TILE);
+    if (grid.y > 65535u) return PM_ERR_INVALID_ARG;
+    pm::transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, rows, cols, ld_src, dst, ld_dst);
     return pm::launch_status();
 }
 

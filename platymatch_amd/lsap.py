@@ -129,6 +129,15 @@ class _Core:
         return u, v, c4r, list(stats)
 
 
+def transposed(U):
+    """A contiguous transpose of a float64 GPU matrix by the tiled kernel (pm_transpose_f64; torch's strided copy takes
+    ~0.4 s for the 19 GB of a 50 000 x 47 000 matrix, the kernel ~15 ms)."""
+    torch = nat.torch_mod()
+    out = torch.empty((U.shape[1], U.shape[0]), dtype=torch.float64, device=U.device)
+    nat.check(nat.load().pm_transpose_f64(nat.ptr(U), U.shape[0], U.shape[1], U.stride(0), nat.ptr(out), out.stride(0), nat.stream_ptr()))
+    return out
+
+
 class DeviceMatrix:
     """The dense matrix as the solver sees it: three queries, each one streaming pass of a HIP kernel over HBM.
     (tests/test_lsap_core.py substitutes a NumPy double to exercise the host solver without a GPU.)"""
@@ -281,11 +290,10 @@ ROW_REDUCTION_ROUNDS = 0
 # eps-scaling auction over the sparse core before the first shortest-path solve: (eps0, eps_min) in units of the core's width,
 # the scaling factor, how many auction + pricing rounds, the bid budget.  None = off.  Measured on chi-square matrices
 # (tools/lsap_probe.py): eight assignments at 20 000 x 20 000 nuclei 0.56 s -> 0.13 s, at 50 000 x 50 000 2.65 s -> 0.65 s.
-# max_free_columns: the largest share of spare columns (nc - nr) / nc for which the auction runs.  With spare columns every
-# row freed after the auction strands its column below the dual a free column must carry, and each of those costs a dummy row a
-# long search; near-square problems still gain (20 000 x 19 800: 0.67 s -> 0.54 s), clearly rectangular ones lose
-# (20 000 x 18 000: 0.20 s -> 0.65 s) and are quick without it, because spare columns keep the searches short.
-AUCTION = None if os.environ.get("PM_LSAP_AUCTION") == "0" else dict(eps0=0.25, eps_min=1e-6, factor=5.0, rounds=3, later_eps0=0.01, bids_per_row=40, stop_below=0.02, max_free_columns=0.02)
+# max_free_columns: the largest share of spare columns (nc - nr) / nc for which the auction runs (1.0: always).  With spare
+# columns, rows freed after the auction strand their columns below the dual a free column must carry; each of those is put
+# right by a search from the column side (pm_lsap_core.cpp: reverse_augment), a few steps each.
+AUCTION = None if os.environ.get("PM_LSAP_AUCTION") == "0" else dict(eps0=0.25, eps_min=1e-6, factor=5.0, rounds=3, later_eps0=0.01, bids_per_row=200, later_bids_per_row=60, stop_below=0.02, max_free_columns=1.0)
 
 
 def _row_reduction(M, v, rounds):
@@ -383,7 +391,8 @@ def solve_core(M, info=None):
                 t_a = time.perf_counter()
                 eps0 = AUCTION["eps0"] * width
                 for a_round in range(AUCTION["rounds"]):
-                    bids = core.auction(eps0, AUCTION["eps_min"] * width, AUCTION["factor"], AUCTION["bids_per_row"] * nr)
+                    budget = AUCTION["bids_per_row"] if a_round == 0 else AUCTION["later_bids_per_row"]
+                    bids = core.auction(eps0, AUCTION["eps_min"] * width, AUCTION["factor"], budget * nr)
                     if a_round + 1 == AUCTION["rounds"]:
                         break
                     _, v_a, _, _ = core.get()
@@ -428,7 +437,7 @@ def solve_on_device(U, info=None, force=False):
     info = {} if info is None else info
     n0, m0 = U.shape
     if min(n0, m0) >= (1 if force else DEVICE_MIN_ROWS):
-        W = DeviceMatrix(U if n0 <= m0 else U.t().contiguous())      # rows are the short side (SciPy transposes likewise)
+        W = DeviceMatrix(U if n0 <= m0 else transposed(U))           # rows are the short side (SciPy transposes likewise)
         with torch.cuda.device(U.device):
             sol = solve_core(W, info)
             if sol is not None and certify(W, *sol, info=info):
@@ -459,12 +468,14 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
         return [linear_sum_assignment(U_h.cpu().numpy()), linear_sum_assignment(U_twin.cpu().numpy())]
     out = [None, None]
     near_tie = "device (optimal, a near-tie within the margin: not proven to be SciPy's pick)"
-    W = DeviceMatrix(U_h if n <= m else U_h.t().contiguous())
+    W = DeviceMatrix(U_h if n <= m else transposed(U_h))
+    Wt = None
     sol = solve_core(W, info_h)
     if sol is not None and certify(W, *sol, info=info_h):
         info_h["route"] = "device"
         out[0] = _answer(sol[2], n, m)
-        Wt = DeviceMatrix(U_twin if n <= m else U_twin.t().contiguous())
+        W = None                                        # (possibly a transposed copy: release it before the twin's is made)
+        Wt = DeviceMatrix(U_twin if n <= m else transposed(U_twin))
         if certify(Wt, *sol, info=info_twin):
             info_twin["route"] = "device (sibling's duals certified)"
             out[1] = out[0]
@@ -478,7 +489,9 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
     else:
         info_h["route"] = refused
     # the twin on its own
-    Wt = DeviceMatrix(U_twin if n <= m else U_twin.t().contiguous())
+    W = None
+    if Wt is None:
+        Wt = DeviceMatrix(U_twin if n <= m else transposed(U_twin))
     sol_t = solve_core(Wt, info_twin)
     if sol_t is not None and certify(Wt, *sol_t, info=info_twin):
         info_twin["route"] = "device"

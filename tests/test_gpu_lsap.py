@@ -282,3 +282,13 @@ def test_cost_build_by_pairings_writes_the_same_eight_matrices(dev):
     for h in range(8):
         assert np.array_equal(a[h][0], b[h][0]) and np.array_equal(a[h][1], b[h][1])
         assert np.array_equal(a[h][1], scipy_lsa(U[h].cpu().numpy())[1])
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (63, 65), (64, 64), (300, 1000), (1000, 300), (2049, 777)])
+def test_tiled_transpose(dev, shape):
+    import torch
+    from platymatch_amd import lsap as L
+    U = dev(np.random.default_rng(sum(shape)).random(shape))
+    assert torch.equal(L.transposed(U), U.t().contiguous())
+    V = dev(np.random.default_rng(1).random((shape[0], shape[1] + 5)))[:, :shape[1]]      # a view with a row pitch
+    assert torch.equal(L.transposed(V), V.t().contiguous())

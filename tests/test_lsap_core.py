@@ -256,7 +256,7 @@ def test_engineered_near_ties_are_certified_only_above_the_margin():
 @pytest.mark.parametrize("shape", [(400, 400), (990, 1000), (257, 300), (64, 900), (1200, 1200)])
 def test_auction_warm_start_never_changes_the_certified_answer(shape, monkeypatch):
     """lsap.AUCTION (eps-scaling forward auction over the core before the first shortest-path solve; reverse steps for spare
-    columns): off, on, forced on for clearly rectangular problems, starved of bids (the budget stops it mid-round) and with a
+    columns, searches from the column side for the columns it strands): off, on, on for near-square problems only, starved of bids (the budget stops it mid-round) and with a
     coarse final eps — the certified assignment is SciPy's every time; only the amount of search left differs."""
     from platymatch_amd import lsap as L
     rng = np.random.default_rng(shape[0] * 7 + shape[1])
@@ -264,7 +264,7 @@ def test_auction_warm_start_never_changes_the_certified_answer(shape, monkeypatc
     r, c = scipy_lsa(U)
     base = dict(L.AUCTION)
     steps = {}
-    for name, setting in (("off", None), ("on", base), ("always", dict(base, max_free_columns=1.0)),
+    for name, setting in (("off", None), ("on", base), ("near-square only", dict(base, max_free_columns=0.02)),
                           ("starved", dict(base, max_free_columns=1.0, bids_per_row=1)),
                           ("coarse", dict(base, max_free_columns=1.0, eps_min=0.05, rounds=1))):
         monkeypatch.setattr(L, "AUCTION", setting)
@@ -272,7 +272,7 @@ def test_auction_warm_start_never_changes_the_certified_answer(shape, monkeypatc
         assert got is not None, (name, info)
         assert np.array_equal(got[0], r) and np.array_equal(got[1], c), (name, info)
         steps[name] = info["steps"]
-        assert ("auction_bids" in info) == (name != "off" and (name != "on" or shape[1] - shape[0] <= 0.02 * shape[1])), (name, info)
+        assert ("auction_bids" in info) == (name != "off" and (name != "near-square only" or shape[1] - shape[0] <= 0.02 * shape[1])), (name, info)
     if shape[0] == shape[1]:
         assert steps["on"] < steps["off"], steps                     # the point of it: less search left
 

@@ -25,11 +25,14 @@ U, _ = P.build_costs(be, be.cloud(mv), be.cloud(fx))
 torch.cuda.synchronize()
 if os.environ.get("PM_LSAP_AUCTION") == "0":
     L.AUCTION = None
+for key in ("bids_per_row", "eps0", "eps_min", "factor", "rounds", "later_eps0", "stop_below"):      # e.g. PM_LSAP_bids_per_row=100
+    if L.AUCTION is not None and os.environ.get("PM_LSAP_" + key):
+        L.AUCTION[key] = type(L.AUCTION[key])(float(os.environ["PM_LSAP_" + key]))
 hyps = [int(x) for x in os.environ.get("PM_LSAP_HYPS", "0,1,2,3,4,5,6,7").split(",")]
 for h in hyps:
     info = {}
     t = time.perf_counter()
-    W = L.DeviceMatrix(U[h] if U.shape[1] <= U.shape[2] else U[h].t().contiguous())       # rows are the short side
+    W = L.DeviceMatrix(U[h] if U.shape[1] <= U.shape[2] else L.transposed(U[h]))       # rows are the short side
     sol = L.solve_core(W, info)
     t1 = time.perf_counter() - t
     t = time.perf_counter()
