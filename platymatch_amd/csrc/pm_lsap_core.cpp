@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -346,14 +347,18 @@ struct Core {
             std::fill(assigned.begin(), assigned.end(), -1);
             for (int i = 0; i < n; ++i) queue[i] = i;
             size_t head = 0, count = (size_t)n;            // ring buffer of the unassigned rows (first in, first out)
-            // A PRICE WAR — a handful of rows contesting near-equal columns, each bid worth eps — shows as a round that has
-            // spent many bids per row of the problem while hardly any row is still unassigned: the search settles those few
-            // rows in a fraction of the bids (50 000 x 50 000, one hypothesis: 15.6e6 bids, 0.9 s, against 0.1 s of search).
-            const long war_after = bids + 8L * n;
+            // A PRICE WAR — a handful of rows contesting near-equal columns, each bid worth eps — shows as a round whose tail, with
+            // hardly any row still unassigned (<= 0.5 %), goes on for many bids per row of the problem (16 x n; PM_LSAP_WAR_TAIL
+            // overrides, for experiments): the search settles those few rows in a fraction of the bids.  Measured, eight
+            // assignments / one 100 000 x 100 000 hypothesis: no cut-off 1.12 s / 3.67 s, 64 x n 0.62 s / 1.99 s, 16 x n
+            // 0.68 s / 1.34 s, 4 x n 0.46 s / 2.50 s.
             const size_t war_rows = std::max<size_t>(16, (size_t)n / 200);
+            static const long war_tail = [] { const char *e = std::getenv("PM_LSAP_WAR_TAIL"); return e ? std::atol(e) : 16L; }();
+            long tail_from = bids;                          // the bid count when more than war_rows rows were last unassigned
             bool war = false;
             while (count > 0 && bids < stop_at) {
-                if (bids > war_after && count <= war_rows) { war = true; break; }
+                if (count > war_rows) tail_from = bids;
+                else if (bids - tail_from > war_tail * n) { war = true; break; }
                 const int i = queue[head];
                 head = head + 1 == (size_t)n ? 0 : head + 1;
                 --count;
