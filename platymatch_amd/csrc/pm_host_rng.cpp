@@ -20,12 +20,15 @@
 
 namespace {
 
-// MT19937 with the 624 tempered outputs of a state block produced in one (vectorisable) sweep.  `pos` counts the
-// outputs of the current block already consumed, exactly NumPy's `pos`.
+// MT19937 with the 624 tempered outputs of a state block produced in one (vectorisable) sweep.  The consumer's vector loop
+// takes 64 outputs at a time and must not stop at block boundaries (the last < 64 of a block would go 16 at a time, through
+// a dependent prefix sum: a third of the loop's time): the outputs live in a window buf[CARRY + 624]; when fewer than 64
+// are left they are moved in front of the next block, which is tempered right behind them.
+constexpr int CARRY = 64;
 struct MT {
-    uint32_t *key;
-    int pos;
-    uint32_t out[624];
+    uint32_t key[624];             // the state behind the block in buf[CARRY ..]
+    uint32_t prev[624];            // the state behind the block before it (whose last outputs may sit in buf[.. CARRY))
+    uint32_t buf[CARRY + 624];
 
     // (both loops vectorise: the recurrence reaches back 227 words; clones are picked at load time by the CPU's features)
     __attribute__((target_clones("avx512f", "avx2", "default"))) void twist() {
@@ -44,19 +47,41 @@ struct MT {
         key[623] = key[396] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX);
     }
     __attribute__((target_clones("avx512f", "avx2", "default"))) void temper() {
+        uint32_t *__restrict dst = buf + CARRY;
         for (int i = 0; i < 624; i++) {
             uint32_t y = key[i];
             y ^= (y >> 11);
             y ^= (y << 7) & 0x9d2c5680u;
             y ^= (y << 15) & 0xefc60000u;
             y ^= (y >> 18);
-            out[i] = y;
+            dst[i] = y;
         }
     }
-    void refill() {       // all outputs of the current block are consumed: advance the state by one block
+    // the caller's state, `pos` outputs of its block consumed -> index of the next output in buf
+    int first(const uint32_t *state, int pos) {
+        __builtin_memcpy(key, state, sizeof(key));
+        __builtin_memcpy(prev, state, sizeof(prev));
+        temper();
+        return CARRY + pos;
+    }
+    // fewer than CARRY outputs are left (buf[p .. CARRY + 624)): move them in front of the next block -> new index
+    int refill(int p) {
+        const int left = CARRY + 624 - p;
+        __builtin_memmove(buf + CARRY - left, buf + p, sizeof(uint32_t) * (size_t)left);
+        __builtin_memcpy(prev, key, sizeof(prev));
         twist();
         temper();
-        pos = 0;
+        return CARRY - left;
+    }
+    // the state to hand back when the next output would be buf[p]
+    void finish(int p, uint32_t *key_out, int *pos_out) const {
+        if (p >= CARRY) {
+            __builtin_memcpy(key_out, key, sizeof(key));
+            *pos_out = p - CARRY;
+        } else {                                     // still inside the outputs carried over from the block before
+            __builtin_memcpy(key_out, prev, sizeof(prev));
+            *pos_out = 624 - (CARRY - p);
+        }
     }
 };
 
@@ -117,33 +142,41 @@ __attribute__((target("avx512f,avx512bw,avx512vl,bmi2,popcnt"))) static long con
     const __m512i lane = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     for (;;) {
         // 64 draws at once, free of the count-to-threshold dependency: over these draws i stays within [i0 - 63, i0], so a value
-        // <= i0 - 63 is accepted and one > i0 rejected whatever the counts are; only a value inside that band needs them.
+        // <= i0 - 63 is accepted and one > i0 rejected whatever the counts are.  Only a value inside that band needs the number
+        // of acceptances before it; those few (a draw falls in the band with probability 63 / 2^b) are settled one by one, in
+        // draw order, from the masks.
         if (avail - used >= 64 && i - 64 >= lo) {
             const __m512i hi = _mm512_set1_epi32((int)i), below = _mm512_set1_epi32((int)(i - 63));
             const __m512i v0 = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used)), vmask);
             const __m512i v1 = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used + 16)), vmask);
             const __m512i v2 = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used + 32)), vmask);
             const __m512i v3 = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used + 48)), vmask);
-            const __mmask16 h0 = _mm512_cmple_epu32_mask(v0, hi), h1 = _mm512_cmple_epu32_mask(v1, hi);
-            const __mmask16 h2 = _mm512_cmple_epu32_mask(v2, hi), h3 = _mm512_cmple_epu32_mask(v3, hi);
-            const __mmask16 l0 = _mm512_cmple_epu32_mask(v0, below), l1 = _mm512_cmple_epu32_mask(v1, below);
-            const __mmask16 l2 = _mm512_cmple_epu32_mask(v2, below), l3 = _mm512_cmple_epu32_mask(v3, below);
-            if ((((unsigned)h0 ^ (unsigned)l0) | ((unsigned)h1 ^ (unsigned)l1) | ((unsigned)h2 ^ (unsigned)l2) | ((unsigned)h3 ^ (unsigned)l3)) == 0) {
-                // (compress in registers + a full-width store: what lies beyond the accepted values is overwritten by the next store;
-                // w has 64 entries of slack)
-                const int c0 = __builtin_popcount((unsigned)h0), c1 = __builtin_popcount((unsigned)h1);
-                const int c2 = __builtin_popcount((unsigned)h2), c3 = __builtin_popcount((unsigned)h3);
-                _mm512_storeu_si512((void *)(w + wp), _mm512_maskz_compress_epi32(h0, v0));
-                _mm512_storeu_si512((void *)(w + wp + c0), _mm512_maskz_compress_epi32(h1, v1));
-                _mm512_storeu_si512((void *)(w + wp + c0 + c1), _mm512_maskz_compress_epi32(h2, v2));
-                _mm512_storeu_si512((void *)(w + wp + c0 + c1 + c2), _mm512_maskz_compress_epi32(h3, v3));
-                const int acc = c0 + c1 + c2 + c3;
-                wp += acc;
-                i -= acc;
-                used += 64;
-                continue;
+            const uint64_t cand = (uint64_t)_mm512_cmple_epu32_mask(v0, hi) | ((uint64_t)_mm512_cmple_epu32_mask(v1, hi) << 16) |
+                                  ((uint64_t)_mm512_cmple_epu32_mask(v2, hi) << 32) | ((uint64_t)_mm512_cmple_epu32_mask(v3, hi) << 48);
+            uint64_t acc = (uint64_t)_mm512_cmple_epu32_mask(v0, below) | ((uint64_t)_mm512_cmple_epu32_mask(v1, below) << 16) |
+                           ((uint64_t)_mm512_cmple_epu32_mask(v2, below) << 32) | ((uint64_t)_mm512_cmple_epu32_mask(v3, below) << 48);
+            uint64_t band = cand & ~acc;
+            while (band) {                                  // in draw order: the earlier ones are decided by now
+                const int t = __builtin_ctzll(band);
+                band &= band - 1;
+                const long before = __builtin_popcountll(acc & ((1ull << t) - 1));
+                if ((long)(rnd[used + t] & mask) <= i - before) acc |= 1ull << t;
             }
+            // (compress in registers + a full-width store: what lies beyond the accepted values is overwritten by the next store;
+            // w has 64 entries of slack)
+            const __mmask16 m0 = (__mmask16)acc, m1 = (__mmask16)(acc >> 16), m2 = (__mmask16)(acc >> 32), m3 = (__mmask16)(acc >> 48);
+            const int c0 = __builtin_popcount((unsigned)m0), c1 = __builtin_popcount((unsigned)m1), c2 = __builtin_popcount((unsigned)m2);
+            _mm512_storeu_si512((void *)(w + wp), _mm512_maskz_compress_epi32(m0, v0));
+            _mm512_storeu_si512((void *)(w + wp + c0), _mm512_maskz_compress_epi32(m1, v1));
+            _mm512_storeu_si512((void *)(w + wp + c0 + c1), _mm512_maskz_compress_epi32(m2, v2));
+            _mm512_storeu_si512((void *)(w + wp + c0 + c1 + c2), _mm512_maskz_compress_epi32(m3, v3));
+            const int total = (int)__builtin_popcountll(acc);
+            wp += total;
+            i -= total;
+            used += 64;
+            continue;
         }
+        if (i - 64 >= lo) break;                             // short of outputs, not at the end of a mask run: the caller tops up
         // 16 draws: the acceptance pattern as the fixed point of a_t = [v_t <= i0 - #{s < t: a_s}] (see above)
         if (!(avail - used >= 16 && i - 16 >= lo)) break;
         const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used)), vmask);
@@ -185,23 +218,23 @@ static bool have_avx512() { return false; }
 
 // One trial's rejection sampling: consume generator outputs (block by block through `next_block`) until the n - 1 swap partners
 // of a shuffle are decided; w receives them in draw order.  rnd / p: the current block and the position in it (updated).
-template <class NextBlock>
-static inline void draw_partners(long n, int32_t *__restrict w, const uint32_t *__restrict &rnd, int &p, bool simd, NextBlock &&next_block) {
+// One trial's rejection sampling: consume generator outputs until the n - 1 swap partners of a shuffle are decided; w
+// receives them in draw order.  p: index of the next output in mt.buf (updated).
+static inline void draw_partners(long n, int32_t *__restrict w, MT &mt, int &p, bool simd) {
     // Fisher-Yates from the top, in runs of i that share one rejection mask (2^b - 1 for i in [2^(b-1), 2^b)): a draw
     // is accepted if it is <= the current i, which then drops by one.  Accepted values are appended to w without a
     // data-dependent branch (a rejected draw is overwritten by the next one); no array is permuted.
+    constexpr int END = CARRY + 624;
+    const uint32_t *__restrict rnd = mt.buf;
     long i = n - 1, wp = 0;
     while (i >= 1) {
         const uint32_t mask = 0xffffffffu >> __builtin_clz((uint32_t)i);   // smallest all-ones mask >= i
         const long lo = (long)(mask >> 1) + 1;                             // last i that uses this mask
         while (i >= lo) {
-            if (p == 624) {
-                rnd = next_block();
-                p = 0;
-            }
-            if (simd) p += (int)consume_avx512(rnd + p, 624 - p, mask, lo, &i, w, &wp);
-            // scalar: up to 16 draws (the band case, the tail of a generator block, the end of a mask run)
-            for (int q = 0; q < 16 && p < 624 && i >= lo; ++q) {
+            if (END - p < CARRY) p = mt.refill(p);
+            if (simd) p += (int)consume_avx512(rnd + p, END - p, mask, lo, &i, w, &wp);
+            // scalar: up to 16 draws (the end of a mask run)
+            for (int q = 0; q < 16 && p < END && i >= lo; ++q) {
                 const uint32_t v = rnd[p++] & mask;
                 w[wp] = (int32_t)v;
                 const long take = (v <= (uint32_t)i);
@@ -214,19 +247,15 @@ static inline void draw_partners(long n, int32_t *__restrict w, const uint32_t *
 
 static int legacy_choice_serial(uint32_t *key, int *pos, long n, int k, long trials, int32_t *out) {
     MT mt;
-    mt.key = key;
-    mt.pos = *pos;
-    mt.temper();                                        // outputs pos..623 of the block the caller's state is in
+    int p = mt.first(key, *pos);                        // outputs pos..623 of the block the caller's state is in
     std::vector<int32_t> partner((size_t)n + CHUNK);
     int32_t *__restrict w = partner.data();
-    const uint32_t *__restrict rnd = mt.out;           // locals the compiler can keep apart from the stores into w[]
     const bool simd = have_avx512();
-    int p = mt.pos;
     for (long t = 0; t < trials; ++t) {
-        draw_partners(n, w, rnd, p, simd, [&]() { mt.refill(); return (const uint32_t *)mt.out; });
+        draw_partners(n, w, mt, p, simd);
         first_entries(w, n, k, out + t * k);
     }
-    *pos = p;
+    mt.finish(p, key, pos);
     return PM_OK;
 }
 
