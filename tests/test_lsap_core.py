@@ -289,3 +289,34 @@ def test_rectangular_cores_do_not_scan_dummy_rows_densely():
     assert got is not None and np.array_equal(got[1], scipy_lsa(U)[1])
     dummy_scans = info["dummy_scans"] % 1000000
     assert dummy_scans <= 3 * (m - n), info
+
+
+def test_fuzz_of_shapes_and_cost_distributions_against_scipy():
+    """Random shapes (square, wide, tall) and cost distributions — uniform, column-scaled, heavy-tailed, squared distances of
+    point sets, negative entries, costs on a coarse grid plus noise (near-ties) — through solve_core + certify with the
+    auction warm start on: whatever is certified equals SciPy's answer; what is not certified is rare."""
+    rng = np.random.default_rng(2024)
+    uncertified = 0
+    for it in range(70):
+        n, m = int(rng.integers(2, 500)), int(rng.integers(2, 500))
+        kind = it % 6
+        if kind == 0:
+            U = rng.random((n, m))
+        elif kind == 1:
+            U = rng.random((n, m)) * rng.random((1, m)) + 0.3 * rng.random((n, 1))
+        elif kind == 2:
+            U = np.abs(rng.normal(size=(n, m))) ** 3
+        elif kind == 3:
+            a, b = rng.random((n, 3)), rng.random((m, 3))
+            U = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+        elif kind == 4:
+            U = rng.random((n, m)) - 0.5
+        else:
+            U = np.round(rng.random((n, m)) * 50) / 50 + 1e-9 * rng.random((n, m))
+        got, info = run(U)
+        if got is None:
+            uncertified += 1
+            continue
+        r, c = scipy_lsa(U)
+        assert np.array_equal(got[0], r) and np.array_equal(got[1], c), (it, n, m, kind, info)
+    assert uncertified <= 3
