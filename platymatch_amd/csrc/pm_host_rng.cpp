@@ -21,10 +21,9 @@
 namespace {
 
 // MT19937 with the 624 tempered outputs of a state block produced in one (vectorisable) sweep.  The consumer's vector loop
-// takes 64 outputs at a time and must not stop at block boundaries (the last < 64 of a block would go 16 at a time, through
-// a dependent prefix sum: a third of the loop's time): the outputs live in a window buf[CARRY + 624]; when fewer than 64
-// are left they are moved in front of the next block, which is tempered right behind them.
-constexpr int CARRY = 64;
+// takes 128 (or 64) outputs at a time and should not stop at block boundaries: the outputs live in a window buf[CARRY + 624];
+// when fewer than CARRY are left they are moved in front of the next block, which is tempered right behind them.
+constexpr int CARRY = 128;
 struct MT {
     uint32_t key[624];             // the state behind the block in buf[CARRY ..]
     uint32_t prev[624];            // the state behind the block before it (whose last outputs may sit in buf[.. CARRY))
@@ -141,6 +140,53 @@ __attribute__((target("avx512f,avx512bw,avx512vl,bmi2,popcnt"))) static long con
     const __m512i vmask = _mm512_set1_epi32((int)mask);
     const __m512i lane = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     for (;;) {
+        // 128 draws at once: two groups of 64 whose masks do not depend on each other (the second one's band is twice as wide:
+        // its draws see i somewhere in [i0 - 127, i0]); what runs from one step to the next through i is then one chain of
+        // broadcast -> compare -> mask -> count per 128 draws instead of per 64.
+        if (avail - used >= 128 && i - 128 >= lo) {
+            const __m512i hi = _mm512_set1_epi32((int)i), belowA = _mm512_set1_epi32((int)(i - 63)), belowB = _mm512_set1_epi32((int)(i - 127));
+            __m512i v[8];
+#pragma GCC unroll 8
+            for (int g = 0; g < 8; ++g) v[g] = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used + 16 * g)), vmask);
+            uint64_t candA = 0, accA = 0, candB = 0, accB = 0;
+#pragma GCC unroll 4
+            for (int g = 0; g < 4; ++g) {
+                candA |= (uint64_t)_mm512_cmple_epu32_mask(v[g], hi) << (16 * g);
+                accA |= (uint64_t)_mm512_cmple_epu32_mask(v[g], belowA) << (16 * g);
+                candB |= (uint64_t)_mm512_cmple_epu32_mask(v[4 + g], hi) << (16 * g);
+                accB |= (uint64_t)_mm512_cmple_epu32_mask(v[4 + g], belowB) << (16 * g);
+            }
+            uint64_t band = candA & ~accA;
+            while (band) {                                  // in draw order: the earlier ones are decided by now
+                const int t = __builtin_ctzll(band);
+                band &= band - 1;
+                if ((long)(rnd[used + t] & mask) <= i - (long)__builtin_popcountll(accA & ((1ull << t) - 1))) accA |= 1ull << t;
+            }
+            const long totalA = __builtin_popcountll(accA);
+            band = candB & ~accB;
+            while (band) {
+                const int t = __builtin_ctzll(band);
+                band &= band - 1;
+                if ((long)(rnd[used + 64 + t] & mask) <= i - totalA - (long)__builtin_popcountll(accB & ((1ull << t) - 1))) accB |= 1ull << t;
+            }
+            long at = wp;
+#pragma GCC unroll 4
+            for (int g = 0; g < 4; ++g) {
+                const __mmask16 m = (__mmask16)(accA >> (16 * g));
+                _mm512_storeu_si512((void *)(w + at), _mm512_maskz_compress_epi32(m, v[g]));
+                at += __builtin_popcount((unsigned)m);
+            }
+#pragma GCC unroll 4
+            for (int g = 0; g < 4; ++g) {
+                const __mmask16 m = (__mmask16)(accB >> (16 * g));
+                _mm512_storeu_si512((void *)(w + at), _mm512_maskz_compress_epi32(m, v[4 + g]));
+                at += __builtin_popcount((unsigned)m);
+            }
+            i -= at - wp;
+            wp = at;
+            used += 128;
+            continue;
+        }
         // 64 draws at once, free of the count-to-threshold dependency: over these draws i stays within [i0 - 63, i0], so a value
         // <= i0 - 63 is accepted and one > i0 rejected whatever the counts are.  Only a value inside that band needs the number
         // of acceptances before it; those few (a draw falls in the band with probability 63 / 2^b) are settled one by one, in
@@ -176,29 +222,23 @@ __attribute__((target("avx512f,avx512bw,avx512vl,bmi2,popcnt"))) static long con
             used += 64;
             continue;
         }
-        if (i - 64 >= lo) break;                             // short of outputs, not at the end of a mask run: the caller tops up
-        // 16 draws: the acceptance pattern as the fixed point of a_t = [v_t <= i0 - #{s < t: a_s}] (see above)
+        if (i - 128 >= lo) break;                            // short of outputs, not near the end of a mask run: the caller tops up
+        // the last < 64 of a mask run, 16 draws at a time in the same way (band: the 15 values below i0)
         if (!(avail - used >= 16 && i - 16 >= lo)) break;
         const __m512i v = _mm512_and_si512(_mm512_loadu_si512((const void *)(rnd + used)), vmask);
-        const __m512i thr0 = _mm512_sub_epi32(_mm512_set1_epi32((int)i), lane);                  // every earlier draw accepted
-        const __mmask16 a0 = _mm512_cmple_epu32_mask(v, thr0);
-        // counts of a0 before each lane: exclusive prefix sum of the 0/1 lanes (four shift-and-add steps)
-        const unsigned m0 = a0;
-        const __m512i ones = _mm512_maskz_set1_epi32(a0, 1);
-        const __m512i zero = _mm512_setzero_si512();
-        __m512i ps = ones;
-        ps = _mm512_add_epi32(ps, _mm512_alignr_epi32(ps, zero, 15));
-        ps = _mm512_add_epi32(ps, _mm512_alignr_epi32(ps, zero, 14));
-        ps = _mm512_add_epi32(ps, _mm512_alignr_epi32(ps, zero, 12));
-        ps = _mm512_add_epi32(ps, _mm512_alignr_epi32(ps, zero, 8));
-        const __m512i cnt = _mm512_sub_epi32(ps, ones);
-        const __m512i thr1 = _mm512_sub_epi32(_mm512_set1_epi32((int)i), cnt);
-        const __mmask16 a1 = _mm512_cmple_epu32_mask(v, thr1);
-        if (a0 != a1) break;                                                                      // a draw in the band: scalar decides
-        _mm512_storeu_si512((void *)(w + wp), _mm512_maskz_compress_epi32(a0, v));
-        const int acc = __builtin_popcount(m0);
-        wp += acc;
-        i -= acc;
+        const unsigned cand = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)i));
+        unsigned acc = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32((int)(i - 15)));
+        unsigned band = cand & ~acc;
+        while (band) {
+            const int t = __builtin_ctz(band);
+            band &= band - 1;
+            const long before = __builtin_popcount(acc & ((1u << t) - 1));
+            if ((long)(rnd[used + t] & mask) <= i - before) acc |= 1u << t;
+        }
+        _mm512_storeu_si512((void *)(w + wp), _mm512_maskz_compress_epi32((__mmask16)acc, v));
+        const int total = __builtin_popcount(acc);
+        wp += total;
+        i -= total;
         used += 16;
     }
     *pi = i;
