@@ -532,9 +532,11 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
             info["routes"] = ["host"] * 8
         return res
 
+    caller = torch.cuda.current_stream(U8.device).cuda_stream          # (concurrent callers, e.g. batch workers, keep apart)
+
     def pair(h):
         twin = [t for t, s in TWINS.items() if s == h][0]
-        stream = torch.cuda.Stream(device=U8.device)
+        stream = nat.side_stream(U8.device, ("pair", caller, h))      # persistent: the allocator's cache is per stream
         with torch.cuda.device(U8.device), torch.cuda.stream(stream):
             if ready is not None:
                 stream.wait_event(ready[h])

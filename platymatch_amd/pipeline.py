@@ -656,6 +656,16 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
         n, m = _pair_size(pairs[k])
         return 64.0 * n * m + 2880.0 * (2 * n + 4 * m) * 2
 
+    slots = threading.local()
+    next_slot = [0]
+
+    def worker_slot():
+        if not hasattr(slots, "id"):
+            with gate:
+                slots.id = next_slot[0]
+                next_slot[0] += 1
+        return slots.id
+
     def one(k):
         det = {"timing": True} if timings is not None else None
         if not on_gpu:                       # a caller-supplied host backend (tests): no stream to set
@@ -667,7 +677,7 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
                     gate.wait()
                 in_flight[0] += want
             try:
-                stream = torch.cuda.Stream(device=dev)
+                stream = nat.side_stream(dev, ("batch worker", worker_slot()))   # persistent per worker thread
                 with torch.cuda.device(dev), torch.cuda.stream(stream):
                     out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, details=det, **kwargs)
                     stream.synchronize()
@@ -688,11 +698,14 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
         return dict(zip(order, ex.map(one, order)))
 
 
-def estimate_transform_batch(pairs, workers=5, seeds=None, group=None, timings=None, **kwargs):
+def estimate_transform_batch(pairs, workers=8, seeds=None, group=None, timings=None, **kwargs):
     """Several independent registrations (BASELINE config 5: "replicas only" — pairs never exchange data).
 
-    One GPU (group=None): each worker thread drives its pairs on its own HIP stream, so the GPU stages of different pairs
-    overlap and the Hungarian solves (GIL-free, lsap.py) run concurrently on the host.
+    One GPU (group=None): each worker thread drives its pairs on its own HIP stream — a PERSISTENT one (nat.side_stream:
+    torch's allocator caches per stream; with a fresh stream per pair every cost buffer was a new hipMalloc, ~13 s of a 15 s
+    batch) —, so the GPU stages of different pairs overlap and the host stages (assignment cores, RANSAC draws: GIL-free)
+    run concurrently.  workers: 8 measured best on the 16 cores a one-GPU box grants (64 pairs of 2k-20k nuclei: 5 workers
+    10.0 s, 8 5.8-6.9 s, 10 5.7-5.9 s, 12 6.6 s); the HBM gate below bounds what is in flight.
     Several GPUs (group = a torch.distributed group, one process per GPU): every rank holds the whole list; pairs are
     dealt to ranks largest first (batch_assignment, no communication), each rank registers its share as above, and ONE
     all-reduce of 40 doubles per pair (A_sc, A_icp, inlier counts; every entry is non-zero on its owner only, so the sum is

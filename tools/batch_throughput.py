@@ -28,7 +28,7 @@ from platymatch_amd.estimate_transform import perform_icp as pi  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=64)
-    ap.add_argument("--workers", type=int, default=4)
+    ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--min-points", type=int, default=2000)
     ap.add_argument("--max-points", type=int, default=20000)
     ap.add_argument("--trials", type=int, default=8000)
