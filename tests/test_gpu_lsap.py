@@ -292,3 +292,22 @@ def test_tiled_transpose(dev, shape):
     assert torch.equal(L.transposed(U), U.t().contiguous())
     V = dev(np.random.default_rng(1).random((shape[0], shape[1] + 5)))[:, :shape[1]]      # a view with a row pitch
     assert torch.equal(L.transposed(V), V.t().contiguous())
+
+
+@pytest.mark.parametrize("n,m", [(4200, 4000), (4000, 4200), (4100, 4060)])
+def test_rectangular_chi_square_assignments_at_a_few_thousand_nuclei(dev, n, m):
+    """Clouds of different sizes (the rule for real specimen pairs), both orientations and a near-square one, at a size where the
+    auction warm start, its reverse steps, the column-side searches for stranded columns and (N > M) the tiled transpose all do
+    real work: two hypotheses and their twins against SciPy, routes device-resident, counters sane."""
+    from platymatch_amd import lsap as L, pipeline as P
+    mv, fx, _ = synth_pair(max(n, m), 31)
+    be = P.GpuBackend()
+    U, _ = P.build_costs(be, be.cloud(np.ascontiguousarray(mv[:, :n])), be.cloud(np.ascontiguousarray(fx[:, :m])))
+    for h, twin in ((0, 5), (2, 7)):
+        ih, it = {}, {}
+        got = L.solve_pair_on_device(U[h], U[twin], ih, it)
+        assert ih["route"] == "device" and it["route"].startswith("device"), (ih.get("route"), it.get("route"))
+        assert "auction_bids" in ih and ih["dummy_scans"] % 1000000 <= 4 * abs(n - m) + 16, ih
+        for k, hyp in enumerate((h, twin)):
+            rs, cs = scipy_lsa(U[hyp].cpu().numpy())
+            assert np.array_equal(got[k][0], rs) and np.array_equal(got[k][1], cs), (hyp, ih)
