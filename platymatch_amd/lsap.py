@@ -515,8 +515,9 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
     back as None instead (bench.py's bounded extra leg).
     ready: four events, one per pairing (U11/U22, U12/U21, U13/U24, U14/U23), recorded when that pairing's two matrices have
     been written (_kernels.chi2_cost8_frame1_by_pairings): its solve starts then, while later pairings are still being built.
-    (Measured at 50 000 nuclei: no gain — the three wrong-frame hypotheses need the same ~2.8 s each, so the last one built
-    decides, and the solver's matrix queries queue behind the cost kernel: 4.5 s against 4.0 s.  The driver does not use it.)"""
+    (Measured at 50 000 nuclei, twice: no gain.  Before the auction warm start the three wrong-frame hypotheses needed the same
+    ~2.8 s each, so the last one built decided (4.5 s against 4.0 s); with it the solves are short but made of dense passes
+    that queue behind the cost kernel (2.2 s against 1.8 s).  The driver does not use it.)"""
     torch = nat.torch_mod()
     n, m = U8.shape[1], U8.shape[2]
     out = [None] * 8
