@@ -15,7 +15,14 @@
 //      the assignment any exact solver — SciPy's included — returns.  Otherwise (ties: duplicate nuclei, symmetric clouds)
 //      the caller falls back to pm_lsap_solve, SciPy's algorithm step for step.
 // Rectangular problems (nr < nc) are squared with nc - nr dummy rows of zero cost, kept implicit (no edge storage): every
-// column then ends matched, which is what makes step 3's "free the row and its column" repair valid.
+// column then ends matched, which is what makes step 3's "free the row and its column" repair valid.  A free column carries
+// v = 0 (the largest column dual) until a dummy row takes it; the pieces that keep this cheap: scan_row (a dummy row is
+// scanned at most from one base per search), phase (never scans a spare column it does not match), reverse_augment (a column
+// stranded below 0 is put right by a search from the column side).
+// Step 2 starts from a warm start where the caller asks for one (auction): an eps-scaling forward auction over the core's
+// edges, with reverse steps for spare columns, leaves duals close to the optimum's and most rows matched tight; the
+// shortest-path search then has ~10 steps per row left instead of hundreds.  The auction proves nothing — exactness rests
+// on the search that follows and on the certificate.
 //
 // The algorithm is the textbook sparse Jonker-Volgenant / Hungarian augmentation (as in SciPy's solver, restricted to the
 // core edges) — own code, no third-party source.  Plain C++, no GPU code; one instance per matrix, no global state.
