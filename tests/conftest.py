@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_library_is_built():
+    """The tests bind libplatymatch_hip.so (host solver, RNG replica, argument checks: no GPU needed for those): build it in-tree
+    if a fresh checkout has not yet (hipcc cross-compiles without a GPU; __graft_entry__.build() does the same)."""
+    from platymatch_amd.build import build_native
+    build_native()
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
