@@ -128,6 +128,73 @@ def pmc_traffic(kernel_substring, n):
     return None, None
 
 
+def spawn_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` started as ONE process (no WORLD_SIZE in the environment): become the launcher.  N fresh
+    children of this same script are started, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set — what `python -m torch.distributed.run --nproc-per-node N` would set.  The launcher itself never imports torch and
+    never touches a GPU (a process that has initialised the GPU must not be replaced or forked on this pool); rank 0's JSON
+    line reaches stdout because the children inherit it.  When a rank fails the others are given a grace period (they may be
+    waiting in a collective for it) and are then ended by their own PIDs.  -> the worst child exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(base.get("MASTER_PORT") or port), WORLD_SIZE=str(n_ranks),
+                LOCAL_WORLD_SIZE=str(n_ranks), PM_BENCH_SPAWNED="1")
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_ranks) // n_ranks)))
+    procs = []
+    for r in range(n_ranks):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    grace = float(os.environ.get("PM_BENCH_SPAWN_GRACE_S", "60"))
+    worst, failed_at = 0, None
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is not None:
+                live.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    failed_at = failed_at or time.monotonic()
+        if failed_at is not None and live and time.monotonic() - failed_at > grace:
+            for p in live:
+                p.terminate()                    # exactly the children this launcher started
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            worst = worst or 1
+            break
+        time.sleep(0.05)
+    return worst
+
+
+def dry_run(args):
+    """--dry-run: the launcher / rendezvous path without a GPU (CPU test of `bench.py --gpus N`): every rank joins a gloo
+    group, the timing all-reduce (MAX) and the barrier of the real run are exercised, rank 0 prints a JSON line."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seen = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = 1.0
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank_plus_one": seen,
+                          "spawned": os.environ.get("PM_BENCH_SPAWNED") == "1", "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,7 +204,24 @@ def main():
     ap.add_argument("--icp-iters", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-assignment", action="store_true", help="skip the untimed extra leg (eight assignments of the same build)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous only (gloo, no GPU): what the CPU test-suite runs")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # One process asked for several GPUs (the driver's `python bench.py --gpus N`): start the N ranks as fresh children
+    # BEFORE torch is imported or a GPU is touched, relay rank 0's line, return the worst child's exit code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start %d ranks (python bench.py --gpus %d does so by itself when WORLD_SIZE is unset)"
+                         % (args.gpus, world, args.gpus, args.gpus))
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import torch.distributed as dist
@@ -145,11 +229,8 @@ def main():
     from platymatch_amd import _native as nat
     from platymatch_amd import pipeline as P
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if os.environ.get("PM_BENCH_ONE_DEVICE") != "1" and local >= torch.cuda.device_count():
+        raise SystemExit("rank %d: device %d not found (%d visible)" % (rank, local, torch.cuda.device_count()))
     nat.load()                                   # fails loudly if the HIP library is missing
     # rehearsal switches (not used by the driver): PM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # PM_BENCH_BACKEND=gloo replaces RCCL, so the sharded code path can be exercised on a one-GPU box

@@ -135,9 +135,14 @@ __global__ __launch_bounds__(LS_THREADS) void col_min_final_kernel(const double 
 //   complementary slackness   |(U[i][j] - v[j]) - u[i]| <= delta         for j = col4row[i]          -> summary[2] counts failures
 // and the non-matching entries with reduced cost <= eps (the "tight" edges uniqueness is decided on): appended to
 // tight[cap][2] (with their reduced costs in tight_red[cap]) in arbitrary order, summary[1] = their number (may exceed
-// cap: then the list is incomplete).
+// cap: then the list is incomplete).  A row's tight entries are staged in LDS and appended with ONE global reservation per
+// row (not one atomic per entry: ~2.5e9 atomics on one address for a degenerate 50k matrix, and an int32 count that wraps
+// negative past 2^31 entries); the count saturates: once it exceeds cap no workgroup adds to it any more, and a row with
+// more than CERT_STAGE tight entries reports cap + 1 (list incomplete) instead of a partial list.
 // stats[0] = largest |reduced cost| on a matched entry, stats[1] = largest violation (positive number), as float64 bit
 // patterns (non-negative doubles order like their bit patterns, so an integer atomic max does it).
+constexpr int CERT_STAGE = 1024;      // tight entries of one row staged in LDS (12 KB)
+
 __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *__restrict__ U, int nc, size_t ld,
                                                                  const double *__restrict__ u, const double *__restrict__ v,
                                                                  const int32_t *__restrict__ col4row, double delta, double eps,
@@ -146,8 +151,12 @@ __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *_
                                                                  double *__restrict__ row_slack, double *__restrict__ row_neg) {
     __shared__ int s_cnt[2];
     __shared__ unsigned long long s_max[2];
+    __shared__ int s_nt, s_base;
+    __shared__ int32_t s_tj[CERT_STAGE];
+    __shared__ double s_tr[CERT_STAGE];
     const int tid = threadIdx.x, i = blockIdx.x;
     if (tid < 2) { s_cnt[tid] = 0; s_max[tid] = 0ull; }
+    if (tid == 0) { s_nt = 0; s_base = -1; }
     __syncthreads();
     const double *row = U + (size_t)i * ld;
     const double ui = u[i];
@@ -164,8 +173,8 @@ __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *_
             worst = fmax(worst, -red);
         } else if (red <= eps) {
             worst = fmax(worst, -red);                       // a negative reduced cost inside the tolerance still counts in the bound
-            const int at = atomicAdd(&summary[1], 1);
-            if (at < cap) { tight[2 * (size_t)at] = i; tight[2 * (size_t)at + 1] = j; tight_red[at] = red; }
+            const int at = atomicAdd(&s_nt, 1);              // LDS
+            if (at < CERT_STAGE) { s_tj[at] = j; s_tr[at] = red; }
         }
     }
     if (viol) atomicAdd(&s_cnt[0], viol);
@@ -182,6 +191,27 @@ __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *_
         // assignment costs at least (the new entries' reduced costs) - sum(row_slack) - sum(row_neg) more than this one
         if (row_slack) row_slack[i] = __longlong_as_double((long long)s_max[0]);
         if (row_neg) row_neg[i] = __longlong_as_double((long long)s_max[1]);
+        const int nt = s_nt;
+        if (nt > 0) {
+            // saturating count: nothing is added once the list has overflowed (the host only asks "more than cap?"), so the
+            // int32 cannot wrap: at most (resident workgroups) x CERT_STAGE is added beyond cap
+            const int seen = __hip_atomic_load(&summary[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (nt > CERT_STAGE) {
+                if (seen <= cap) atomicMax(&summary[1], cap < 0x7fffffff ? cap + 1 : cap);   // a row beyond the staging area: list incomplete
+            } else if (seen <= cap) {
+                const int base = atomicAdd(&summary[1], nt);
+                if (base >= 0 && base < cap) s_base = base;
+            }
+        }
+    }
+    __syncthreads();
+    const int base = s_base;
+    if (base >= 0) {
+        const int nt = s_nt;                                 // <= CERT_STAGE here
+        for (int k = tid; k < nt; k += LS_THREADS) {
+            const long long at = (long long)base + k;
+            if (at < cap) { tight[2 * (size_t)at] = i; tight[2 * (size_t)at + 1] = s_tj[k]; tight_red[at] = s_tr[k]; }
+        }
     }
 }
 

@@ -133,8 +133,9 @@ def transposed(U):
     """A contiguous transpose of a float64 GPU matrix by the tiled kernel (pm_transpose_f64; torch's strided copy takes
     ~0.4 s for the 19 GB of a 50 000 x 47 000 matrix, the kernel ~15 ms)."""
     torch = nat.torch_mod()
-    out = torch.empty((U.shape[1], U.shape[0]), dtype=torch.float64, device=U.device)
-    nat.check(nat.load().pm_transpose_f64(nat.ptr(U), U.shape[0], U.shape[1], U.stride(0), nat.ptr(out), out.stride(0), nat.stream_ptr()))
+    with torch.cuda.device(U.device):        # the launch goes to a stream of the device that owns U, whatever the current device is
+        out = torch.empty((U.shape[1], U.shape[0]), dtype=torch.float64, device=U.device)
+        nat.check(nat.load().pm_transpose_f64(nat.ptr(U), U.shape[0], U.shape[1], U.stride(0), nat.ptr(out), out.stride(0), nat.stream_ptr(U)))
     return out
 
 
@@ -437,8 +438,8 @@ def solve_on_device(U, info=None, force=False):
     info = {} if info is None else info
     n0, m0 = U.shape
     if min(n0, m0) >= (1 if force else DEVICE_MIN_ROWS):
-        W = DeviceMatrix(U if n0 <= m0 else transposed(U))           # rows are the short side (SciPy transposes likewise)
         with torch.cuda.device(U.device):
+            W = DeviceMatrix(U if n0 <= m0 else transposed(U))       # rows are the short side (SciPy transposes likewise)
             sol = solve_core(W, info)
             if sol is not None and certify(W, *sol, info=info):
                 info["route"] = "device"

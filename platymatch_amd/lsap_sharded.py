@@ -51,6 +51,22 @@ def _answer(local, row0, rows, op, args):
     raise ValueError("unknown operation %r" % (op,))
 
 
+class _Failed:
+    """What a rank gathers instead of an answer when its share of a query raised (e.g. out of device memory while allocating
+    the certificate's buffers): the two collectives of a query stay matched on every rank, and the root turns the message
+    into the error solve_pair_sharded raises on ALL ranks."""
+
+    def __init__(self, rank, exc):
+        self.message = "rank %d: %s: %s" % (rank, type(exc).__name__, exc)
+
+
+def _safe_answer(rank, local, row0, rows, op, args):
+    try:
+        return _answer(local, row0, rows, op, args)
+    except Exception as e:                               # never leave the query between its broadcast and its gather
+        return _Failed(rank, e)
+
+
 class ShardedMatrix:
     """lsap.DeviceMatrix's interface over row blocks on several ranks — the object the ROOT hands to lsap.solve_core /
     lsap.certify.  `locals_` are this rank's blocks of the matrices that may be queried (e.g. a hypothesis and its twin)."""
@@ -63,9 +79,12 @@ class ShardedMatrix:
         dist = _dist()
         rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
         dist.broadcast_object_list([(op, self.which, args)], src=_global(self.group, self.root), group=self.group)
-        mine = _answer(self.locals[self.which], self.bounds[rank], self.bounds[rank + 1] - self.bounds[rank], op, args)
+        mine = _safe_answer(rank, self.locals[self.which], self.bounds[rank], self.bounds[rank + 1] - self.bounds[rank], op, args)
         parts = [None] * world
         dist.gather_object(mine, parts, dst=_global(self.group, self.root), group=self.group)
+        failed = [p.message for p in parts if isinstance(p, _Failed)]
+        if failed:                                        # raised with both collectives of the query completed on every rank
+            raise RuntimeError("query %r failed on " % (op,) + "; ".join(failed))
         return parts
 
     def row_select(self, v, k):
@@ -122,7 +141,7 @@ def serve(locals_, bounds, group, root):
         op, which, args = box[0]
         if op == "stop":
             return
-        dist.gather_object(_answer(locals_[which], row0, rows, op, args), None, dst=_global(group, root), group=group)
+        dist.gather_object(_safe_answer(rank, locals_[which], row0, rows, op, args), None, dst=_global(group, root), group=group)
 
 
 def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=None, accept_near_ties=False):

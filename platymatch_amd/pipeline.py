@@ -117,6 +117,32 @@ class GpuBackend:
         return self.K.icp_update(sums, origin, mov, fix, nn, A_icp, parts_out=parts_out, nn_trusted=True, status=status)
 
 
+def cost_bytes(rows, n, m, world=1):
+    """Device memory the assignment stage of an N x M registration holds at its peak on one rank: the eight cost matrices of
+    its `rows` moving rows (64 rows M bytes) and, when N > M, the transposed copies the solver works on — the short side
+    must be the rows (lsap.solve_pair_on_device): one 8 N M-byte copy per pairing in flight, four pairings side by side on
+    one GPU (96 N M in all); sharded, a hypothesis with N > M is assembled whole on its owner next to its transpose
+    (pipeline.assign: at most ceil(8 / G) hypotheses per owner, one transposed at a time)."""
+    need = 64.0 * rows * m
+    if n > m:
+        need += 32.0 * n * m if world == 1 else 8.0 * n * m * (-(-8 // world) + 1)
+    return need
+
+
+def agree_max(value, group, device=None):
+    """max over the ranks of a small non-negative integer (a 4-byte all-reduce): how ranks settle a decision each of them
+    could take differently (free memory, local row counts), so that all of them enter the same sequence of collectives."""
+    _, world = _world(group)
+    if world == 1:
+        return int(value)
+    import torch
+    dist = _dist()
+    on_host = dist.get_backend(group) == "gloo"
+    t = torch.tensor([int(value)], dtype=torch.int32, device="cpu" if on_host else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
 def shard_bounds(n, world):
     """Contiguous row blocks, sizes differing by at most one: block g = [b[g], b[g+1])."""
     base, extra = divmod(n, world)
@@ -548,9 +574,14 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         try:
             sc_m, sc_f, bn = build_descriptors(be, mov, fix, group)
             # all eight matrices at once when they fit (four assignments then run side by side); otherwise two at a time
-            need = 64.0 * sc_m.shape[1] * sc_f.shape[1]
-            streamed = stream_hypotheses if stream_hypotheses is not None else (
-                hasattr(be, "free_bytes") and hasattr(be, "chi2_cost_pair") and need > 0.85 * be.free_bytes())
+            need = cost_bytes(sc_m.shape[1], mov.shape[1], sc_f.shape[1], world)
+            if stream_hypotheses is not None:
+                streamed = bool(stream_hypotheses)
+            else:
+                streamed = hasattr(be, "free_bytes") and hasattr(be, "chi2_cost_pair") and need > 0.85 * be.free_bytes()
+                # free memory and row counts differ from rank to rank: near the threshold ranks would take different branches,
+                # i.e. different sequences of collectives.  One rank that must stream makes all of them stream.
+                streamed = bool(agree_max(1 if streamed else 0, group, mov.device))
             U = None if streamed else be.chi2_cost8(sc_m, sc_f)
         except BaseException:
             draws.thread.join()
@@ -654,7 +685,7 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
 
     def need(k):
         n, m = _pair_size(pairs[k])
-        return 64.0 * n * m + 2880.0 * (2 * n + 4 * m) * 2
+        return cost_bytes(n, n, m) + 2880.0 * (2 * n + 4 * m) * 2
 
     slots = threading.local()
     next_slot = [0]

@@ -1,0 +1,111 @@
+"""Run by tests/test_gpu_rccl.py in a FRESH process: initialise torch.distributed's "nccl" backend (= RCCL on ROCm) at world
+size 1 on cuda:0 and push one tensor of every (collective, dtype, reduce-op) combination the sharded pipeline uses through
+it; then run the headless driver with group=WORLD on a reference fixture.  Prints one JSON line.
+
+Collectives of the product (platymatch_amd/pipeline.py, lsap_sharded.py, bench.py):
+  all_reduce SUM f64   cloud_statistics (mean-distance tile sums), estimate_transform_batch (result table)
+  all_reduce MAX i32   gather_fixed_descriptors (symmetry flag), assign (status words)
+  all_reduce MAX f64   bench.py (max-over-ranks step time)
+  all_gather f64 list  all_gather_rows (fixed descriptors), icp_sharded (26 doubles per iteration)
+  all_gather i32 list  cost_row_argmins
+  gather f64           assign (row blocks of an uncertified hypothesis to its owner)
+  broadcast i64        assign (index vectors from the owner)
+  broadcast/gather of Python objects   lsap_sharded query protocol
+  barrier              bench.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", sys.argv[1] if len(sys.argv) > 1 else "29531")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    out = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+    g = dist.group.WORLD
+
+    x = torch.arange(1000, dtype=torch.float64, device=dev) / 7.0
+    want = x.clone()
+    dist.all_reduce(x, op=dist.ReduceOp.SUM, group=g)
+    out["all_reduce_sum_f64"] = bool(torch.equal(x, want))
+    f = torch.tensor([3], dtype=torch.int32, device=dev)
+    dist.all_reduce(f, op=dist.ReduceOp.MAX, group=g)
+    out["all_reduce_max_i32"] = int(f.item()) == 3
+    t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=g)
+    out["all_reduce_max_f64"] = float(t.item()) == 1.25
+    blk = torch.rand((1, 37, 360), dtype=torch.float64, device=dev)
+    got = [torch.empty_like(blk)]
+    dist.all_gather(got, blk, group=g)
+    out["all_gather_f64"] = bool(torch.equal(got[0], blk))
+    idx = torch.arange(8 * 11, dtype=torch.int32, device=dev).reshape(8, 11)
+    goti = [torch.empty_like(idx)]
+    dist.all_gather(goti, idx, group=g)
+    out["all_gather_i32"] = bool(torch.equal(goti[0], idx))
+    rows = torch.rand((5, 64), dtype=torch.float64, device=dev)
+    whole = torch.empty((1, 5, 64), dtype=torch.float64, device=dev)
+    dist.gather(rows, [whole[0]], dst=0, group=g)
+    out["gather_f64"] = bool(torch.equal(whole[0], rows))
+    b = torch.arange(2 * 9, dtype=torch.int64, device=dev).reshape(2, 9)
+    keep = b.clone()
+    dist.broadcast(b, src=0, group=g)
+    out["broadcast_i64"] = bool(torch.equal(b, keep))
+    objs = [("row_select", {"k": 16})]
+    dist.broadcast_object_list(objs, src=0, group=g)
+    parts = [None]
+    dist.gather_object(("answer", np.arange(3)), parts, dst=0, group=g)
+    out["objects"] = objs[0][0] == "row_select" and parts[0][0] == "answer"
+    dist.barrier(group=g)
+    torch.cuda.synchronize()
+
+    # the product's own helpers over the same group
+    from platymatch_amd import pipeline as P
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    be = P.GpuBackend(dev)
+    local = torch.rand((4, 21, 360), dtype=torch.float64, device=dev)
+    out["all_gather_rows"] = bool(torch.equal(P.all_gather_rows(local, [0, 21], 1, g), local))
+
+    # the sharded statistics step by step (pipeline.cloud_statistics takes the one-GPU shortcut at world size 1): tile sums ->
+    # RCCL all-reduce -> ordered finish must give the bits of the one-device kernel; the symmetry flag through MAX
+    cloud = be.cloud(np.load(os.path.join(ROOT, "tests", "golden", "synth1000.npz"))["moving"])
+    part = be.mean_distance_partials(cloud, 0, 1)
+    dist.all_reduce(part, op=dist.ReduceOp.SUM, group=g)
+    md = be.mean_distance_finish(part, cloud.shape[1])
+    out["sharded_mean_distance_bits"] = bool(torch.equal(md.reshape(-1), be.stats(cloud)[1].reshape(-1)))
+    c, md1, x0 = be.stats(cloud)
+    sc_m = be.shape_context(cloud, c, md1, x0, 2, 0, cloud.shape[1])
+    sc_f = be.shape_context(cloud, c, md1, x0, 4, 0, cloud.shape[1])
+    flag = be.symmetry_flag(sc_m, sc_f)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=g)
+    out["symmetry_flag_dtype"] = str(flag.dtype)
+    out["symmetry_flag"] = int(flag.item())
+
+    # the headless driver with group=WORLD against the reference fixture (tests/golden/synth128.npz)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "synth128.npz"))
+    det = {}
+    A_sc, A_icp, inl = P.estimate_transform(fx["moving"], fx["fixed"], ransac_trials=int(fx["ransac_trials"]),
+                                            ransac_error=float(fx["ransac_error"]), icp_iterations=int(fx["icp_iters"]),
+                                            seed=int(fx["ransac_seed"]), details=det, group=g)
+    out["lsa_equal_fixture"] = all(bool(np.array_equal(det["lsa"][h][1], fx["lsa_cols"][h]) and np.array_equal(det["lsa"][h][0], fx["lsa_rows"][h]))
+                                   for h in range(8))
+    out["inliers_equal_fixture"] = bool(np.array_equal(inl, fx["ransac_inliers"]))
+    ref = fx["A_final"]
+    out["A_final_relerr"] = float(np.linalg.norm(A_icp @ A_sc - ref) / np.linalg.norm(ref))
+    dist.barrier(group=g)
+    dist.destroy_process_group()
+    print("RCCL_WORKER " + json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

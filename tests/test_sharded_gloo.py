@@ -406,3 +406,56 @@ def test_sharded_pair_solves_an_unrelated_twin_on_its_own_core_and_flags_near_ti
     assert np.array_equal(r0["AT0"], scipy_lsa(A)[1]) and np.array_equal(r0["AT1"], [-1])       # near-tie: refused by default
     rows = np.arange(A.shape[0])
     assert abs(T[rows, r0["AT_accept1"]].sum() - T[scipy_lsa(T)].sum()) < 1e-12 * len(rows)      # accepted: optimal to rounding
+
+
+def _failing_query_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from platymatch_amd import pipeline as P
+        from platymatch_amd.lsap_sharded import solve_pair_sharded
+        from test_lsap_core import HostMatrix
+
+        class Breaks(HostMatrix):
+            """A rank's block whose certificate pass fails (on a GPU: out of memory while allocating the tight-edge buffers)."""
+            def __init__(self, X, broken):
+                super().__init__(X)
+                self.broken = broken
+
+            def certificate(self, *a):
+                if self.broken:
+                    raise MemoryError("no room for the certificate's buffers")
+                return super().certificate(*a)
+
+        rng = np.random.default_rng(23)
+        n, m = 120, 140
+        A = rng.random((n, m)) + 0.5
+        b = P.shard_bounds(n, world)
+        msgs = []
+        for broken_rank, root in ((1, 0), (0, 0), (1, 1)):       # a worker's share fails; the root's own share fails; root = rank 1
+            try:
+                solve_pair_sharded(Breaks(A[b[rank]:b[rank + 1]], rank == broken_rank), None, b, m, dist.group.WORLD, root)
+                msgs.append("no error")
+            except RuntimeError as e:
+                msgs.append(str(e))
+        # and the protocol is still usable afterwards: a clean solve on the same group
+        c, _ = solve_pair_sharded(HostMatrix(A[b[rank]:b[rank + 1]]), None, b, m, dist.group.WORLD, 0)
+        np.savez(out_path % rank, msgs=np.array(msgs), c=np.asarray(c), A=A)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_query_that_fails_on_one_rank_is_raised_on_all_and_leaves_no_rank_behind(tmp_path):
+    """an exception inside a rank's share of a query (between the query's broadcast and its gather) used to leave
+    the other side in a collective for ever.  Now the failure travels as the answer and every rank raises the same error."""
+    from scipy.optimize import linear_sum_assignment as scipy_lsa
+    out = str(tmp_path / "f%d.npz")
+    mp.spawn(_failing_query_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    assert list(r0["msgs"]) == list(r1["msgs"])
+    for msg, who in zip(r0["msgs"], (1, 0, 1)):
+        assert "MemoryError" in str(msg) and ("rank %d" % who) in str(msg) and "certificate" in str(msg)
+    assert np.array_equal(r0["c"], r1["c"]) and np.array_equal(r0["c"], scipy_lsa(r0["A"])[1])
