@@ -284,6 +284,22 @@ int pm_ransac_affine(const double *mov, int n_mov, const double *fix, int n_fix,
                      const int32_t *cols, int n, const int32_t *samples, int min_samples, int trials, double error,
                      double *A_out, int32_t *inliers, int32_t *degenerate, void *stream);
 
+/* Index sets drawn ON THE DEVICE, for runs nobody seeded.  do_ransac draws a trial's pairs with
+ * np.random.choice(n, min_samples, replace=False) from NumPy's global generator (shape_context.py:122), which the reference
+ * never seeds: the contract is "min_samples distinct pairs, every subset equally likely".  Trial t draws from its own
+ * counter-based stream — Philox-4x32-10 with key = seed and counter = (t, block, run, 0); `run` separates the eight
+ * do_ransac calls of one registration — by Floyd's subset algorithm with exactly uniform bounded integers (Lemire).  The
+ * same (seed, run, n, min_samples) always yields the same sets, on any device.
+ *   pm_ransac_draw         samples[trials][min_samples] int32 only (transform='Similar' fits on the host; tests)
+ *   pm_ransac_affine_draw  pm_ransac_affine with the draw fused in front of each trial's fit; the sets are also written to
+ *                          samples_out (the caller refits flagged trials with pinv and may want the winner's pairs)
+ * Seeded calls keep the host replica of NumPy's stream (pm_legacy_choice) and pm_ransac_affine. */
+int pm_ransac_draw(int n, int min_samples, int trials, uint64_t seed, uint32_t run, int32_t *samples, void *stream);
+int pm_ransac_affine_draw(const double *mov, int n_mov, const double *fix, int n_fix, const int32_t *rows,
+                          const int32_t *cols, int n, int min_samples, int trials, uint64_t seed, uint32_t run,
+                          double error, int32_t *samples_out, double *A_out, int32_t *inliers, int32_t *degenerate,
+                          void *stream);
+
 /* Score caller-supplied transforms instead of fitting (transform='Similar', whose 4x4 eigen-decomposition stays on
  * the host, and the pinv refits of degenerate affine samples): A_in [trials][16]; only rows 0-2 are applied, as
  * apply_affine_transform does (apply_transform.py:14-17). */

@@ -404,6 +404,39 @@ def ransac_affine(mov, fix, rows, cols, samples, error):
     return A, inl, deg
 
 
+def ransac_draw(n, k, trials, seed, run=0, device=None):
+    """[trials, k] int32 GPU: k distinct indices of range(n) per trial from the device sampler (Philox-4x32-10 keyed by the
+    64-bit `seed`, counter (trial, block, run); Floyd's subset algorithm): pm_ransac_draw."""
+    torch = _t()
+    n, k, trials = int(n), int(k), int(trials)
+    if k > n or k <= 0 or trials <= 0:
+        raise ValueError("need 0 < k <= n and trials > 0")
+    out = torch.empty((trials, k), dtype=torch.int32, device=nat.device(device))
+    _here(out, "samples")
+    check(nat.load().pm_ransac_draw(n, k, trials, int(seed) & (2 ** 64 - 1), int(run) & 0xffffffff, ptr(out), nat.stream_ptr()))
+    return out
+
+
+def ransac_affine_draw(mov, fix, rows, cols, k, trials, seed, run, error):
+    """ransac_affine with each trial's index set drawn on the device in front of its fit (pm_ransac_affine_draw)
+    -> (samples [trials, k] int32, A [trials, 4, 4], inliers [trials] int32, degenerate [trials] int32)."""
+    torch = _t()
+    mov, fix, rows, cols, n = _pairs(mov, fix, rows, cols)
+    k, trials = int(k), int(trials)
+    if k < 4:
+        raise ValueError("k >= 4 (fewer pairs are rank deficient by construction: host pinv)")
+    if k > n:
+        raise ValueError("more samples per trial than matched pairs")
+    samples = torch.empty((trials, k), dtype=torch.int32, device=mov.device)
+    A = torch.empty((trials, 4, 4), dtype=torch.float64, device=mov.device)
+    inl = torch.empty(trials, dtype=torch.int32, device=mov.device)
+    deg = torch.empty(trials, dtype=torch.int32, device=mov.device)
+    check(nat.load().pm_ransac_affine_draw(ptr(mov), mov.shape[1], ptr(fix), fix.shape[1], ptr(rows), ptr(cols), n, k, trials,
+                                           int(seed) & (2 ** 64 - 1), int(run) & 0xffffffff, float(error), ptr(samples), ptr(A),
+                                           ptr(inl), ptr(deg), nat.stream_ptr()))
+    return samples, A, inl, deg
+
+
 def ransac_score(mov, fix, rows, cols, A, error):
     torch = _t()
     mov, fix, rows, cols, n = _pairs(mov, fix, rows, cols)

@@ -73,6 +73,9 @@ SIGNATURES = {
                                           _c_size_t, _c_void_p]),
     "pm_ransac_affine": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int,
                                   _c_double, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_ransac_draw": (_c_int, [_c_int, _c_int, _c_int, ctypes.c_uint64, ctypes.c_uint32, _c_void_p, _c_void_p]),
+    "pm_ransac_affine_draw": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                       ctypes.c_uint64, ctypes.c_uint32, _c_double, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "pm_ransac_score": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int,
                                  _c_double, _c_void_p, _c_void_p]),
     "pm_apply_affine": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p]),

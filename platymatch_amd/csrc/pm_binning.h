@@ -190,3 +190,63 @@ PM_HD int pm_bin_index(double x_, double y_, double z_, double r_, double r) {
     int idx = ring * 72 + th * 12 + pm_phi_index(x_, y_);
     return idx < PM_NBINS ? idx : PM_DROP;
 }
+
+// ---- single-precision pre-classification (the tile kernel's inner step, pm_shape_context.hip) -------------------------
+// Which bin a neighbour falls into is a set of sign decisions: which side of four spheres (rings), of four cones and a plane
+// (theta) and of twelve half-planes (phi sectors) it lies on.  A decision taken in float32 is THE decision — the one the
+// float64 expressions above reach, which are the oracle's — whenever the float32 quantity is clear of its threshold by more
+// than float32 arithmetic can be off.  With v the float64 difference vector rounded to float32 (f), the frame rounded to
+// float32, L = |f|_1 and s = |v|^2:
+//   linear quantities (x_, y_, z_, y_ - tan(30|60) x_)   are off by < 2^-19.9 L   -> accepted when clear by mL = 2^-17 L
+//   quadratic ones (4 z_^2 - s, 4 z_^2 - 3 s)            are off by < 2^-15.9 s   -> accepted when clear by mQ = 2^-14 s
+//   w = s * 64 / md^2 (ring = position of w among 1, 4, 16, 64) is off by < 2^-17.9 w -> accepted when w's mantissa is clear
+//   of a power of four by 2^-15
+// (the thresholds' own representation — cos(k pi/6) rounded, np.logspace's ulp-off edges, fl(2 pi/12) steps — moves them
+// by < 2^-50, far inside every margin).  Frames 2..4 are then the fixed phi permutations of frame 1 (x_, y_ clear of zero).
+// About one neighbour in 4 000 is NOT clear: -1 is returned and the caller decides it with pm_bin_index4 in float64.
+// theta from t = z_|z_| / s:  thresholds cos^2(30) = 3/4, cos^2(60) = 1/4, 0 and their negatives.
+#define PM_TAN30F 0x1.279a74p-1f
+#define PM_TAN60F 0x1.bb67aep+0f
+
+PM_HD int pm_bin_fast32(float f0, float f1, float f2, const float fr[9], float k64) {
+    const float L = (__builtin_fabsf(f0) + __builtin_fabsf(f1)) + __builtin_fabsf(f2);
+    const float vx = __builtin_fmaf(fr[2], f2, __builtin_fmaf(fr[1], f1, fr[0] * f0));
+    const float vy = __builtin_fmaf(fr[5], f2, __builtin_fmaf(fr[4], f1, fr[3] * f0));
+    const float vz = __builtin_fmaf(fr[8], f2, __builtin_fmaf(fr[7], f1, fr[6] * f0));
+    const float q2 = vz * vz;
+    const float s = __builtin_fmaf(vx, vx, __builtin_fmaf(vy, vy, q2));
+    const float a = 4.0f * q2;
+    const float dd1 = a - s, dd3 = __builtin_fmaf(-3.0f, s, a);
+    const float mQ = s * 0x1p-14f, mL = L * 0x1p-17f;
+    const float ax = __builtin_fabsf(vx), ay = __builtin_fabsf(vy);
+    const float d1 = __builtin_fmaf(-PM_TAN30F, ax, ay), d2 = __builtin_fmaf(-PM_TAN60F, ax, ay);
+    const float w = s * k64;
+    unsigned int wb;
+    __builtin_memcpy(&wb, &w, 4);
+    const unsigned int e = wb >> 23;                       // (w >= 0 or NaN: no sign bit to strip unless NaN, rejected below)
+    const int E = (int)e - 127;                            // floor(log2 w)
+    const unsigned int frac = wb & 0x7fffffu;
+    const unsigned int dist = (E & 1) ? (0x7fffffu - frac) : frac;     // distance (in ulps of w) to the nearest power of FOUR boundary
+    const int safe = (__builtin_fabsf(dd1) > mQ) & (__builtin_fabsf(dd3) > mQ) & (__builtin_fabsf(vz) > mL)
+                   & (__builtin_fabsf(d1) > mL) & (__builtin_fabsf(d2) > mL) & (ax > mL) & (ay > mL)
+                   & ((e - 40u) < 176u) & (dist >= 256u);
+    int ring = (E >> 1) + 1;                               // #{k : w >= 4^k, k = 0..3}
+    ring = ring < 0 ? 0 : (ring > 4 ? 4 : ring);
+    const int c = (dd1 > 0.0f) + (dd3 > 0.0f);
+    const int th = (vz > 0.0f) ? 2 - c : 3 + c;
+    const int k = (d1 > 0.0f) + (d2 > 0.0f);
+    const int u = (vx > 0.0f) ? k : 5 - k;                 // sector within the upper half plane, 0..5
+    const int p0 = (vy > 0.0f) ? u : 11 - u;               // (computed for every lane, selected below: no divergent branch)
+    return safe ? ring * 72 + th * 12 + p0 : -1;
+}
+
+// phi sector of frame f (1..3) given frame 1's (the permutations of get_unary's four frames, shape_context.py:172-181) and back
+PM_HD int pm_phi_perm(int f, int p0) {
+    return f == 0 ? p0 : f == 1 ? (p0 < 6 ? p0 + 6 : p0 - 6) : f == 2 ? 11 - p0 : (p0 < 6 ? 5 - p0 : 17 - p0);
+}
+// bin of frame f for a neighbour that frame 1 puts into `bin` (every permutation above is an involution or the half turn,
+// which is its own inverse: the same map reads a frame-f bin back to frame 1's)
+PM_HD int pm_bin_perm(int f, int bin) {
+    const int shell = bin / 12, p0 = bin - shell * 12;
+    return shell * 12 + pm_phi_perm(f, p0);
+}

@@ -16,16 +16,79 @@
 
 namespace pm {
 
+// ---- index sets drawn on the device (unseeded runs) -----------------------------------------------------------------
+// The reference draws a trial's pairs with np.random.choice(n, k, replace=False) from NumPy's GLOBAL generator
+// (shape_context.py:122) and never seeds it: what it asks for is "k distinct pairs, every k-subset equally
+// likely", not a particular stream.  NumPy's call permutes all n indices per trial — 8 x 8 000 full shuffles per
+// registration, the step that bounded a registration below 50 000 nuclei when restated on the host (pm_host_rng.cpp, kept
+// for SEEDED runs, where the reference's exact sets are reproduced).  Here each trial owns a counter-based stream
+// (Philox-4x32-10, Salmon et al. SC'11: key = the caller's 64-bit seed, counter = (trial, block, run, 0)) and picks its k
+// indices by Floyd's algorithm: for j = n-k .. n-1: t = uniform{0..j}; take t unless already taken, else j — every k-subset
+// with probability 1 / C(n, k), k draws, no array.  Uniform integers by Lemire's multiply-and-reject (exactly uniform).
+struct Philox {
+    uint32_t k0, k1, c0, c1, c2, c3;
+    uint32_t w[4];
+    int have;
+    __device__ __forceinline__ Philox(uint64_t seed, uint32_t trial, uint32_t run) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)),
+                                                                                   c0(trial), c1(0u), c2(run), c3(0u), have(0) {}
+    __device__ __forceinline__ void block() {
+        uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * x0, p1 = (uint64_t)0xCD9E8D57u * x2;
+            const uint32_t y0 = (uint32_t)(p1 >> 32) ^ x1 ^ a, y1 = (uint32_t)p1, y2 = (uint32_t)(p0 >> 32) ^ x3 ^ b, y3 = (uint32_t)p0;
+            x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3;
+        ++c1;                                              // next block of this trial's stream
+        have = 4;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        if (have == 0) block();
+        const uint32_t v = have == 4 ? w[0] : have == 3 ? w[1] : have == 2 ? w[2] : w[3];    // (no dynamic register indexing)
+        --have;
+        return v;
+    }
+    // uniform integer in [0, range), range >= 1 (Lemire 2019: unbiased, one multiply, a division only on the rare retry path)
+    __device__ __forceinline__ uint32_t below(uint32_t range) {
+        uint64_t m = (uint64_t)next() * range;
+        uint32_t lo = (uint32_t)m;
+        if (lo < range) {
+            const uint32_t thresh = (0u - range) % range;
+            while (lo < thresh) { m = (uint64_t)next() * range; lo = (uint32_t)m; }
+        }
+        return (uint32_t)(m >> 32);
+    }
+};
+
+// k distinct indices of [0, n) for one trial, written to out[0..k) (global memory of this thread's own row).
+__device__ __forceinline__ void draw_subset(uint64_t seed, uint32_t trial, uint32_t run, int n, int k, int32_t *out) {
+    Philox g(seed, trial, run);
+    for (int q = 0; q < k; ++q) {
+        const int j = n - k + q;
+        int t = (int)g.below((uint32_t)j + 1u);
+        for (int p = 0; p < q; ++p)
+            if (out[p] == t) { t = j; break; }             // j itself cannot have been taken: earlier picks are < j
+        out[q] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void draw_kernel(int n, int k, int trials, uint64_t seed, uint32_t run, int32_t *__restrict__ samples) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < trials) draw_subset(seed, (uint32_t)t, run, n, k, samples + (size_t)t * k);
+}
+
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = 4;
 constexpr int RS_CHUNK = 512;
 constexpr int RS_SUB = RS_CHUNK / RS_WAVES;
 
-template <bool FIT>
+template <bool FIT, bool DRAW = false>
 __global__ __launch_bounds__(RS_THREADS) void ransac_kernel(const double *__restrict__ mov, int n_mov,
                                                             const double *__restrict__ fix, int n_fix,
                                                             const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
-                                                            int n, const int32_t *__restrict__ samples, int k,
+                                                            int n, int32_t *samples, uint64_t seed, uint32_t run, int k,
                                                             const double *__restrict__ A_in, int trials, double error,
                                                             double *__restrict__ A_out, int32_t *__restrict__ inliers,
                                                             int32_t *__restrict__ degenerate) {
@@ -40,6 +103,14 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kernel(const double *__rest
     double A[16];
     bool flagged = false;
     if (FIT) {
+        if (DRAW) {
+            // this trial's index set is drawn here, in front of its fit: lane `lane` of wave 0 draws it into the caller's samples
+            // array (kept: degenerate samples are refitted on the host, and the winner's set is reported); the same lane of
+            // the other three waves — which fit the same trial and score another quarter of each chunk — reads it from there
+            // behind the workgroup barrier (release/acquire at workgroup scope: one CU, one L1)
+            if (wave == 0 && t < trials) draw_subset(seed, (uint32_t)t, run, n, k, samples + (size_t)t * k);
+            __syncthreads();
+        }
         auto pair_of = [&](int q, double a[3], double f[3]) {
             const int s = samples[(size_t)tc * k + q];
             const int im = rows ? rows[s] : s, jf = cols ? cols[s] : s;
@@ -141,7 +212,26 @@ int pm_ransac_affine(const double *mov, int n_mov, const double *fix, int n_fix,
     if (min_samples < 4) return PM_ERR_UNSUPPORTED;      // fewer than four pairs: rank deficient by construction (host pinv)
     if (min_samples > n) return PM_ERR_INVALID_ARG;
     pm::ransac_kernel<true><<<(trials + 63) / 64, pm::RS_THREADS, 0, (hipStream_t)stream>>>(
-        mov, n_mov, fix, n_fix, rows, cols, n, samples, min_samples, nullptr, trials, error, A_out, inliers, degenerate);
+        mov, n_mov, fix, n_fix, rows, cols, n, const_cast<int32_t *>(samples), 0ull, 0u, min_samples, nullptr, trials, error, A_out,
+        inliers, degenerate);
+    return pm::launch_status();
+}
+
+int pm_ransac_draw(int n, int min_samples, int trials, uint64_t seed, uint32_t run, int32_t *samples, void *stream) {
+    if (!samples || n <= 0 || trials <= 0 || min_samples <= 0) return PM_ERR_INVALID_ARG;
+    if (min_samples > n) return PM_ERR_INVALID_ARG;
+    pm::draw_kernel<<<(trials + 255) / 256, 256, 0, (hipStream_t)stream>>>(n, min_samples, trials, seed, run, samples);
+    return pm::launch_status();
+}
+
+int pm_ransac_affine_draw(const double *mov, int n_mov, const double *fix, int n_fix, const int32_t *rows, const int32_t *cols,
+                          int n, int min_samples, int trials, uint64_t seed, uint32_t run, double error, int32_t *samples_out,
+                          double *A_out, int32_t *inliers, int32_t *degenerate, void *stream) {
+    if (!mov || !fix || !samples_out || !inliers || n_mov <= 0 || n_fix <= 0 || n <= 0 || trials <= 0) return PM_ERR_INVALID_ARG;
+    if (min_samples < 4) return PM_ERR_UNSUPPORTED;
+    if (min_samples > n) return PM_ERR_INVALID_ARG;
+    pm::ransac_kernel<true, true><<<(trials + 63) / 64, pm::RS_THREADS, 0, (hipStream_t)stream>>>(
+        mov, n_mov, fix, n_fix, rows, cols, n, samples_out, seed, run, min_samples, nullptr, trials, error, A_out, inliers, degenerate);
     return pm::launch_status();
 }
 
@@ -149,7 +239,7 @@ int pm_ransac_score(const double *mov, int n_mov, const double *fix, int n_fix, 
                     int n, const double *A_in, int trials, double error, int32_t *inliers, void *stream) {
     if (!mov || !fix || !A_in || !inliers || n_mov <= 0 || n_fix <= 0 || n <= 0 || trials <= 0) return PM_ERR_INVALID_ARG;
     pm::ransac_kernel<false><<<(trials + 63) / 64, pm::RS_THREADS, 0, (hipStream_t)stream>>>(
-        mov, n_mov, fix, n_fix, rows, cols, n, nullptr, 0, A_in, trials, error, nullptr, inliers, nullptr);
+        mov, n_mov, fix, n_fix, rows, cols, n, nullptr, 0ull, 0u, 0, A_in, trials, error, nullptr, inliers, nullptr);
     return pm::launch_status();
 }
 

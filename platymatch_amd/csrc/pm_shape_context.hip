@@ -10,6 +10,15 @@
 // Frames 2..4 differ from frame 1 only in the signs of (x, y) (:172-175, :180-181), so ring and theta are
 // shared; the phi sectors of all frames come from one classification when the neighbour is clear of every
 // sector edge and from exact per-frame sign tests otherwise (pm_bin_index4, pm_binning.h).
+//
+// Round 3: the default path is the TILE kernel below (sc_tile_kernel): a workgroup owns SC_Q consecutive queried points, a
+// lane keeps one neighbour's coordinates in registers and walks the tile's queries (their frames are wave-uniform: scalar
+// loads from the frame table the prepare kernel wrote, SGPR operands), the neighbour is pre-classified in float32
+// (pm_bin_fast32: accepted only when clear of every bin boundary by more than float32 can be off, ~3 999 of 4 000) and
+// decided by the float64 expressions otherwise; ONE histogram per query (frame 1) is kept in LDS — frames 2..4 are its phi
+// permutations, written out as such.  A neighbour whose exact per-frame bins are NOT that permutation (it sits on a sector
+// edge or a pole of the frame) marks the tile, and the one-workgroup-per-point kernel (shape_context_kernel, the round-1
+// design, four explicit histograms) recomputes the marked tiles: same results in every case, by construction.
 #include "pm_common.h"
 #include "pm_binning.h"
 
@@ -17,16 +26,171 @@ namespace pm {
 
 constexpr int SC_THREADS = 256;
 constexpr int SC_WAVES = SC_THREADS / 64;
+constexpr int SC_Q = 16;              // queried points per workgroup of the tile kernel (LDS: 16 x 1 440 B)
+
+// What the prepare kernel leaves in the workspace for a launch over rows [row0, row0 + nrows):
+//   ScParams            ring thresholds, 64 / md^2 in float32, whether the float32 pre-classification may be used
+//   frames32 [nrows][12] float   x, y, z of each queried point's frame (9 used), for the scalar loads of the tile kernel
+//   frames64 [nrows][9]  double  the same frame in float64: what the exact path projects with (the oracle's bits)
+//   redo     [tiles]    int32    1 = recompute this tile with the general kernel
+struct ScParams {
+    double rho[4];
+    float k64;
+    int fast_ok;
+    int pad[2];
+};
+
+__device__ __forceinline__ void local_frame(const double *__restrict__ xyz, int n, int i, const double *__restrict__ centroid3,
+                                            const double *__restrict__ x0_3, double fr[9]) {
+    // shape_context.py:169-175; one rounding per written operation, in the oracle's order
+    const double p0 = xyz[i], p1 = xyz[(size_t)n + i], p2 = xyz[2 * (size_t)n + i];
+    double w0 = p0 - centroid3[0], w1 = p1 - centroid3[1], w2 = p2 - centroid3[2];
+    double nw = __builtin_sqrt((w0 * w0 + w1 * w1) + w2 * w2);
+    const double z0 = w0 / nw, z1 = w1 / nw, z2 = w2 / nw;
+    const double a0 = x0_3[0], a1 = x0_3[1], a2 = x0_3[2];
+    double d = (a0 * z0 + a1 * z1) + a2 * z2;
+    double x0 = a0 - z0 * d, x1 = a1 - z1 * d, x2 = a2 - z2 * d;
+    double nx = __builtin_sqrt((x0 * x0 + x1 * x1) + x2 * x2);
+    x0 /= nx; x1 /= nx; x2 /= nx;
+    double y0 = z1 * x2 - z2 * x1, y1 = z2 * x0 - z0 * x2, y2 = z0 * x1 - z1 * x0;   // get_Y
+    double ny = __builtin_sqrt((y0 * y0 + y1 * y1) + y2 * y2);
+    y0 /= ny; y1 /= ny; y2 /= ny;
+    fr[0] = x0; fr[1] = x1; fr[2] = x2; fr[3] = y0; fr[4] = y1; fr[5] = y2; fr[6] = z0; fr[7] = z1; fr[8] = z2;
+}
+
+__global__ __launch_bounds__(256) void sc_prepare_kernel(const double *__restrict__ xyz, int n, int row0, int nrows,
+                                                         const double *__restrict__ centroid3, const double *__restrict__ x0_3,
+                                                         const double *__restrict__ mean_dist1, ScParams *__restrict__ prm,
+                                                         float *__restrict__ frames32, double *__restrict__ frames64) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r == 0) {
+        const double md = mean_dist1[0];
+        double rho[4];
+        pm_ring_thresholds(md, rho);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) prm->rho[k] = rho[k];
+        const double k64 = 64.0 / (md * md);
+        const int ok = (md > 0.0) && (k64 >= 0x1p-30) && (k64 <= 0x1p+30);       // false for NaN
+        prm->k64 = ok ? (float)k64 : 0.0f;
+        prm->fast_ok = ok;
+        prm->pad[0] = prm->pad[1] = 0;
+    }
+    if (r >= nrows) return;
+    double fr[9];
+    local_frame(xyz, n, row0 + r, centroid3, x0_3, fr);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { frames64[(size_t)r * 9 + k] = fr[k]; frames32[(size_t)r * 12 + k] = (float)fr[k]; }
+#pragma unroll
+    for (int k = 9; k < 12; ++k) frames32[(size_t)r * 12 + k] = 0.0f;
+}
+
+// One neighbour of one query, decided in float64 with the oracle's operations; -> frame 1's bin if the frames' bins are the
+// permutations the tile kernel's output assumes (or every frame drops it: -1), -2 if they are not (the tile must be redone).
+template <int NF>
+__device__ __noinline__ int sc_exact_bin(double v0, double v1, double v2, const double *__restrict__ fr,
+                                         const double *__restrict__ rho_g) {
+    const double rho[4] = {rho_g[0], rho_g[1], rho_g[2], rho_g[3]};
+    const double vx = (fr[0] * v0 + fr[1] * v1) + fr[2] * v2;
+    const double vy = (fr[3] * v0 + fr[4] * v1) + fr[5] * v2;
+    const double vz = (fr[6] * v0 + fr[7] * v1) + fr[8] * v2;
+    int b[4];
+    pm_bin_index4(vx, vy, vz, rho, NF, b);
+    if (b[0] == PM_DROP) {
+        bool all = true;
+#pragma unroll
+        for (int f = 1; f < NF; ++f) all = all && (b[f] == PM_DROP);
+        return all ? -1 : -2;
+    }
+    bool conform = true;
+#pragma unroll
+    for (int f = 1; f < NF; ++f) conform = conform && (b[f] == pm_bin_perm(f, b[0]));
+    return conform ? b[0] : -2;
+}
+
+template <int NF>
+__global__ __launch_bounds__(SC_THREADS) void sc_tile_kernel(
+    const double *__restrict__ xyz, int n, int row0, int nrows, const ScParams *__restrict__ prm,
+    const float *__restrict__ frames32, const double *__restrict__ frames64, int32_t *__restrict__ counts,
+    int32_t *__restrict__ totals, double *__restrict__ hist, int32_t *__restrict__ redo) {
+    __shared__ unsigned int h[SC_Q][PM_NBINS];
+    __shared__ unsigned int tot_s[SC_Q];
+    __shared__ int s_redo;
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * SC_Q;                      // first row of the tile (within the row block)
+    const int nq = min(SC_Q, nrows - q0);
+    for (int k = tid; k < SC_Q * PM_NBINS; k += SC_THREADS) (&h[0][0])[k] = 0u;
+    if (tid < SC_Q) tot_s[tid] = 0u;
+    if (tid == 0) s_redo = 0;
+    __syncthreads();
+
+    const double *P0 = xyz, *P1 = xyz + (size_t)n, *P2 = xyz + 2 * (size_t)n;
+    const float k64 = prm->k64;
+    const bool fast_ok = prm->fast_ok != 0;
+
+    for (int j0 = 0; j0 < n; j0 += SC_THREADS) {
+        const int j = j0 + tid;
+        const bool valid = j < n;
+        const int jj = valid ? j : n - 1;
+        const double pj0 = P0[jj], pj1 = P1[jj], pj2 = P2[jj];
+        // the tile's queries one after the other (wave-uniform): each query's point and float32 frame arrive by scalar loads,
+        // fetched one query ahead so that their latency hides behind the previous query's arithmetic
+        const int i0 = row0 + q0;
+        double c0 = P0[i0], c1 = P1[i0], c2 = P2[i0];
+        const float *fq = frames32 + (size_t)q0 * 12;
+        float f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3], f4 = fq[4], f5 = fq[5], f6 = fq[6], f7 = fq[7], f8 = fq[8];
+        for (int q = 0; q < nq; ++q) {
+            const int qn = min(q + 1, nq - 1), in = row0 + q0 + qn;
+            const double n0 = P0[in], n1 = P1[in], n2 = P2[in];
+            const float *fn = frames32 + (size_t)(q0 + qn) * 12;
+            const float g0 = fn[0], g1 = fn[1], g2 = fn[2], g3 = fn[3], g4 = fn[4], g5 = fn[5], g6 = fn[6], g7 = fn[7], g8 = fn[8];
+            const double v0 = pj0 - c0, v1 = pj1 - c1, v2 = pj2 - c2;   // np.delete (:168): the point itself gives v = 0, dropped below as NaN
+            const float fr[9] = {f0, f1, f2, f3, f4, f5, f6, f7, f8};
+            int bin = fast_ok ? pm_bin_fast32((float)v0, (float)v1, (float)v2, fr, k64) : -1;
+            if (bin < 0 && valid) {
+                // not clear of a boundary in float32 (or the pair of the point with itself / a duplicate: v = 0 -> NaN -> not
+                // counted, exactly as arccos(0/0) in the reference): the float64 expressions decide
+                bin = sc_exact_bin<NF>(v0, v1, v2, frames64 + (size_t)(q0 + q) * 9, prm->rho);
+                if (bin == -2) s_redo = 1;
+            }
+            if (valid && bin >= 0) atomicAdd(&h[q][bin], 1u);
+            c0 = n0; c1 = n1; c2 = n2;
+            f0 = g0; f1 = g1; f2 = g2; f3 = g3; f4 = g4; f5 = g5; f6 = g6; f7 = g7; f8 = g8;
+        }
+    }
+    __syncthreads();
+    if (s_redo) {                                          // some neighbour sits on a sector edge or pole: general kernel
+        if (tid == 0) redo[blockIdx.x] = 1;
+        return;
+    }
+    if (tid == 0) redo[blockIdx.x] = 0;
+    // totals: every frame counts the same neighbours (a permutation inside each (ring, theta) shell)
+    for (int k = tid; k < nq * PM_NBINS; k += SC_THREADS) {
+        const unsigned int c = (&h[0][0])[k];
+        if (c) atomicAdd(&tot_s[k / PM_NBINS], c);
+    }
+    __syncthreads();
+    for (int f = 0; f < NF; ++f) {
+        for (int k = tid; k < nq * PM_NBINS; k += SC_THREADS) {
+            const int q = k / PM_NBINS, bin = k - q * PM_NBINS;
+            const unsigned int c = h[q][pm_bin_perm(f, bin)];                     // frame f's bin <- frame 1's (self-inverse maps)
+            const size_t o = ((size_t)f * nrows + (q0 + q)) * PM_NBINS + bin;
+            if (counts) counts[o] = (int32_t)c;
+            if (hist) hist[o] = (double)c / (double)tot_s[q];                      // sc / sc.sum() (:41); 0/0 = NaN as in the reference
+        }
+        if (totals && tid < nq) totals[(size_t)f * nrows + q0 + tid] = (int32_t)tot_s[tid];
+    }
+}
 
 template <int NF>
 __global__ __launch_bounds__(SC_THREADS) void shape_context_kernel(
     const double *__restrict__ xyz, int n, int row0, const double *__restrict__ centroid3,
     const double *__restrict__ x0_3, const double *__restrict__ mean_dist1, int32_t *__restrict__ counts,
-    int32_t *__restrict__ totals, double *__restrict__ hist, int nrows) {
+    int32_t *__restrict__ totals, double *__restrict__ hist, int nrows, const int32_t *__restrict__ redo) {
     __shared__ unsigned int h[SC_WAVES][NF][PM_NBINS];
     __shared__ unsigned int tot_s[NF];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int row = blockIdx.x;       // row within this block of rows
+    if (redo && !redo[row / SC_Q]) return;                 // (behind the tile kernel: only the tiles it marked)
     const int i = row0 + row;         // queried point
     for (int k = tid; k < SC_WAVES * NF * PM_NBINS; k += SC_THREADS) (&h[0][0][0])[k] = 0u;
     if (tid < NF) tot_s[tid] = 0u;
@@ -126,8 +290,60 @@ extern "C" int pm_shape_context(const double *xyz, int n, int row0, int nrows, c
     if (nrows == 0) return PM_OK;
     hipStream_t s = (hipStream_t)stream;
     if (n_frames == 2)
-        pm::shape_context_kernel<2><<<nrows, pm::SC_THREADS, 0, s>>>(xyz, n, row0, centroid3, x0_3, mean_dist1, counts, totals, hist, nrows);
+        pm::shape_context_kernel<2><<<nrows, pm::SC_THREADS, 0, s>>>(xyz, n, row0, centroid3, x0_3, mean_dist1, counts, totals, hist, nrows, nullptr);
     else
-        pm::shape_context_kernel<4><<<nrows, pm::SC_THREADS, 0, s>>>(xyz, n, row0, centroid3, x0_3, mean_dist1, counts, totals, hist, nrows);
+        pm::shape_context_kernel<4><<<nrows, pm::SC_THREADS, 0, s>>>(xyz, n, row0, centroid3, x0_3, mean_dist1, counts, totals, hist, nrows, nullptr);
+    return pm::launch_status();
+}
+
+namespace pm {
+struct ScWorkspace {
+    ScParams *prm;
+    float *frames32;
+    double *frames64;
+    int32_t *redo;
+};
+inline size_t sc_ws_layout(int nrows, char *base, ScWorkspace *w) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t at = off; off = align_up(off + bytes, 256); return at; };
+    const size_t o_prm = take(sizeof(ScParams));
+    const size_t o_f32 = take((size_t)nrows * 12 * sizeof(float));
+    const size_t o_f64 = take((size_t)nrows * 9 * sizeof(double));
+    const size_t o_redo = take((size_t)((nrows + SC_Q - 1) / SC_Q) * sizeof(int32_t));
+    if (w) {
+        w->prm = (ScParams *)(base + o_prm);
+        w->frames32 = (float *)(base + o_f32);
+        w->frames64 = (double *)(base + o_f64);
+        w->redo = (int32_t *)(base + o_redo);
+    }
+    return off;
+}
+}  // namespace pm
+
+extern "C" size_t pm_shape_context_workspace(int nrows) {
+    return nrows <= 0 ? 256 : pm::sc_ws_layout(nrows, nullptr, nullptr);
+}
+
+extern "C" int pm_shape_context_tiled(const double *xyz, int n, int row0, int nrows, const double *centroid3,
+                                      const double *x0_3, const double *mean_dist1, int n_frames, int32_t *counts,
+                                      int32_t *totals, double *hist, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!xyz || !centroid3 || !x0_3 || !mean_dist1 || n <= 0 || row0 < 0 || nrows < 0 || row0 + nrows > n)
+        return PM_ERR_INVALID_ARG;
+    if (n_frames != 2 && n_frames != 4) return PM_ERR_INVALID_ARG;
+    if (!counts && !totals && !hist) return PM_ERR_INVALID_ARG;
+    if (nrows == 0) return PM_OK;
+    if (!workspace || ((uintptr_t)workspace & 255) || workspace_bytes < pm_shape_context_workspace(nrows)) return PM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    pm::ScWorkspace w;
+    pm::sc_ws_layout(nrows, (char *)workspace, &w);
+    const int tiles = (nrows + pm::SC_Q - 1) / pm::SC_Q;
+    pm::sc_prepare_kernel<<<(nrows + 255) / 256, 256, 0, s>>>(xyz, n, row0, nrows, centroid3, x0_3, mean_dist1, w.prm, w.frames32, w.frames64);
+    if (n_frames == 2) {
+        pm::sc_tile_kernel<2><<<tiles, pm::SC_THREADS, 0, s>>>(xyz, n, row0, nrows, w.prm, w.frames32, w.frames64, counts, totals, hist, w.redo);
+        pm::shape_context_kernel<2><<<nrows, pm::SC_THREADS, 0, s>>>(xyz, n, row0, centroid3, x0_3, mean_dist1, counts, totals, hist, nrows, w.redo);
+    } else {
+        pm::sc_tile_kernel<4><<<tiles, pm::SC_THREADS, 0, s>>>(xyz, n, row0, nrows, w.prm, w.frames32, w.frames64, counts, totals, hist, w.redo);
+        pm::shape_context_kernel<4><<<nrows, pm::SC_THREADS, 0, s>>>(xyz, n, row0, centroid3, x0_3, mean_dist1, counts, totals, hist, nrows, w.redo);
+    }
     return pm::launch_status();
 }

@@ -218,8 +218,24 @@ def draw_ransac_samples(n, min_samples, trials, rng=None):
     return out
 
 
+# Where do_ransac's index sets come from when the caller passes neither `samples` nor `device_seed`:
+#   "numpy"  (default) NumPy's global generator, call for call as the reference consumes it (shape_context.py:122): after
+#            np.random.seed(s) the reference's own sets, hence its own result — what the fixture tests rely on;
+#   "device" the device sampler (pm_ransac_affine_draw), keyed by 64 bits taken from NumPy's global generator: for callers
+#            that never seed (the widget: SURVEY.md §5) — the same distribution of results without 8 x 8 000 host shuffles.
+SAMPLER = "numpy"
+
+
+def fresh_device_seed(rng=None):
+    """64 bits for the device sampler, taken from NumPy's global generator (or `rng`): a caller who seeded it gets
+    repeatable — though not the reference's — index sets; otherwise NumPy's own entropy-seeded start-up state decides."""
+    src = np.random if rng is None else rng
+    lo, hi = (int(v) for v in src.randint(0, 2 ** 32, size=2, dtype=np.uint64))
+    return (hi << 32) | lo
+
+
 def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transform='Affine', rows=None, cols=None,
-              samples=None):
+              samples=None, device_seed=None, run=0):
     """shape_context.py:103-139 -> (A_best 4 x 4, inliers_best).
 
     The host draws the index sets (same RNG calls as the reference); one kernel launch fits and
@@ -229,7 +245,8 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
     with no inliers at all A_best stays np.ones((4, 4)), as in the reference (:119-120, 136-138).
     `rows`/`cols` (optional) select matched pairs without gathering on the host:
     pairs are (moving_all[:, rows[k]], fixed_all[:, cols[k]]).  `samples` (optional, [trials, min_samples] int32):
-    index sets already drawn with draw_ransac_samples (pipeline.estimate_transform draws them ahead of time)."""
+    index sets already drawn with draw_ransac_samples (pipeline.estimate_transform draws them ahead of time).
+    `device_seed` (optional, 64-bit int): draw the sets on the device instead (Philox stream `run` of that seed; see SAMPLER)."""
     torch = nat.torch_mod()
     m, f = nat.to_dev(moving_all), nat.to_dev(fixed_all)
     if m.dim() != 2 or f.dim() != 2:
@@ -247,12 +264,23 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
     ones = np.ones((4, 4))
     if trials <= 0:
         return (torch.as_tensor(ones, device=m.device) if nat.is_torch(moving_all) else ones), 0
-    if samples is None:
-        samples = draw_ransac_samples(n, int(min_samples), trials)
-    else:
+    if transform not in ('Affine', 'Similar'):
+        raise ValueError("transform must be 'Affine' or 'Similar'")
+    if samples is None and device_seed is None and SAMPLER == "device" and int(min_samples) <= n:
+        device_seed = fresh_device_seed()
+    fused = None
+    if samples is not None:
         samples = np.ascontiguousarray(samples, dtype=np.int32)
         if samples.shape != (trials, int(min_samples)):
             raise ValueError("samples must be [trials, min_samples]")
+    elif device_seed is None or int(min_samples) > n:       # (min_samples > n raises inside np.random.choice, as in the reference)
+        samples = draw_ransac_samples(n, int(min_samples), trials)
+    elif transform == 'Affine' and int(min_samples) >= 4:
+        # the draw is fused in front of each trial's fit; the sets stay on the device (fetched only for trials the host refits)
+        fused = K.ransac_affine_draw(m, f, rows, cols, int(min_samples), trials, device_seed, run, float(error))
+        samples = _DeviceSamples(fused[0])
+    else:
+        samples = K.ransac_draw(n, int(min_samples), trials, device_seed, run, device=m.device).cpu().numpy()
     if transform == 'Affine':
         from .find_transform import affine_pinv_host, affine_pinv_host_batch
         k = int(min_samples)
@@ -266,7 +294,10 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
                 hosts["m"], hosts["f"] = mh, fh
             return hosts["m"], hosts["f"]
 
-        if k >= 4:
+        if fused is not None:
+            _, A, inl, deg = fused
+            redo = np.flatnonzero(deg.cpu().numpy())
+        elif k >= 4:
             A, inl, deg = K.ransac_affine(m, f, rows, cols, nat.to_dev(samples, dtype=torch.int32, dev=m.device), float(error))
             redo = np.flatnonzero(deg.cpu().numpy())
         else:                             # fewer than four pairs: rank deficient by construction, every fit is pinv's
@@ -312,8 +343,20 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
         s = samples[best]
         A_best = similar_transform_host(mh[:, s], fh[:, s])
         return (torch.as_tensor(A_best, device=m.device) if nat.is_torch(moving_all) else A_best), int(inl_h[best])
-    else:
-        raise ValueError("transform must be 'Affine' or 'Similar'")
+
+
+class _DeviceSamples:
+    """Index sets that were drawn on the device and stay there: rows are fetched only when the host needs them (the pinv
+    refit of flagged trials, the winner's set)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    def __getitem__(self, idx):
+        torch = nat.torch_mod()
+        if isinstance(idx, (int, np.integer)):
+            return self.dev[int(idx)].cpu().numpy()
+        return self.dev[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.dev.device)].cpu().numpy()
 
 
 def get_unary(centroid, mean_distance, detections, type, transposed=False, x0=None):

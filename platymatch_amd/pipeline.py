@@ -30,6 +30,8 @@ _RNG_LOCK = threading.RLock()
 class GpuBackend:
     """The product's only compute backend: the HIP kernels behind libplatymatch_hip.so."""
 
+    device_sampler = True      # do_ransac can draw its index sets on the device (unseeded runs)
+
     def __init__(self, dev=None):
         from . import _kernels
         self.K = _kernels
@@ -85,10 +87,10 @@ class GpuBackend:
         from .estimate_transform.shape_context import draw_ransac_samples
         return draw_ransac_samples(n, min_samples, trials, rng=rng)
 
-    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples, samples=None):
+    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples, samples=None, device_seed=None, run=0):
         from .estimate_transform.shape_context import do_ransac
         return do_ransac(mov, fix, min_samples=min_samples, trials=trials, error=error, transform=transform,
-                         rows=rows, cols=cols, samples=samples)
+                         rows=rows, cols=cols, samples=samples, device_seed=device_seed, run=run)
 
     def fit(self, kp_m, kp_f, transform):
         from .estimate_transform.find_transform import get_affine_transform, get_similar_transform
@@ -527,10 +529,28 @@ class _SampleDraws:
         return self.sets
 
 
+def _shared_device_seed(group, device):
+    """64 bits for the device sampler, the same on every rank: rank 0 takes them from NumPy's global generator
+    (shape_context.fresh_device_seed) and broadcasts them (8 bytes) — unseeded ranks would otherwise draw different index
+    sets, fit different A_sc and refine different clouds while exchanging moment sums as if they were one."""
+    from .estimate_transform.shape_context import fresh_device_seed
+    rank, world = _world(group)
+    with _RNG_LOCK:
+        seed = fresh_device_seed()
+    if world == 1:
+        return seed
+    import torch
+    dist = _dist()
+    on_host = dist.get_backend(group) == "gloo"
+    t = torch.tensor([seed - (1 << 64) if seed >= (1 << 63) else seed], dtype=torch.int64, device="cpu" if on_host else device)
+    dist.broadcast(t, src=_global_rank(group, 0), group=group)
+    return int(t.item()) & ((1 << 64) - 1)
+
+
 def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
                        ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, group=None,
                        backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS, private_rng=False, stream_hypotheses=None,
-                       accept_near_ties=False):
+                       accept_near_ties=False, sampler='auto'):
     """Reproduces _dock_widget.py:526-718 -> (A_sc, A_icp, inliers[8]); final transform = A_icp @ A_sc (:428).
 
     moving, fixed   3 x N / 3 x M float64 (rows z, y, x), NumPy or torch
@@ -539,6 +559,12 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     ransac_error    16 for CSV detections (_dock_widget.py:613-614); with nucleus sizes the widget uses
                     0.5 * (mean(size_m)**(1/3) + mean(size_f)**(1/3)) — pass that value
     seed            if not None, np.random.seed(seed) right before the eight RANSAC runs
+    sampler         where the RANSAC index sets come from.  'numpy': NumPy's global generator, call for call as the reference
+                    consumes it (8 x trials np.random.choice calls = full shuffles, drawn on a helper thread) — with a seed, the
+                    reference's own sets; 'device': drawn on the GPU in front of each trial's fit (Philox + Floyd's subset
+                    algorithm, keyed by 64 bits from NumPy's global generator, or by `seed` if one is given); 'auto' (default):
+                    'numpy' when a seed is given — the reference's seeded result is reproduced bit for bit —, 'device' when
+                    not: the reference never seeds, so an unseeded run is random there too
     private_rng     with a seed: draw from a private RandomState(seed) and leave NumPy's global generator untouched
                     (same index sets; what estimate_transform_batch uses so that concurrent runs do not queue)
     group           torch.distributed process group to shard over (None = this GPU only); every rank
@@ -567,9 +593,15 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         return time.perf_counter()
 
     t0 = time.perf_counter()
+    if sampler not in ('auto', 'numpy', 'device'):
+        raise ValueError("sampler must be 'auto', 'numpy' or 'device'")
+    on_device = (sampler == 'device' or (sampler == 'auto' and seed is None)) and getattr(be, "device_sampler", False) \
+        and int(ransac_samples) <= min(mov.shape[1], fix.shape[1])
     if mode == 'unsupervised':
         # what do_ransac draws depends only on the number of matched pairs: start drawing before the GPU has built anything
-        draws = _SampleDraws(be, min(mov.shape[1], fix.shape[1]), int(ransac_samples), int(ransac_trials), seed, private_rng)
+        # (device sampler: nothing to draw ahead — each trial's set is drawn in front of its fit)
+        draws = _SampleDraws(be, min(mov.shape[1], fix.shape[1]), int(ransac_samples), 0 if on_device else int(ransac_trials),
+                             seed, private_rng)
         a_info = None if details is None else details.setdefault("assignment", {})
         try:
             sc_m, sc_f, bn = build_descriptors(be, mov, fix, group)
@@ -601,9 +633,15 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             if timing is not None:
                 timing["host_draws_thread"] = draws.seconds
         A_h = []
+        if on_device:
+            dseed = (int(seed) & ((1 << 64) - 1)) if seed is not None else _shared_device_seed(group, mov.device)
         for h, (r, c) in enumerate(lsa):
-            A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
-                                ransac_samples, samples=sets[h])
+            if on_device:                            # stream h of the registration's seed: the eight runs draw independent sets
+                A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
+                                    ransac_samples, device_seed=dseed, run=h)
+            else:
+                A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
+                                    ransac_samples, samples=sets[h])
             A_h.append(nat.to_dev(A, dev=mov.device))
             inliers[h] = k
         A_sc = A_h[int(np.argmax(inliers))]          # first maximum (_dock_widget.py:683-703)
@@ -664,7 +702,7 @@ def _pair_size(pair):
     return tuple(int(x.shape[1]) for x in pair[:2])
 
 
-def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
+def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
     """This process's share of a batch: pairs ks on `workers` host threads, one HIP stream each."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
@@ -698,7 +736,7 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
         return slots.id
 
     def one(k):
-        det = {"timing": True} if timings is not None else None
+        det = {"timing": True} if timings is not None else ({} if reports is not None else None)
         if not on_gpu:                       # a caller-supplied host backend (tests): no stream to set
             out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, details=det, **kwargs)
         else:
@@ -718,6 +756,8 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
                     gate.notify_all()
         if timings is not None:
             timings[k] = det["timing"]
+        if reports is not None:
+            reports[k] = {"routes": det.get("assignment", {}).get("routes"), "mode": det.get("assignment", {}).get("mode")}
         return out
 
     # largest first: the long Hungarian solves start early and the short pairs fill the gaps at the end
@@ -729,7 +769,7 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None):
         return dict(zip(order, ex.map(one, order)))
 
 
-def estimate_transform_batch(pairs, workers=8, seeds=None, group=None, timings=None, **kwargs):
+def estimate_transform_batch(pairs, workers=8, seeds=None, group=None, timings=None, reports=None, **kwargs):
     """Several independent registrations (BASELINE config 5: "replicas only" — pairs never exchange data).
 
     One GPU (group=None): each worker thread drives its pairs on its own HIP stream — a PERSISTENT one (nat.side_stream:
@@ -745,7 +785,8 @@ def estimate_transform_batch(pairs, workers=8, seeds=None, group=None, timings=N
     Seeded pairs draw their RANSAC index sets from a private RandomState(seed) (the sets np.random.seed(seed) would
     give); unseeded pairs draw from NumPy's global generator one after the other.
     pairs: iterable of (moving, fixed); seeds: optional per-pair RANSAC seeds; timings: optional dict, filled with
-    {pair index: wall-clock split of its stages} for the pairs this process registered (adds stream synchronisations).
+    {pair index: wall-clock split of its stages} for the pairs this process registered (adds stream synchronisations);
+    reports: optional dict, filled with {pair index: {"routes": how each of its eight assignments was obtained}}.
     -> list of (A_sc, A_icp, inliers) in input order, each identical to a stand-alone estimate_transform call."""
     import torch
     pairs = list(pairs)
@@ -756,14 +797,14 @@ def estimate_transform_batch(pairs, workers=8, seeds=None, group=None, timings=N
         raise ValueError("details is per registration: call estimate_transform for the pair of interest")
     rank, world = _world(group)
     if world == 1:
-        res = _run_local(pairs, list(range(len(pairs))), workers, seeds, kwargs, timings)
+        res = _run_local(pairs, list(range(len(pairs))), workers, seeds, kwargs, timings, reports)
         return [res[k] for k in range(len(pairs))]
     dist = _dist()
     owner = batch_assignment([_pair_size(p) for p in pairs], world)
     mine = [k for k in range(len(pairs)) if owner[k] == rank]
     failure = None
     try:
-        res = _run_local(pairs, mine, workers, seeds, kwargs, timings)
+        res = _run_local(pairs, mine, workers, seeds, kwargs, timings, reports)
     except Exception as e:                     # keep the collective below matched on every rank, then raise everywhere
         failure, res = e, {}
     be = kwargs.get("backend")

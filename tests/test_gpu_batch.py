@@ -59,3 +59,83 @@ def test_smallest_pair_of_the_batch_matches_the_oracle_stage_by_stage(pairs, ora
     assert np.array_equal(det_g["nn"], det_o["nn"])
     ref = o_icp @ o_sc
     assert np.linalg.norm(A_icp @ A_sc - ref) / np.linalg.norm(ref) < 1e-9
+
+
+def test_config5_at_its_stated_size_64_pairs_of_2k_to_20k(pairs):
+    del pairs                                     # (the module fixture only makes sure the library is built and loaded)
+    """BASELINE config 5 as stated: 64 specimen pairs, sizes default_rng(5).integers(2000, 20001) (SURVEY.md §8d), each a complete
+    unsupervised registration (_dock_widget.py:526-718: 8 x 8 000 RANSAC trials, 50 ICP iterations), one GPU, eight worker
+    threads with a HIP stream each.  Every one of the 512 assignments must come from the device-resident route with a
+    certificate (no dense host solve), every pair must recover its ground-truth transform to the noise level, the three
+    largest pairs must equal their stand-alone registrations bit for bit, and LP duality is re-checked on the host for the
+    winning hypothesis of the largest pair.  Prints registrations/s for the seeded (NumPy-stream draws) and the unseeded
+    (device sampler) batch."""
+    import time
+    import torch
+    from platymatch_amd import _kernels as K, lsap as L, pipeline as P
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    sizes = [int(x) for x in np.random.default_rng(5).integers(2000, 20001, size=64)]
+    assert min(sizes) >= 2000 and max(sizes) <= 20000
+    batch, truth = [], []
+    for k, n in enumerate(sizes):
+        mv, fx, A = synth_pair(n, 100 + k)
+        batch.append((mv, fx))
+        truth.append(A)
+    kw = dict(ransac_trials=8000, ransac_error=16, icp_iterations=50)
+    P.estimate_transform(batch[0][0][:, :1500], batch[0][1][:, :1500], ransac_trials=100, icp_iterations=2)      # warm-up
+    seeds = list(range(64))
+    reports = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = P.estimate_transform_batch(batch, workers=8, seeds=seeds, reports=reports, **kw)
+    torch.cuda.synchronize()
+    dt_seeded = time.perf_counter() - t0
+    assert sorted(reports) == list(range(64))
+    routes = [r for k in range(64) for r in reports[k]["routes"]]
+    assert len(routes) == 512 and all(r is not None and r.startswith("device") and "near-tie" not in r for r in routes), sorted(set(map(str, routes)))
+    worst = 0.0
+    for k, ((A_sc, A_icp, inl), A) in enumerate(zip(out, truth)):
+        err = np.linalg.norm(A_icp @ A_sc - A) / np.linalg.norm(A)
+        worst = max(worst, err)
+        assert err < 2e-3, (k, sizes[k], err)                   # sigma = 1 jitter on the fixed cloud
+        assert inl.max() >= 0.9 * sizes[k], (k, inl)
+    # the three largest pairs on their own: identical bits
+    big3 = sorted(range(64), key=lambda k: -sizes[k])[:3]
+    det = {}
+    for k in big3:
+        d = det if k == big3[0] else None
+        A_sc, A_icp, inl = P.estimate_transform(batch[k][0], batch[k][1], seed=seeds[k], details=d, **kw)
+        assert np.array_equal(inl, out[k][2]) and np.array_equal(A_sc, out[k][0]) and np.array_equal(A_icp, out[k][1]), k
+    # LP duality for the winning hypothesis of the largest pair, re-checked on the host in extended precision
+    k = big3[0]
+    h = int(np.argmax(out[k][2]))
+    be = P.GpuBackend()
+    mov, fix = be.cloud(batch[k][0]), be.cloud(batch[k][1])
+    sc_m, sc_f, _ = P.build_descriptors(be, mov, fix)
+    name = P.HYPOTHESES[h]
+    U = K.chi2_cost(sc_m[int(name[0]) - 1], sc_f[int(name[1]) - 1])
+    M = L.DeviceMatrix(U)
+    info = {}
+    sol = L.solve_core(M, info)
+    assert sol is not None and L.certify(M, *sol, info=info), info
+    u, v, c4r = sol
+    n = sizes[k]
+    assert np.array_equal(c4r.astype(np.int64), det["lsa"][h][1]) and np.array_equal(np.sort(c4r), np.arange(n))
+    assigned = U[torch.arange(n, device=U.device), torch.as_tensor(c4r.astype(np.int64), device=U.device)].cpu().numpy()
+    primal = np.sum(assigned.astype(np.longdouble))
+    dual = np.sum(u.astype(np.longdouble)) + np.sum(v.astype(np.longdouble))
+    assert abs(float(primal - dual)) <= 1e-9 * float(primal), (float(primal), float(dual))
+    del U, M
+    # the default for callers who do not seed: index sets drawn on the device
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out_u = P.estimate_transform_batch(batch, workers=8, **kw)
+    torch.cuda.synchronize()
+    dt_unseeded = time.perf_counter() - t0
+    worst_u = max(np.linalg.norm(o[1] @ o[0] - A) / np.linalg.norm(A) for o, A in zip(out_u, truth))
+    assert worst_u < 2e-3
+    print("\nconfig 5: 64 pairs of %d..%d nuclei on one GPU: seeded (NumPy-stream draws) %.2f s = %.2f registrations/s; unseeded "
+          "(device sampler) %.2f s = %.2f registrations/s; worst rel. error vs ground truth %.1e / %.1e; 512 of 512 assignments "
+          "device-certified; primal - dual of the largest pair's winner %.1e"
+          % (min(sizes), max(sizes), dt_seeded, 64 / dt_seeded, dt_unseeded, 64 / dt_unseeded, worst, worst_u, float(primal - dual)))

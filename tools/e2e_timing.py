@@ -58,3 +58,14 @@ for rep in range(int(os.environ.get("PM_E2E_REPEAT", "3"))):
     torch.cuda.synchronize()
     print("%-34s %9.1f ms   (same inliers: %s)  stages %s" % ("estimate_transform, whole", (time.perf_counter() - t) * 1e3, list(inl2) == inl,
                                                             {k: round(v, 3) for k, v in det.get("timing", {}).items()}), flush=True)
+
+# the default for callers who do not seed (the widget never does): index sets drawn on the device in front of each fit
+for rep in range(int(os.environ.get("PM_E2E_REPEAT", "3"))):
+    det = {"timing": True}
+    t = time.perf_counter()
+    A_sc3, A_icp3, inl3 = P.estimate_transform(mov, fix, ransac_trials=trials, ransac_error=16, icp_iterations=50, details=det)
+    torch.cuda.synchronize()
+    final3 = (A_icp3 @ A_sc3).cpu().numpy()
+    print("%-34s %9.1f ms   (inliers %s, rel. error %.2e)  stages %s"
+          % ("estimate_transform, unseeded", (time.perf_counter() - t) * 1e3, list(inl3), np.linalg.norm(final3 - A_gt) / np.linalg.norm(A_gt),
+             {k: round(v, 3) for k, v in det.get("timing", {}).items()}), flush=True)
