@@ -109,6 +109,19 @@ int pm_shape_context(const double *xyz, int n, int row0, int nrows, const double
                      const double *x0_3, const double *mean_dist1, int n_frames, int32_t *counts,
                      int32_t *totals, double *hist, void *stream);
 
+/* The same histograms by the tile kernel (round 3; what the Python mirror calls): a workgroup owns 16 consecutive rows, a
+ * lane keeps one neighbour in registers and walks the tile's queries (frames by scalar loads), neighbours are
+ * pre-classified in float32 and accepted only when clear of every bin boundary by more than float32 can be off (about
+ * 3 999 of 4 000; pm_binning.h: pm_bin_fast32), the others are decided by the float64 expressions of pm_shape_context; one
+ * histogram per row is kept (frame 1) and frames 2..4 are written as its phi permutations.  Tiles holding a neighbour for
+ * which that permutation does not hold exactly (on a sector edge or pole of the frame) are recomputed by pm_shape_context's
+ * kernel inside the same call.  Outputs are identical to pm_shape_context's in every case.
+ * workspace: pm_shape_context_workspace(nrows) bytes, 256-byte aligned (frames, thresholds, per-tile flags). */
+size_t pm_shape_context_workspace(int nrows);
+int pm_shape_context_tiled(const double *xyz, int n, int row0, int nrows, const double *centroid3,
+                           const double *x0_3, const double *mean_dist1, int n_frames, int32_t *counts,
+                           int32_t *totals, double *hist, void *workspace, size_t workspace_bytes, void *stream);
+
 /* get_shape_context (shape_context.py:10-42) on an explicit neighbour list already expressed in the
  * local frame: nb is n x 3 row-major (x_, y_, z_ per row, as the reference passes it); counts[360]
  * int32 and/or hist[360] float64 (= counts / counts.sum()); total[1] int32 may be NULL. */

@@ -177,8 +177,10 @@ def label_moments(labels, n_labels=None):
     return counts, sums
 
 
-def shape_context(xyz, centroid3, x0_3, mean_dist1, n_frames, row0=0, nrows=None, want_counts=False, want_hist=True):
-    """-> dict(hist=[F, nrows, 360] float64, counts=[F, nrows, 360] int32, totals=[F, nrows] int32)."""
+def shape_context(xyz, centroid3, x0_3, mean_dist1, n_frames, row0=0, nrows=None, want_counts=False, want_hist=True, path="tiled"):
+    """-> dict(hist=[F, nrows, 360] float64, counts=[F, nrows, 360] int32, totals=[F, nrows] int32).
+    path: "tiled" (default: pm_shape_context_tiled) or "general" (pm_shape_context, one workgroup per point: the kernel the
+    tiled call itself falls back to for tiles with neighbours on a sector edge) — identical outputs."""
     torch = _t()
     xyz = _cloud(xyz)
     n = xyz.shape[1]
@@ -193,8 +195,16 @@ def shape_context(xyz, centroid3, x0_3, mean_dist1, n_frames, row0=0, nrows=None
     totals = torch.empty((n_frames, nrows), dtype=torch.int32, device=xyz.device) if want_counts else None
     if not (want_hist or want_counts):
         raise ValueError("nothing requested")
-    check(nat.load().pm_shape_context(ptr(xyz), n, row0, nrows, ptr(c), ptr(a), ptr(md), n_frames, ptr(counts), ptr(totals),
-                                      ptr(hist), nat.stream_ptr()))
+    lib = nat.load()
+    if path == "general":
+        check(lib.pm_shape_context(ptr(xyz), n, row0, nrows, ptr(c), ptr(a), ptr(md), n_frames, ptr(counts), ptr(totals),
+                                   ptr(hist), nat.stream_ptr()))
+    elif path == "tiled":
+        ws = nat.workspace(lib.pm_shape_context_workspace(nrows), xyz.device)
+        check(lib.pm_shape_context_tiled(ptr(xyz), n, row0, nrows, ptr(c), ptr(a), ptr(md), n_frames, ptr(counts), ptr(totals),
+                                         ptr(hist), ptr(ws), ws.numel(), nat.stream_ptr()))
+    else:
+        raise ValueError("path must be 'tiled' or 'general'")
     return {"hist": hist, "counts": counts, "totals": totals}
 
 

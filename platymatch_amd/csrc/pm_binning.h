@@ -227,9 +227,13 @@ PM_HD int pm_bin_fast32(float f0, float f1, float f2, const float fr[9], float k
     const int E = (int)e - 127;                            // floor(log2 w)
     const unsigned int frac = wb & 0x7fffffu;
     const unsigned int dist = (E & 1) ? (0x7fffffu - frac) : frac;     // distance (in ulps of w) to the nearest power of FOUR boundary
-    const int safe = (__builtin_fabsf(dd1) > mQ) & (__builtin_fabsf(dd3) > mQ) & (__builtin_fabsf(vz) > mL)
-                   & (__builtin_fabsf(d1) > mL) & (__builtin_fabsf(d2) > mL) & (ax > mL) & (ay > mL)
-                   & ((e - 40u) < 176u) & (dist >= 256u);
+    // clear of every boundary?  (minima first: five comparisons instead of nine — on the GPU every comparison result is a lane
+    // mask in scalar registers and every `and` of two masks a scalar instruction, and a CU has ONE scalar unit for its four
+    // SIMDs.  fminf drops a NaN operand, but a NaN or infinite coordinate makes s — hence w — NaN or infinite: e = 255 fails.)
+    const float nearQ = __builtin_fminf(__builtin_fabsf(dd1), __builtin_fabsf(dd3));
+    const float nearL = __builtin_fminf(__builtin_fminf(__builtin_fabsf(vz), __builtin_fabsf(d1)),
+                                        __builtin_fminf(__builtin_fabsf(d2), __builtin_fminf(ax, ay)));
+    const int safe = (nearQ > mQ) & (nearL > mL) & ((e - 40u) < 176u) & (dist >= 256u);
     int ring = (E >> 1) + 1;                               // #{k : w >= 4^k, k = 0..3}
     ring = ring < 0 ? 0 : (ring > 4 ? 4 : ring);
     const int c = (dd1 > 0.0f) + (dd3 > 0.0f);

@@ -19,6 +19,7 @@
 // permutations, written out as such.  A neighbour whose exact per-frame bins are NOT that permutation (it sits on a sector
 // edge or a pole of the frame) marks the tile, and the one-workgroup-per-point kernel (shape_context_kernel, the round-1
 // design, four explicit histograms) recomputes the marked tiles: same results in every case, by construction.
+#include <algorithm>
 #include "pm_common.h"
 #include "pm_binning.h"
 
@@ -30,9 +31,17 @@ constexpr int SC_Q = 16;              // queried points per workgroup of the til
 
 // What the prepare kernel leaves in the workspace for a launch over rows [row0, row0 + nrows):
 //   ScParams            ring thresholds, 64 / md^2 in float32, whether the float32 pre-classification may be used
-//   frames32 [nrows][12] float   x, y, z of each queried point's frame (9 used), for the scalar loads of the tile kernel
+//   frames32 [nrows][16 dwords]  per queried point ONE 64-byte record {x, y, z of its frame as 9 floats, pad, its coordinates as
+//                                3 doubles}: the tile kernel fetches a query with a single s_load_dwordx16
 //   frames64 [nrows][9]  double  the same frame in float64: what the exact path projects with (the oracle's bits)
 //   redo     [tiles]    int32    1 = recompute this tile with the general kernel
+struct alignas(64) ScQuery {          // what the tile kernel needs of one queried point: 16 dwords, one scalar load
+    float fr[9];
+    float pad;
+    double p[3];
+};
+static_assert(sizeof(ScQuery) == 64, "one s_load_dwordx16");
+
 struct ScParams {
     double rho[4];
     float k64;
@@ -78,10 +87,13 @@ __global__ __launch_bounds__(256) void sc_prepare_kernel(const double *__restric
     if (r >= nrows) return;
     double fr[9];
     local_frame(xyz, n, row0 + r, centroid3, x0_3, fr);
+    ScQuery rec;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { frames64[(size_t)r * 9 + k] = fr[k]; frames32[(size_t)r * 12 + k] = (float)fr[k]; }
-#pragma unroll
-    for (int k = 9; k < 12; ++k) frames32[(size_t)r * 12 + k] = 0.0f;
+    for (int k = 0; k < 9; ++k) { frames64[(size_t)r * 9 + k] = fr[k]; rec.fr[k] = (float)fr[k]; }
+    rec.pad = 0.0f;
+    const int i = row0 + r;
+    rec.p[0] = xyz[i]; rec.p[1] = xyz[(size_t)n + i]; rec.p[2] = xyz[2 * (size_t)n + i];
+    ((ScQuery *)frames32)[r] = rec;
 }
 
 // One neighbour of one query, decided in float64 with the oracle's operations; -> frame 1's bin if the frames' bins are the
@@ -107,19 +119,22 @@ __device__ __noinline__ int sc_exact_bin(double v0, double v1, double v2, const 
     return conform ? b[0] : -2;
 }
 
+// grid = (tiles, segments): workgroup (t, g) bins the neighbours [g * seg_len, (g + 1) * seg_len) for the 16 rows of tile t and
+// adds its histogram into cnt1 (integer atomics: exact, order-free).  Splitting the neighbours keeps the work units small
+// against the chip (a 50 000-row launch has 3 125 tiles for 1 536 resident workgroups — 2.03 per slot, i.e. a third round
+// for 53 of them — and a rank's 6 250-row block of an 8-GPU run would fill a quarter of the slots).
 template <int NF>
 __global__ __launch_bounds__(SC_THREADS) void sc_tile_kernel(
-    const double *__restrict__ xyz, int n, int row0, int nrows, const ScParams *__restrict__ prm,
-    const float *__restrict__ frames32, const double *__restrict__ frames64, int32_t *__restrict__ counts,
-    int32_t *__restrict__ totals, double *__restrict__ hist, int32_t *__restrict__ redo) {
+    const double *__restrict__ xyz, int n, int row0, int nrows, int seg_len, const ScParams *__restrict__ prm,
+    const float *__restrict__ frames32, const double *__restrict__ frames64, unsigned int *__restrict__ cnt1,
+    int32_t *__restrict__ redo) {
     __shared__ unsigned int h[SC_Q][PM_NBINS];
-    __shared__ unsigned int tot_s[SC_Q];
     __shared__ int s_redo;
     const int tid = threadIdx.x;
     const int q0 = blockIdx.x * SC_Q;                      // first row of the tile (within the row block)
     const int nq = min(SC_Q, nrows - q0);
+    const int j_begin = blockIdx.y * seg_len, j_end = min(n, j_begin + seg_len);
     for (int k = tid; k < SC_Q * PM_NBINS; k += SC_THREADS) (&h[0][0])[k] = 0u;
-    if (tid < SC_Q) tot_s[tid] = 0u;
     if (tid == 0) s_redo = 0;
     __syncthreads();
 
@@ -127,24 +142,19 @@ __global__ __launch_bounds__(SC_THREADS) void sc_tile_kernel(
     const float k64 = prm->k64;
     const bool fast_ok = prm->fast_ok != 0;
 
-    for (int j0 = 0; j0 < n; j0 += SC_THREADS) {
+    for (int j0 = j_begin; j0 < j_end; j0 += SC_THREADS) {
         const int j = j0 + tid;
-        const bool valid = j < n;
-        const int jj = valid ? j : n - 1;
+        const bool valid = j < j_end;
+        const int jj = valid ? j : j_end - 1;
         const double pj0 = P0[jj], pj1 = P1[jj], pj2 = P2[jj];
         // the tile's queries one after the other (wave-uniform): each query's point and float32 frame arrive by scalar loads,
         // fetched one query ahead so that their latency hides behind the previous query's arithmetic
-        const int i0 = row0 + q0;
-        double c0 = P0[i0], c1 = P1[i0], c2 = P2[i0];
-        const float *fq = frames32 + (size_t)q0 * 12;
-        float f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3], f4 = fq[4], f5 = fq[5], f6 = fq[6], f7 = fq[7], f8 = fq[8];
-        for (int q = 0; q < nq; ++q) {
-            const int qn = min(q + 1, nq - 1), in = row0 + q0 + qn;
-            const double n0 = P0[in], n1 = P1[in], n2 = P2[in];
-            const float *fn = frames32 + (size_t)(q0 + qn) * 12;
-            const float g0 = fn[0], g1 = fn[1], g2 = fn[2], g3 = fn[3], g4 = fn[4], g5 = fn[5], g6 = fn[6], g7 = fn[7], g8 = fn[8];
-            const double v0 = pj0 - c0, v1 = pj1 - c1, v2 = pj2 - c2;   // np.delete (:168): the point itself gives v = 0, dropped below as NaN
-            const float fr[9] = {f0, f1, f2, f3, f4, f5, f6, f7, f8};
+        // the tile's queries one after the other (wave-uniform): a query's record arrives by scalar loads, fetched one query
+        // ahead (two register sets used in turn, no copies) so that its latency hides behind the previous query's arithmetic
+        const ScQuery *qrec = (const ScQuery *)frames32 + q0;
+        auto one_query = [&](const ScQuery &r, int q) {
+            const double v0 = pj0 - r.p[0], v1 = pj1 - r.p[1], v2 = pj2 - r.p[2];   // np.delete (:168): the point itself gives v = 0, dropped below as NaN
+            const float fr[9] = {r.fr[0], r.fr[1], r.fr[2], r.fr[3], r.fr[4], r.fr[5], r.fr[6], r.fr[7], r.fr[8]};
             int bin = fast_ok ? pm_bin_fast32((float)v0, (float)v1, (float)v2, fr, k64) : -1;
             if (bin < 0 && valid) {
                 // not clear of a boundary in float32 (or the pair of the point with itself / a duplicate: v = 0 -> NaN -> not
@@ -153,31 +163,56 @@ __global__ __launch_bounds__(SC_THREADS) void sc_tile_kernel(
                 if (bin == -2) s_redo = 1;
             }
             if (valid && bin >= 0) atomicAdd(&h[q][bin], 1u);
-            c0 = n0; c1 = n1; c2 = n2;
-            f0 = g0; f1 = g1; f2 = g2; f3 = g3; f4 = g4; f5 = g5; f6 = g6; f7 = g7; f8 = g8;
+        };
+        ScQuery ra = qrec[0];
+        for (int q = 0; q < nq; q += 2) {
+            const ScQuery rb = qrec[min(q + 1, nq - 1)];
+            one_query(ra, q);
+            ra = qrec[min(q + 2, nq - 1)];
+            if (q + 1 < nq) one_query(rb, q + 1);
         }
     }
     __syncthreads();
     if (s_redo) {                                          // some neighbour sits on a sector edge or pole: general kernel
-        if (tid == 0) redo[blockIdx.x] = 1;
+        if (tid == 0) redo[blockIdx.x] = 1;                // (zeroed by the prepare kernel; only ever set)
         return;
     }
-    if (tid == 0) redo[blockIdx.x] = 0;
-    // totals: every frame counts the same neighbours (a permutation inside each (ring, theta) shell)
     for (int k = tid; k < nq * PM_NBINS; k += SC_THREADS) {
         const unsigned int c = (&h[0][0])[k];
-        if (c) atomicAdd(&tot_s[k / PM_NBINS], c);
+        if (c) atomicAdd(&cnt1[(size_t)q0 * PM_NBINS + k], c);
     }
+}
+
+// Frame 1's counts -> the outputs of all frames: totals, counts, normalised histograms (one workgroup per row).
+template <int NF>
+__global__ __launch_bounds__(128) void sc_finish_kernel(const unsigned int *__restrict__ cnt1, int nrows, const int32_t *__restrict__ redo,
+                                                        int32_t *__restrict__ counts, int32_t *__restrict__ totals,
+                                                        double *__restrict__ hist) {
+    __shared__ unsigned int c_s[PM_NBINS];
+    __shared__ unsigned int part[2];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (redo[row / SC_Q]) return;                          // the general kernel writes this tile's rows
+    unsigned int mine = 0;
+    for (int k = tid; k < PM_NBINS; k += 128) {
+        const unsigned int c = cnt1[(size_t)row * PM_NBINS + k];
+        c_s[k] = c;
+        mine += c;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, PM_WAVE);
+    if ((tid & 63) == 0) part[tid >> 6] = mine;
     __syncthreads();
+    // every frame counts the same neighbours (a permutation inside each (ring, theta) shell): one total
+    const unsigned int tot = part[0] + part[1];
+#pragma unroll
     for (int f = 0; f < NF; ++f) {
-        for (int k = tid; k < nq * PM_NBINS; k += SC_THREADS) {
-            const int q = k / PM_NBINS, bin = k - q * PM_NBINS;
-            const unsigned int c = h[q][pm_bin_perm(f, bin)];                     // frame f's bin <- frame 1's (self-inverse maps)
-            const size_t o = ((size_t)f * nrows + (q0 + q)) * PM_NBINS + bin;
+        for (int bin = tid; bin < PM_NBINS; bin += 128) {
+            const unsigned int c = c_s[pm_bin_perm(f, bin)];                       // frame f's bin <- frame 1's (self-inverse maps)
+            const size_t o = ((size_t)f * nrows + row) * PM_NBINS + bin;
             if (counts) counts[o] = (int32_t)c;
-            if (hist) hist[o] = (double)c / (double)tot_s[q];                      // sc / sc.sum() (:41); 0/0 = NaN as in the reference
+            if (hist) hist[o] = (double)c / (double)tot;                           // sc / sc.sum() (:41); 0/0 = NaN as in the reference
         }
-        if (totals && tid < nq) totals[(size_t)f * nrows + q0 + tid] = (int32_t)tot_s[tid];
+        if (totals && tid == 0) totals[(size_t)f * nrows + row] = (int32_t)tot;
     }
 }
 
@@ -302,26 +337,32 @@ struct ScWorkspace {
     float *frames32;
     double *frames64;
     int32_t *redo;
+    unsigned int *cnt1;
+    size_t zero_from, zero_bytes;      // [redo | cnt1]: zeroed before every launch
 };
 inline size_t sc_ws_layout(int nrows, char *base, ScWorkspace *w) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t at = off; off = align_up(off + bytes, 256); return at; };
     const size_t o_prm = take(sizeof(ScParams));
-    const size_t o_f32 = take((size_t)nrows * 12 * sizeof(float));
+    const size_t o_f32 = take((size_t)nrows * sizeof(ScQuery));
     const size_t o_f64 = take((size_t)nrows * 9 * sizeof(double));
     const size_t o_redo = take((size_t)((nrows + SC_Q - 1) / SC_Q) * sizeof(int32_t));
+    const size_t o_cnt = take((size_t)nrows * PM_NBINS * sizeof(unsigned int));
     if (w) {
         w->prm = (ScParams *)(base + o_prm);
         w->frames32 = (float *)(base + o_f32);
         w->frames64 = (double *)(base + o_f64);
         w->redo = (int32_t *)(base + o_redo);
+        w->cnt1 = (unsigned int *)(base + o_cnt);
+        w->zero_from = o_redo;
+        w->zero_bytes = off - o_redo;
     }
     return off;
 }
 }  // namespace pm
 
 extern "C" size_t pm_shape_context_workspace(int nrows) {
-    return nrows <= 0 ? 256 : pm::sc_ws_layout(nrows, nullptr, nullptr);
+    return nrows <= 0 ? 0 : pm::sc_ws_layout(nrows, nullptr, nullptr);
 }
 
 extern "C" int pm_shape_context_tiled(const double *xyz, int n, int row0, int nrows, const double *centroid3,
@@ -337,12 +378,22 @@ extern "C" int pm_shape_context_tiled(const double *xyz, int n, int row0, int nr
     pm::ScWorkspace w;
     pm::sc_ws_layout(nrows, (char *)workspace, &w);
     const int tiles = (nrows + pm::SC_Q - 1) / pm::SC_Q;
+    // neighbour segments: about ten work units per resident workgroup (256 CUs x 6), each at least 2 048 neighbours long
+    int segs = (10 * 1536 + tiles - 1) / tiles;
+    segs = std::max(1, std::min(segs, (n + 2047) / 2048));
+    int seg_len = (n + segs - 1) / segs;
+    seg_len = (seg_len + pm::SC_THREADS - 1) / pm::SC_THREADS * pm::SC_THREADS;
+    segs = (n + seg_len - 1) / seg_len;
+    if (hipMemsetAsync((char *)workspace + w.zero_from, 0, w.zero_bytes, s) != hipSuccess) return PM_ERR_LAUNCH;
     pm::sc_prepare_kernel<<<(nrows + 255) / 256, 256, 0, s>>>(xyz, n, row0, nrows, centroid3, x0_3, mean_dist1, w.prm, w.frames32, w.frames64);
+    const dim3 grid((unsigned)tiles, (unsigned)segs);
     if (n_frames == 2) {
-        pm::sc_tile_kernel<2><<<tiles, pm::SC_THREADS, 0, s>>>(xyz, n, row0, nrows, w.prm, w.frames32, w.frames64, counts, totals, hist, w.redo);
+        pm::sc_tile_kernel<2><<<grid, pm::SC_THREADS, 0, s>>>(xyz, n, row0, nrows, seg_len, w.prm, w.frames32, w.frames64, w.cnt1, w.redo);
+        pm::sc_finish_kernel<2><<<nrows, 128, 0, s>>>(w.cnt1, nrows, w.redo, counts, totals, hist);
         pm::shape_context_kernel<2><<<nrows, pm::SC_THREADS, 0, s>>>(xyz, n, row0, centroid3, x0_3, mean_dist1, counts, totals, hist, nrows, w.redo);
     } else {
-        pm::sc_tile_kernel<4><<<tiles, pm::SC_THREADS, 0, s>>>(xyz, n, row0, nrows, w.prm, w.frames32, w.frames64, counts, totals, hist, w.redo);
+        pm::sc_tile_kernel<4><<<grid, pm::SC_THREADS, 0, s>>>(xyz, n, row0, nrows, seg_len, w.prm, w.frames32, w.frames64, w.cnt1, w.redo);
+        pm::sc_finish_kernel<4><<<nrows, 128, 0, s>>>(w.cnt1, nrows, w.redo, counts, totals, hist);
         pm::shape_context_kernel<4><<<nrows, pm::SC_THREADS, 0, s>>>(xyz, n, row0, centroid3, x0_3, mean_dist1, counts, totals, hist, nrows, w.redo);
     }
     return pm::launch_status();

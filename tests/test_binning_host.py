@@ -198,3 +198,114 @@ def test_four_frame_step_ring_and_theta_decided_on_squares(host_lib, oracle):
                         tests.append((rad * np.sin(th) * np.cos(ph), rad * np.sin(th) * np.sin(ph), rad * np.cos(th)))
         tests = np.array(tests)
         assert np.array_equal(prod_bin4(host_lib, tests, md), oracle_bin4(oracle, tests, md)), md
+
+
+# ---- the tile kernel's float32 pre-classification (pm_bin_fast32): whatever it decides must be what float64 decides
+def _frame(rng):
+    """An orthonormal frame as the kernel builds it (z towards the point, x = axis minus its z part, y = z x x)."""
+    z = rng.normal(size=3)
+    z /= np.linalg.norm(z)
+    a = rng.normal(size=3)
+    a /= np.linalg.norm(a)
+    x = a - z * (a @ z)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    y /= np.linalg.norm(y)
+    return np.concatenate([x, y, z])
+
+
+def fast32(lib, v, fr, md):
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    out = np.empty(len(v), np.int32)
+    proj = np.empty((len(v), 3))
+    lib.pmt_bin_fast32(v.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(len(v)), np.ascontiguousarray(fr).ctypes.data_as(ctypes.c_void_p),
+                       ctypes.c_double(md), out.ctypes.data_as(ctypes.c_void_p), proj.ctypes.data_as(ctypes.c_void_p))
+    return out, proj
+
+
+def _check_fast32(lib, oracle, v, fr, md):
+    """-> (number decided in float32, number of vectors).  Every decided vector: frame 1's bin is the oracle's on the float64
+    frame coordinates, and frames 2..4 are its permutations."""
+    got, proj = fast32(lib, v, fr, md)
+    dec = got >= 0
+    want = oracle_bin4(oracle, proj[dec], md)
+    assert np.array_equal(got[dec], want[:, 0])
+    for f in (1, 2, 3):
+        perm = np.array([lib.pmt_bin_perm(f, int(b)) for b in np.unique(got[dec])])
+        lut = dict(zip(np.unique(got[dec]).tolist(), perm.tolist()))
+        assert np.array_equal(np.array([lut[int(b)] for b in got[dec]]), want[:, f]), f
+    return int(dec.sum()), len(v)
+
+
+def test_float32_preclassification_agrees_with_float64_wherever_it_decides(host_lib, oracle):
+    rng = np.random.default_rng(11)
+    decided = total = 0
+    for trial in range(12):
+        fr = _frame(rng)
+        md = [114.13353403330422, 37.0, 1.0, 250.0, 0.01, 3000.0][trial % 6]
+        scale = rng.uniform(0.02, 6.0, size=(150_000, 1)) * md
+        v = rng.normal(size=(150_000, 3)) * scale / np.sqrt(3)
+        d, t = _check_fast32(host_lib, oracle, v, fr, md)
+        decided += d
+        total += t
+    assert decided / total > 0.999, decided / total          # "about 3 999 of 4 000"; measured here
+    print("float32 pre-classification decides %.5f of random neighbours" % (decided / total))
+
+
+def test_float32_preclassification_never_decides_near_a_boundary(host_lib, oracle):
+    """Neighbours placed at relative distances 0, 1e-9 ... 1e-3 on both sides of every ring sphere, theta cone and phi
+    half-plane, plus the poles and the self pair: decided ones must be right; those within float32's reach of a boundary
+    must come back undecided (-1)."""
+    rng = np.random.default_rng(12)
+    rels = [0.0, 1e-12, -1e-12, 1e-9, -1e-9, 1e-7, -1e-7, 1e-6, -1e-6, 3e-6, -3e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3]
+    for md in (114.13353403330422, 1.0, 37.0):
+        for _ in range(4):
+            fr = _frame(rng)
+            X, Y, Z = fr[:3], fr[3:6], fr[6:]
+            pts, near = [], []
+            for edge in (0.125, 0.25, 0.5, 1.0):
+                for rel in rels:
+                    for _ in range(8):
+                        u = rng.normal(size=3)
+                        u /= np.linalg.norm(u)
+                        pts.append(edge * md * (1 + rel) * u)
+                        near.append(abs(rel) <= 1e-7)
+            for k in range(0, 7):
+                for rel in rels:
+                    th = k * np.pi / 6 + rel
+                    for rad in (0.3 * md, 1.7 * md):
+                        for ph in (0.1, 2.0, 4.4, 6.0):
+                            loc = np.array([rad * np.sin(th) * np.cos(ph), rad * np.sin(th) * np.sin(ph), rad * np.cos(th)])
+                            pts.append(loc[0] * X + loc[1] * Y + loc[2] * Z)
+                            near.append(abs(rel) <= 1e-7)
+            for m in range(12):
+                for rel in rels:
+                    ph = m * np.pi / 6 + rel
+                    for rad in (0.3 * md, 1.7 * md):
+                        for th in (0.4, 1.3, 2.5):
+                            loc = np.array([rad * np.sin(th) * np.cos(ph), rad * np.sin(th) * np.sin(ph), rad * np.cos(th)])
+                            pts.append(loc[0] * X + loc[1] * Y + loc[2] * Z)
+                            near.append(abs(rel) <= 1e-7)
+            pts += [np.zeros(3), 5.0 * Z, -5.0 * Z, 1e-30 * X, 1e30 * X, np.array([np.nan, 1.0, 1.0])]
+            near += [True] * 6
+            pts, near = np.array(pts), np.array(near)
+            got, _ = fast32(host_lib, pts, fr, md)
+            assert (got[near] == -1).all()
+            ok = np.isfinite(pts).all(1)
+            _check_fast32(host_lib, oracle, pts[ok], fr, md)
+    # mean distances outside the float32 range of 64 / md^2: nothing is decided in float32
+    for md in (1e-9, 1e9, 0.0, float("nan"), float("inf")):
+        got, _ = fast32(host_lib, rng.normal(size=(100, 3)), _frame(rng), md)
+        assert (got == -1).all()
+
+
+def test_bin_permutations_are_the_frames_of_get_unary(host_lib):
+    q = np.arange(12)
+    for bin_ in range(360):
+        shell, p0 = divmod(bin_, 12)
+        assert host_lib.pmt_bin_perm(0, bin_) == bin_
+        assert host_lib.pmt_bin_perm(1, bin_) == shell * 12 + (p0 + 6) % 12
+        assert host_lib.pmt_bin_perm(2, bin_) == shell * 12 + 11 - p0
+        assert host_lib.pmt_bin_perm(3, bin_) == shell * 12 + (5 - p0) % 12
+        for f in range(4):                                   # reading back: the same map
+            assert host_lib.pmt_bin_perm(f, host_lib.pmt_bin_perm(f, bin_)) == bin_

@@ -840,3 +840,77 @@ def test_term_table_is_ruled_out_for_anything_but_count_over_total(gpu):
     assert _table_launch(gpu, da, db, ws=small)[0] == -2
     big = gpu.t.empty(1 << 20, dtype=gpu.t.uint8, device=da.device)
     assert _table_launch(gpu, da, db, ws=big[8:])[0] == -2
+
+
+# ------------------------------------------------------------------------------------------------ tile kernel (round 3)
+def _both_paths(gpu, cloud, c, md, x0, nf, **kw):
+    xyz = gpu.d(np.ascontiguousarray(cloud))
+    args = (xyz, gpu.d(np.asarray(c, dtype=np.float64).reshape(3)), gpu.d(np.asarray(x0, dtype=np.float64).reshape(3)),
+            gpu.d(np.array([md], dtype=np.float64)), nf)
+    out = []
+    for path in ("tiled", "general"):
+        r = gpu.K.shape_context(*args, want_counts=True, want_hist=True, path=path, **kw)
+        out.append((r["counts"].cpu().numpy(), r["totals"].cpu().numpy(), r["hist"].cpu().numpy()))
+    return out
+
+
+@pytest.mark.parametrize("n,seed", [(3, 0), (17, 1), (256, 2), (257, 3), (1000, 4), (5000, 5)])
+def test_tile_kernel_equals_the_general_kernel_on_generic_clouds(gpu, oracle, n, seed):
+    mv, fx, _ = synth_pair(n, seed)
+    for cloud, nf in ((mv, 2), (fx, 4)):
+        c, md, x0 = oracle.get_centroid(cloud, False), oracle.get_mean_distance(cloud, False), oracle.pca_axis(cloud.T)
+        (tc, tt, th), (gc, gt, gh) = _both_paths(gpu, cloud, c, md, x0, nf)
+        assert np.array_equal(tc, gc) and np.array_equal(tt, gt)
+        assert np.array_equal(th.view(np.uint64), gh.view(np.uint64))
+        assert (tt == n - 1).all()                         # every other point is counted, in every frame
+    # a row block that starts and ends inside tiles
+    if n >= 257:
+        c, md, x0 = oracle.get_centroid(fx, False), oracle.get_mean_distance(fx, False), oracle.pca_axis(fx.T)
+        (tc, tt, th), (gc, gt, gh) = _both_paths(gpu, fx, c, md, x0, 4, row0=7, nrows=n - 20)
+        assert np.array_equal(tc, gc) and np.array_equal(tt, gt) and np.array_equal(th.view(np.uint64), gh.view(np.uint64))
+
+
+def test_tile_kernel_on_lattices_duplicates_and_degenerate_statistics(gpu, oracle, micro):
+    """Where the float32 pre-classification must hand over and where the permutation of the frames breaks: neighbours exactly on
+    ring spheres, theta cones, sector edges and poles (an integer lattice seen from the centroid's direction), duplicate
+    points, the point at the centroid (NaN frame), and mean distances that rule the float32 path out."""
+    g = np.arange(-3, 4, dtype=np.float64)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1)                      # 343 points, centroid = origin point
+    dup = np.concatenate([lattice[:, :50], lattice[:, :50], lattice[:, 100:140] + 0.25], axis=1)   # duplicates
+    cases = [(lattice, np.zeros(3), 1.0, np.array([1.0, 0.0, 0.0])),
+             (lattice, np.zeros(3), 2.0, np.array([0.0, 0.6, 0.8])),
+             (lattice + 0.5, np.zeros(3), 1.7320508075688772, np.array([0.0, 0.0, 1.0])),
+             (dup, np.array([0.1, -0.2, 0.3]), 2.5, np.array([0.6, 0.0, 0.8])),
+             (micro["degenerate_cloud"], micro["degenerate_centroid"].ravel(), float(micro["degenerate_mean_dist"]), None)]
+    for cloud, c, md, x0 in cases:
+        if x0 is None:
+            x0 = oracle.pca_axis(cloud.T)
+        for nf in (2, 4):
+            with np.errstate(all="ignore"):
+                (tc, tt, th), (gc, gt, gh) = _both_paths(gpu, cloud, c, md, x0, nf)
+            assert np.array_equal(tc, gc) and np.array_equal(tt, gt)
+            assert np.array_equal(th.view(np.uint64), gh.view(np.uint64))
+    # mean distances for which 64 / md^2 leaves the float32 path's range (everything through float64), zero, NaN, infinity
+    mv, _, _ = synth_pair(300, 9)
+    c, x0 = oracle.get_centroid(mv, False), oracle.pca_axis(mv.T)
+    for md in (1e-9, 1e9, 0.0, float("nan"), float("inf"), 1e-3, 2.0e5):
+        with np.errstate(all="ignore"):
+            (tc, tt, th), (gc, gt, gh) = _both_paths(gpu, mv, c, md, x0, 4)
+        assert np.array_equal(tc, gc) and np.array_equal(tt, gt) and np.array_equal(th.view(np.uint64), gh.view(np.uint64)), md
+
+
+def test_tile_kernel_argument_errors(gpu):
+    import ctypes
+    lib = gpu.nat.load()
+    xyz = gpu.d(np.random.default_rng(0).normal(size=(3, 64)))
+    v3, v1 = gpu.d(np.ones(3)), gpu.d(np.ones(1))
+    hist = gpu.t.empty((2, 64, 360), dtype=gpu.t.float64, device=gpu.dev)
+    need = lib.pm_shape_context_workspace(64)
+    ws = gpu.nat.workspace(need, gpu.dev)
+    p = gpu.nat.ptr
+    call = lambda wsp, nbytes, nf=2: lib.pm_shape_context_tiled(p(xyz), 64, 0, 64, p(v3), p(v3), p(v1), nf, None, None, p(hist), wsp, nbytes, None)
+    assert call(p(ws), need) == 0
+    assert call(p(ws), need - 1) == -2 and call(None, need) == -2                  # PM_ERR_WORKSPACE
+    assert call(p(ws), need, nf=3) == -1                                            # PM_ERR_INVALID_ARG
+    assert lib.pm_shape_context_workspace(0) == 0 and lib.pm_shape_context_workspace(1) >= 256
+    gpu.t.cuda.synchronize()
