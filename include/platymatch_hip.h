@@ -398,6 +398,21 @@ size_t pm_icp_workspace(int n, int m);
 int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_icp16,
            double *residuals, int32_t *nn_all, int32_t *status1, void *ws, size_t ws_bytes, void *stream);
 
+/* The same loop — same arguments, workspace and results, bit for bit — with iterations 1 .. iters-1 in ONE launch of
+ * persistent workgroups (round 3): a workgroup keeps its points, their matches and the current 4 x 4 in registers / LDS,
+ * the search tables stay warm in L2, and an iteration ends with the reduction tree of pm_icp plus the publication of the
+ * fitted transform through a generation word (no kernel boundary, no reload of the cloud, no gather of the previous matches).
+ * CONTRACT: at most ONE pm_icp_one_launch may be in flight per device — two half-resident persistent grids can starve each
+ * other; callers serialise (the Python mirror holds a per-device lock until the stream has drained).  Ordinary kernels on
+ * other streams may run beside it, but while they hold CUs that workgroups of this grid are waiting for, the resident ones
+ * spin: meant for a device that is otherwise idle (one registration at a time) — a batch of registrations on many streams
+ * should call pm_icp.  If the grid does not fit the device at once (more than 65 536 points), or iters < 3, the call runs
+ * pm_icp's launch-per-iteration path.  A workgroup that has waited 2 s for a round gives up and reports status1 = 2: results
+ * are then undefined and the caller reruns with pm_icp. */
+int pm_icp_one_launch(double *mov, int n, const double *fix, int m, int iters, double *A_icp16,
+                      double *residuals, int32_t *nn_all, int32_t *status1, void *ws, size_t ws_bytes,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

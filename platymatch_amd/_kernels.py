@@ -585,9 +585,22 @@ def get_error(a, b):
     return out
 
 
-def icp(mov, fix, iters, want_nn=False, ws=None, status=None):
+_ICP_LOCKS = {}
+_ICP_LOCKS_GUARD = __import__("threading").Lock()
+
+
+def _icp_lock(device):
+    with _ICP_LOCKS_GUARD:
+        return _ICP_LOCKS.setdefault(device.index, __import__("threading").Lock())
+
+
+def icp(mov, fix, iters, want_nn=False, ws=None, status=None, one_launch=False):
     """Affine ICP loop on the device.  `mov` is updated IN PLACE.
     -> (A_icp [4,4], residuals [iters], nn_all [iters, n] or None).
+    one_launch=False (default): one launch per iteration (pm_icp), nothing awaited.  one_launch=True: iterations 1 .. iters-1
+    in ONE launch of persistent workgroups (pm_icp_one_launch) — identical results, measured slower on MI355X
+    (estimate_transform/perform_icp.py: ONE_LAUNCH); at most one such launch may be in flight per device, so the call holds a
+    per-device lock until its stream has drained (other threads' ordinary kernels overlap as before).
     status: optional int32 GPU tensor [1]: 0, or 1 if some iteration met a (nearly) planar moving cloud — the results are
     then meaningless and the loop must be rerun with pinv fits (estimate_transform.perform_icp does)."""
     torch = _t()
@@ -602,6 +615,12 @@ def icp(mov, fix, iters, want_nn=False, ws=None, status=None):
     A = torch.empty((4, 4), dtype=torch.float64, device=mov.device)
     res = torch.empty(max(iters, 1), dtype=torch.float64, device=mov.device)
     nn_all = torch.empty((max(iters, 1), n), dtype=torch.int32, device=mov.device) if want_nn else None
-    check(lib.pm_icp(ptr(mov), n, ptr(fix), m, iters, ptr(A), ptr(res), ptr(nn_all), ptr(_status(status)), ptr(ws), ws.numel(),
-                     nat.stream_ptr()))
+    if one_launch and iters >= 3:
+        with _icp_lock(mov.device):
+            check(lib.pm_icp_one_launch(ptr(mov), n, ptr(fix), m, iters, ptr(A), ptr(res), ptr(nn_all), ptr(_status(status)), ptr(ws),
+                                        ws.numel(), nat.stream_ptr()))
+            torch.cuda.current_stream(mov.device).synchronize()
+    else:
+        check(lib.pm_icp(ptr(mov), n, ptr(fix), m, iters, ptr(A), ptr(res), ptr(nn_all), ptr(_status(status)), ptr(ws), ws.numel(),
+                         nat.stream_ptr()))
     return A, res[:iters], (nn_all[:iters] if want_nn else None)

@@ -30,6 +30,11 @@ size_t iter_counter_bytes(int n);
 int icp_iteration(bool first, double *mov, int n, const double *fix, int m, const void *grid_ws, const int32_t *nn_prev, int32_t *nn_out,
                   const double *origin6, double *leaf_partial, double *group_partial, unsigned int *counters, double *A_est,
                   double *A_icp, double *res_prev_out, int32_t *status, hipStream_t s);
+// iterations first_it .. iters-1 in ONE launch (persistent workgroups; pm_icp_grid.hip)
+bool icp_loop_fits(int n);
+int icp_loop(double *mov, int n, const double *fix, int m, const void *grid_ws, const int32_t *nn_prev, int32_t *nn_last, int32_t *nn_all,
+             const double *origin6, double *leaf_partial, double *group_partial, unsigned int *counters, double *A_est, double *A_icp,
+             double *residuals, int32_t *status, int first_it, int iters, hipStream_t s);
 
 constexpr int NN_THREADS = 256;
 constexpr int NN_TILE = 128;                   // moving points per wave (two per lane)
@@ -245,8 +250,8 @@ int pm_icp_nn(const double *mov, int n, const double *fix, int m, int32_t *nn, d
 
 size_t pm_icp_workspace(int n, int m) { return (n > 0 && m > 0) ? pm::icp_layout(n, m).total : 0; }
 
-int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_icp16, double *residuals, int32_t *nn_all,
-           int32_t *status1, void *ws, size_t ws_bytes, void *stream) {
+static int icp_run(bool one_launch, double *mov, int n, const double *fix, int m, int iters, double *A_icp16, double *residuals,
+                   int32_t *nn_all, int32_t *status1, void *ws, size_t ws_bytes, void *stream) {
     if (!mov || !fix || !A_icp16 || n <= 0 || m <= 0 || iters < 0) return PM_ERR_INVALID_ARG;
     if (!ws || ws_bytes < pm_icp_workspace(n, m)) return PM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -260,19 +265,42 @@ int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_ic
     if (hipMemsetAsync(counters, 0, pm::iter_counter_bytes(n), s) != hipSuccess) return pm::launch_status();
     int rc = pm::grid_build(fix, m, base + L.grid, s);             // the fixed cloud never changes: bin it once
     if (rc != PM_OK) return rc;
-    // ONE launch per iteration: iteration `it` applies the transform fitted by iteration it-1 on the way in
     const int32_t *nn_prev = nullptr;
-    for (int it = 0; it < iters; ++it) {
-        int32_t *nn = nn_all ? nn_all + (size_t)it * n : nn_buf + (size_t)(it & 1) * n;
-        rc = pm::icp_iteration(it == 0, mov, n, fix, m, base + L.grid, nn_prev, nn, origin, (double *)(base + L.leaf),
-                               (double *)(base + L.group), counters, A_est, A_icp16, (residuals && it > 0) ? residuals + (it - 1) : nullptr,
-                               status1, s);
+    if (one_launch && iters >= 3 && pm::icp_loop_fits(n)) {
+        // iteration 0 has nothing to bound its search with (32 lanes per point walk the rings: a launch of its own); iterations
+        // 1 .. iters-1 run in ONE launch of persistent workgroups
+        int32_t *nn0 = nn_all ? nn_all : nn_buf;
+        rc = pm::icp_iteration(true, mov, n, fix, m, base + L.grid, nullptr, nn0, origin, (double *)(base + L.leaf),
+                               (double *)(base + L.group), counters, A_est, A_icp16, nullptr, status1, s);
         if (rc != PM_OK) return rc;
-        nn_prev = nn;
+        rc = pm::icp_loop(mov, n, fix, m, base + L.grid, nn0, nn_buf + n, nn_all, origin, (double *)(base + L.leaf),
+                          (double *)(base + L.group), counters, A_est, A_icp16, residuals, status1, 1, iters, s);
+        if (rc != PM_OK) return rc;
+        nn_prev = nn_buf + n;
+    } else {
+        // ONE launch per iteration: iteration `it` applies the transform fitted by iteration it-1 on the way in
+        for (int it = 0; it < iters; ++it) {
+            int32_t *nn = nn_all ? nn_all + (size_t)it * n : nn_buf + (size_t)(it & 1) * n;
+            rc = pm::icp_iteration(it == 0, mov, n, fix, m, base + L.grid, nn_prev, nn, origin, (double *)(base + L.leaf),
+                                   (double *)(base + L.group), counters, A_est, A_icp16, (residuals && it > 0) ? residuals + (it - 1) : nullptr,
+                                   status1, s);
+            if (rc != PM_OK) return rc;
+            nn_prev = nn;
+        }
     }
     // the last fitted transform still has to be applied (perform_icp.py:23) and its residual taken (:24)
     return pm::update(nullptr, nullptr, A_est, mov, n, fix, m, nn_prev, nullptr, nullptr, nullptr,
                       residuals ? residuals + (iters - 1) : nullptr, (double *)(base + L.update_ws), nullptr, s);
+}
+
+int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_icp16, double *residuals, int32_t *nn_all,
+           int32_t *status1, void *ws, size_t ws_bytes, void *stream) {
+    return icp_run(false, mov, n, fix, m, iters, A_icp16, residuals, nn_all, status1, ws, ws_bytes, stream);
+}
+
+int pm_icp_one_launch(double *mov, int n, const double *fix, int m, int iters, double *A_icp16, double *residuals, int32_t *nn_all,
+                      int32_t *status1, void *ws, size_t ws_bytes, void *stream) {
+    return icp_run(true, mov, n, fix, m, iters, A_icp16, residuals, nn_all, status1, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

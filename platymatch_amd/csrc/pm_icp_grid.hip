@@ -10,6 +10,7 @@
 // d = fixed - moving), same comparison of ROUNDED square roots, ties to the lowest original index — because every
 // point that could tie or win lies within the explored radius; candidate order does not matter since ties are broken
 // on the stored original index explicitly.  Work per iteration drops from N*M to ~N * (points in ~27 cells).
+#include <algorithm>
 #include "pm_common.h"
 #include "pm_solve.h"
 
@@ -28,7 +29,10 @@ constexpr int GR_BALL_RUNS = 36;          // largest box (in runs of x-adjacent 
 // Lanes per moving point once the previous match bounds the search (a handful of cells): 8, or 4 for large clouds so that
 // all workgroups of a launch are resident at once (measured per iteration at 50k: 16 lanes 43.0 us, 8 -> 30.3, 4 -> 25.8;
 // at 20k 8 -> 19.5, 4 -> 20.6; at 5k 8 -> 14.4, 4 -> 15.5).
-constexpr int GR_ITER_FEW_LANES_FROM = 32768;
+#ifndef PM_GR_FEW_FROM
+#define PM_GR_FEW_FROM 32768
+#endif
+constexpr int GR_ITER_FEW_LANES_FROM = PM_GR_FEW_FROM;
 constexpr int GR_LANES = 32;              // lanes per moving point (measured on the 50k blob: 4 -> 73, 8 -> 67, 16 -> 63, 32 -> 56 us per ICP iteration)
 
 struct GridHeader {          // lives at the start of the workspace, written by grid_plan_kernel
@@ -417,6 +421,7 @@ __global__ __launch_bounds__(256) void grid_nn_kernel(const double *__restrict__
 // "last one out" pattern: a counter per group, no workgroup ever waits for another (nothing can hang).
 constexpr int IT_SLOTS = PM_NMOMENTS + 1;          // 22 moments + residual
 constexpr int IT_STRIDE = 24;
+constexpr int IT_FINAL_CHUNK = 2 * PM_TREE_GROUP;   // group partials the last workgroup fetches in one round trip (128: clouds up to 65 536 points)
 
 struct IterArgs {
     double *mov; int n;
@@ -442,16 +447,27 @@ __device__ __forceinline__ void coherent_store(double *p, double v) {
     __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Diagnostic build only (-DPM_ICP_STAMPS, tools/icp_stamps.py): lane 0 of every workgroup stamps the constant 100 MHz clock at
+// the phase boundaries of the iteration into a buffer no other code reads.  The product build contains none of this.
+#ifdef PM_ICP_STAMPS
+__device__ unsigned long long *g_icp_stamps = nullptr;       // [workgroups][8]
+#define PM_STAMP(k) do { if (g_icp_stamps && threadIdx.x == 0) g_icp_stamps[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PM_STAMP(k) do { } while (0)
+#endif
+
 template <int L, bool FIRST>
 __global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
     constexpr int PTS = 256 / L;                        // moving points per workgroup
     constexpr int LPB = PTS / PM_TREE_LEAF;             // leaves of the reduction tree per workgroup
     static_assert(PTS % PM_TREE_LEAF == 0 && LPB >= 1 && PM_TREE_GROUP % LPB == 0, "a workgroup must hold whole leaves of one group");
     __shared__ double term[PTS][IT_STRIDE];
+    __shared__ double s_stage[IT_FINAL_CHUNK * IT_STRIDE];      // 24 KB: the partials of one level, fetched by all threads at once
     __shared__ double totals[IT_STRIDE + 1];
     __shared__ int s_flag;
     const int tid = threadIdx.x, sub = tid & (L - 1), slot = tid / L;
     const int n = a.n, m = a.m;
+    PM_STAMP(0);
     const int i = blockIdx.x * PTS + slot;
     const int ic = min(i, n - 1);
     const GridHeader hd = *a.hd;
@@ -472,10 +488,18 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
         if (sub == 0 && i < n) { a.mov[i] = p0; a.mov[(size_t)n + i] = p1; a.mov[2 * (size_t)n + i] = p2; }
         if (S0 < INFINITY) { iS = S0; iI = j_prev; iX = f0; iY = f1; iZ = f2; }     // (NaN fails the comparison)
     }
+#ifdef PM_ICP_STAMPS
+    if (__builtin_isnan(S0 + p0)) __builtin_amdgcn_s_sleep(1);      // (forces the loads above to have landed before the stamp)
+#endif
+    PM_STAMP(1);
     GridSearch<L, true> q(hd, a.start, a.pts, p0, p1, p2, sub, iS, iI, iX, iY, iZ);
     bool done = false;
     if (!FIRST && S0 < INFINITY) done = q.ball(res_prev * (1.0 + 0x1p-20) + 0x1p-1000);
     if (!done) q.rings();
+#ifdef PM_ICP_STAMPS
+    if (q.bI == -5) __builtin_amdgcn_s_sleep(1);
+#endif
+    PM_STAMP(2);
     if (sub == 0) {
         double s[PM_NMOMENTS];
         if (i < n) {
@@ -507,6 +531,7 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PM_STAMP(3);
     // ---- last one out: leaves -> group -> total -> solve
     const int g = leaf0 / PM_TREE_GROUP;
     __syncthreads();
@@ -515,40 +540,57 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
         s_flag = (atomicAdd(&a.counters[1 + g], (unsigned int)mine) + (unsigned int)mine == size) ? 1 : 0;
     }
     __syncthreads();
+    PM_STAMP(4);
     if (!s_flag) return;
-    if (tid < IT_SLOTS) {
+    // The workgroup whose add completed group g adds its (up to) 64 leaves in leaf order.  Round 3: ALL 256 threads fetch the
+    // partials — every load of the level in flight at once, ONE memory round trip (these are L1-bypassing loads of lines
+    // other XCDs wrote through: ~0.7 us each; 23 lanes fetching eight at a time took eight round trips here and thirteen
+    // for the 98 groups of a 50 000-point cloud) — into LDS, then 23 lanes add in the fixed order.
+    {
         const int size = min(PM_TREE_GROUP, a.leaves - g * PM_TREE_GROUP);
-        const double *lp = a.leaf_partial + (size_t)g * PM_TREE_GROUP * IT_STRIDE + tid;
-        double acc = 0.0;
-        int b = 0;
-        for (; b + 8 <= size; b += 8) {
-            double v[8];
+        const double *lp = a.leaf_partial + (size_t)g * PM_TREE_GROUP * IT_STRIDE;
+        const int total = size * IT_STRIDE;
+        constexpr int PER = (PM_TREE_GROUP * IT_STRIDE + 255) / 256;       // 6
+        double v[PER];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = coherent_load(lp + (size_t)(b + u) * IT_STRIDE);
+        for (int u = 0; u < PER; ++u) v[u] = coherent_load(lp + min(tid + u * 256, total - 1));
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
+        for (int u = 0; u < PER; ++u)
+            if (tid + u * 256 < total) s_stage[tid + u * 256] = v[u];
+        __syncthreads();
+        if (tid < IT_SLOTS) {
+            double acc = 0.0;
+            for (int b = 0; b < size; ++b) acc += s_stage[b * IT_STRIDE + tid];
+            coherent_store(&a.group_partial[(size_t)g * IT_STRIDE + tid], acc);
         }
-        for (; b < size; ++b) acc += coherent_load(lp + (size_t)b * IT_STRIDE);
-        coherent_store(&a.group_partial[(size_t)g * IT_STRIDE + tid], acc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PM_STAMP(5);
     __syncthreads();
     if (tid == 0) s_flag = (atomicAdd(&a.counters[0], 1u) == (unsigned int)a.groups - 1u) ? 1 : 0;
     __syncthreads();
+    PM_STAMP(6);
     if (!s_flag) return;
-    if (tid < IT_SLOTS) {
-        const double *gp = a.group_partial + tid;
+    // ... and the one that completed the last group adds the groups in group order, 64 at a time through the same staging area
+    {
         double acc = 0.0;
-        int b = 0;
-        for (; b + 8 <= a.groups; b += 8) {
-            double v[8];
+        for (int g0 = 0; g0 < a.groups; g0 += IT_FINAL_CHUNK) {
+            const int size = min(IT_FINAL_CHUNK, a.groups - g0);
+            const double *gp = a.group_partial + (size_t)g0 * IT_STRIDE;
+            const int total = size * IT_STRIDE;
+            constexpr int PER = (IT_FINAL_CHUNK * IT_STRIDE + 255) / 256;  // 12
+            double v[PER];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = coherent_load(gp + (size_t)(b + u) * IT_STRIDE);
+            for (int u = 0; u < PER; ++u) v[u] = coherent_load(gp + min(tid + u * 256, total - 1));
+            __syncthreads();                             // (the previous chunk has been added up)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
+            for (int u = 0; u < PER; ++u)
+                if (tid + u * 256 < total) s_stage[tid + u * 256] = v[u];
+            __syncthreads();
+            if (tid < IT_SLOTS)
+                for (int b = 0; b < size; ++b) acc += s_stage[b * IT_STRIDE + tid];
         }
-        for (; b < a.groups; ++b) acc += coherent_load(gp + (size_t)b * IT_STRIDE);
-        totals[1 + tid] = acc;
+        if (tid < IT_SLOTS) totals[1 + tid] = acc;
     }
     for (int c = tid; c < 1 + a.groups; c += 256)                            // everyone has passed: ready for the next launch
         __hip_atomic_store(&a.counters[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -564,6 +606,239 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
         for (int k = 0; k < 16; ++k) a.A_est[k] = A[k];
         compose_affine(A, a.A_icp);
         if (!FIRST && a.res_prev_out) a.res_prev_out[0] = totals[1 + PM_NMOMENTS] / (double)n;
+    }
+    PM_STAMP(7);
+}
+
+#ifdef PM_ICP_STAMPS
+extern "C" int pm_debug_set_icp_stamps(unsigned long long *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_icp_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+
+// ---- the whole loop in one launch (round 3) -------------------------------------------------------------------------------
+// icp_iter_kernel pays, per iteration, for a kernel boundary (which also empties every XCD's L2: the grid tables and the fixed
+// records come back from the Infinity Cache each time), for reloading the moving points and for gathering the previous
+// matches.  icp_loop_kernel runs iterations first_it .. iters-1 in ONE launch: a workgroup keeps its points, their matches
+// and the current 4 x 4 in registers / LDS for the whole loop, the read-only search tables stay warm in L2, and the only
+// inter-workgroup traffic per iteration is the reduction tree of icp_iter_kernel (same leaves, groups and order: same bits)
+// plus the publication of the fitted transform:
+//   every workgroup   leaf partials (write-through) -> drain -> add `mine` to its group's counter;
+//   last of a group   fetch the group's leaves (all threads, one round trip) -> sum in leaf order -> store -> add to counter 0;
+//   last of all       fetch the groups -> sum in group order -> solve -> A_est, A_icp, residual (write-through) -> drain ->
+//                     generation word = round;
+//   every workgroup   one lane polls the generation word (L1-bypassing load + s_sleep), barrier, all reload A_est (bypassing).
+// Counters are never reset: in round r a group's counter ends at r x (its leaves), counter 0 at r x groups.  The grid must be
+// co-resident (icp_loop_capacity, with a margin of one workgroup per CU) and the caller must not have another such launch
+// in flight on the device (two half-resident persistent grids can starve each other); a wait longer than spin_ticks (2 s) sets
+// status 2 and leaves the loop — every workgroup then does — so the grid always drains.
+#ifndef PM_ICP_POLL_SLEEP
+#define PM_ICP_POLL_SLEEP 16
+#endif
+struct LoopArgs {
+    IterArgs a;
+    int first_it, iters;
+    double *residuals;               // [iters] (may be null): slot it-1 is written by iteration it
+    int32_t *nn_all;                 // [iters][n] (may be null)
+    int32_t *nn_last;                // [n]: the matches of the last iteration (for the trailing update kernel)
+    unsigned int *gen;               // generation word, zero on entry
+    unsigned long long spin_ticks;   // how long a workgroup waits for a round (100 MHz ticks) before it reports status 2 and leaves
+};
+
+// The rare half of a round, kept out of line so that its registers (the staged fetches, the solve) do not weigh on the loop
+// every workgroup runs: called by the workgroup that completed group g; the one that also completes the last group
+// publishes the round.  s_stage / totals / flags: the caller's LDS.
+__device__ __forceinline__ void loop_round_tail(const LoopArgs &la, int g, unsigned int gsize, unsigned int round, int it,
+                                             double *s_stage, double *totals, int *s_last_of_all, double *C_s) {
+    const IterArgs &a = la.a;
+    const int tid = threadIdx.x, n = a.n;
+    {
+            const double *lp = a.leaf_partial + (size_t)g * PM_TREE_GROUP * IT_STRIDE;
+            const int total = (int)gsize * IT_STRIDE;
+            constexpr int PER = (PM_TREE_GROUP * IT_STRIDE + 255) / 256;
+            double v[PER];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) v[u] = coherent_load(lp + min(tid + u * 256, total - 1));
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                if (tid + u * 256 < total) s_stage[tid + u * 256] = v[u];
+            __syncthreads();
+            if (tid < IT_SLOTS) {
+                double acc = 0.0;
+                for (int b = 0; b < (int)gsize; ++b) acc += s_stage[b * IT_STRIDE + tid];
+                coherent_store(&a.group_partial[(size_t)g * IT_STRIDE + tid], acc);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) *s_last_of_all = (atomicAdd(&a.counters[0], 1u) + 1u == (unsigned int)a.groups * round) ? 1 : 0;
+            __syncthreads();
+            if (*s_last_of_all) {                         // ... and the last group: total, solve, publish
+                double acc = 0.0;
+                for (int g0 = 0; g0 < a.groups; g0 += IT_FINAL_CHUNK) {
+                    const int size = min(IT_FINAL_CHUNK, a.groups - g0);
+                    const double *gp = a.group_partial + (size_t)g0 * IT_STRIDE;
+                    const int tot = size * IT_STRIDE;
+                    constexpr int PERF = (IT_FINAL_CHUNK * IT_STRIDE + 255) / 256;
+                    double w[PERF];
+#pragma unroll
+                    for (int u = 0; u < PERF; ++u) w[u] = coherent_load(gp + min(tid + u * 256, tot - 1));
+                    __syncthreads();
+#pragma unroll
+                    for (int u = 0; u < PERF; ++u)
+                        if (tid + u * 256 < tot) s_stage[tid + u * 256] = w[u];
+                    __syncthreads();
+                    if (tid < IT_SLOTS)
+                        for (int b = 0; b < size; ++b) acc += s_stage[b * IT_STRIDE + tid];
+                }
+                if (tid < IT_SLOTS) totals[1 + tid] = acc;
+                // A_icp was composed by another workgroup last round: sixteen lanes fetch it at once (bypassing loads issued one
+                // after the other by a single lane would be sixteen round trips), one lane solves and composes in LDS, sixteen
+                // lanes publish
+                // C_s: [0..16) A_icp, [16..32) A_est — the caller's term table, idle since the leaf sums (s_stage is still being read)
+                if (tid >= 64 && tid < 80) C_s[tid - 64] = coherent_load(&a.A_icp[tid - 64]);
+                __syncthreads();
+                if (tid == 0) {
+                    totals[0] = (double)n;
+                    double sums[PM_ICP_NSUMS];
+                    for (int k = 0; k < PM_ICP_NSUMS - 1; ++k) sums[k] = totals[k];
+                    sums[PM_ICP_NSUMS - 1] = 0.0;
+                    double A[16], C[16];
+                    const double ratio = affine_from_sums(sums, a.origin6, A);
+                    if (a.status && !(ratio > PM_DEGENERATE_MOMENTS)) __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int k = 0; k < 16; ++k) C[k] = C_s[k];
+                    compose_affine(A, C);
+                    for (int k = 0; k < 16; ++k) { C_s[k] = C[k]; C_s[16 + k] = A[k]; }
+                    if (la.residuals) la.residuals[it - 1] = totals[1 + PM_NMOMENTS] / (double)n;
+                }
+                __syncthreads();
+                if (tid < 16) coherent_store(&a.A_icp[tid], C_s[tid]);
+                else if (tid < 32) coherent_store(&a.A_est[tid - 16], C_s[tid]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (wave 0 stored everything: its drain covers the publication)
+                if (tid == 0) __hip_atomic_store(la.gen, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(256, 4) void icp_loop_kernel(const LoopArgs la) {      // 4 workgroups per CU: <= 128 VGPRs
+    constexpr int PTS = 256 / L;
+    constexpr int LPB = PTS / PM_TREE_LEAF;
+    static_assert(PTS % PM_TREE_LEAF == 0 && LPB >= 1 && PM_TREE_GROUP % LPB == 0, "a workgroup must hold whole leaves of one group");
+    __shared__ double term[PTS][IT_STRIDE];
+    __shared__ double s_stage[IT_FINAL_CHUNK * IT_STRIDE];
+    __shared__ double totals[IT_STRIDE + 1];
+    __shared__ double A_s[16];
+    __shared__ int s_last_of_group, s_last_of_all, s_ok;   // three words: each is written once per round, between barriers that
+                                                           // every reader has passed (a shared flag reused across uniform branches would race)
+    const IterArgs &a = la.a;
+    const int tid = threadIdx.x, sub = tid & (L - 1), slot = tid / L;
+    const int n = a.n, m = a.m;
+    const int i = blockIdx.x * PTS + slot;
+    const int ic = min(i, n - 1);
+    const GridHeader hd = *a.hd;
+    double p0 = a.mov[ic], p1 = a.mov[(size_t)n + ic], p2 = a.mov[2 * (size_t)n + ic];
+    // the match of the iteration before this launch: its index, and its coordinates gathered once — afterwards both ride along
+    int jm = a.nn_prev[ic];
+    double m0 = a.fix[jm], m1 = a.fix[(size_t)m + jm], m2 = a.fix[2 * (size_t)m + jm];
+    if (tid < 16) A_s[tid] = a.A_prev[tid];             // fitted by the previous launch (kernel boundary: plain load)
+    const int leaf0 = blockIdx.x * LPB;
+    const int mine = min(LPB, a.leaves - leaf0);
+    const int g = leaf0 / PM_TREE_GROUP;
+    const unsigned int gsize = (unsigned int)min(PM_TREE_GROUP, a.leaves - g * PM_TREE_GROUP);
+    const double o0 = a.origin6[0], o1 = a.origin6[1], o2 = a.origin6[2], o3 = a.origin6[3], o4 = a.origin6[4], o5 = a.origin6[5];
+    __syncthreads();
+    unsigned int round = 0;
+    for (int it = la.first_it; it < la.iters; ++it) {
+        ++round;
+#ifdef PM_ICP_STAMPS
+        const bool stamp_it = it == la.iters - 1;
+#define PM_LSTAMP(k) do { if (stamp_it) PM_STAMP(k); } while (0)
+#else
+#define PM_LSTAMP(k) do { } while (0)
+#endif
+        PM_LSTAMP(0);
+        // apply the transform fitted by the previous iteration (:23) and take the residual against the previous match (:24)
+        {
+            const double x = p0, y = p1, z = p2;
+            p0 = ((A_s[0] * x + A_s[1] * y) + A_s[2] * z) + A_s[3];
+            p1 = ((A_s[4] * x + A_s[5] * y) + A_s[6] * z) + A_s[7];
+            p2 = ((A_s[8] * x + A_s[9] * y) + A_s[10] * z) + A_s[11];
+        }
+        const double e0 = p0 - m0, e1 = p1 - m1, e2 = p2 - m2;
+        const double S0 = (e0 * e0 + e1 * e1) + e2 * e2;
+        const double res_prev = __builtin_sqrt(S0);
+        const bool known = S0 < INFINITY;                // (NaN fails the comparison)
+        GridSearch<L, true> q(hd, a.start, a.pts, p0, p1, p2, sub, known ? S0 : INFINITY, known ? jm : 0x7fffffff,
+                              known ? m0 : 0.0, known ? m1 : 0.0, known ? m2 : 0.0);
+        bool done = false;
+        if (known) done = q.ball(res_prev * (1.0 + 0x1p-20) + 0x1p-1000);
+        if (!done) q.rings();
+#ifdef PM_ICP_STAMPS
+        if (q.bI == -5) __builtin_amdgcn_s_sleep(1);
+#endif
+        PM_LSTAMP(2);
+        const bool none = q.bI == 0x7fffffff;            // all-NaN row: np.argmin answers 0
+        jm = none ? 0 : q.bI;
+        if (none) { m0 = a.fix[0]; m1 = a.fix[(size_t)m]; m2 = a.fix[2 * (size_t)m]; }
+        else { m0 = q.bX; m1 = q.bY; m2 = q.bZ; }
+        if (sub == 0) {
+            double s[PM_NMOMENTS];
+            if (i < n) {
+                if (la.nn_all) la.nn_all[(size_t)it * n + i] = jm;
+                moment_terms(p0 - o0, p1 - o1, p2 - o2, m0 - o3, m1 - o4, m2 - o5, s);
+            } else {
+#pragma unroll
+                for (int k = 0; k < PM_NMOMENTS; ++k) s[k] = 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < PM_NMOMENTS; ++k) term[slot][k] = s[k];
+            term[slot][PM_NMOMENTS] = (i < n) ? res_prev : 0.0;
+        }
+        __syncthreads();
+        if (tid < LPB * IT_SLOTS) {
+            const int lf = tid / IT_SLOTS, k = tid - lf * IT_SLOTS;
+            if (lf < mine) {
+                double acc = 0.0;
+#pragma unroll
+                for (int pnt = 0; pnt < PM_TREE_LEAF; ++pnt) acc += term[lf * PM_TREE_LEAF + pnt][k];
+                coherent_store(&a.leaf_partial[(size_t)(leaf0 + lf) * IT_STRIDE + k], acc);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PM_LSTAMP(3);
+        __syncthreads();
+        if (tid == 0) s_last_of_group = (atomicAdd(&a.counters[1 + g], (unsigned int)mine) + (unsigned int)mine == gsize * round) ? 1 : 0;
+        __syncthreads();
+        PM_LSTAMP(4);
+        if (s_last_of_group) loop_round_tail(la, g, gsize, round, it, s_stage, totals, &s_last_of_all, &term[0][0]);   // this workgroup completed its group
+        if (s_last_of_group) PM_LSTAMP(5);
+        // everyone: wait for this round's transform
+        if (tid == 0) {
+            // (a foreign kernel on another stream may hold CUs that workgroups of this grid are still waiting for: the wait is
+            // bounded by wall-clock time, not by a poll count, and the poll is paced — one L1-bypassing load per ~microsecond)
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            int ok = 1;
+            while (__hip_atomic_load(la.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round) {
+                __builtin_amdgcn_s_sleep(PM_ICP_POLL_SLEEP);
+                if (__builtin_amdgcn_s_memrealtime() - t_start > la.spin_ticks) { ok = 0; break; }
+            }
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (!s_ok) {                                   // the grid was not co-resident after all: report and drain
+            if (tid == 0 && a.status) __hip_atomic_store(a.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        PM_LSTAMP(6);
+        if (tid < 16) A_s[tid] = coherent_load(&a.A_est[tid]);
+        __syncthreads();
+        PM_LSTAMP(7);
+    }
+    // positions after every fit but the last, and the last matches: what the trailing update kernel applies the last fit to
+    if (sub == 0 && i < n) {
+        a.mov[i] = p0; a.mov[(size_t)n + i] = p1; a.mov[2 * (size_t)n + i] = p2;
+        la.nn_last[i] = jm;
     }
 }
 
@@ -603,7 +878,57 @@ int iter_leaves(int n) { return (n + PM_TREE_LEAF - 1) / PM_TREE_LEAF; }
 int iter_groups(int n) { return (iter_leaves(n) + PM_TREE_GROUP - 1) / PM_TREE_GROUP; }
 size_t iter_leaf_bytes(int n) { return (size_t)iter_leaves(n) * IT_STRIDE * sizeof(double); }
 size_t iter_group_bytes(int n) { return (size_t)iter_groups(n) * IT_STRIDE * sizeof(double); }
-size_t iter_counter_bytes(int n) { return (size_t)(1 + iter_groups(n)) * sizeof(unsigned int); }
+size_t iter_gen_offset(int n) { return align_up((size_t)(1 + iter_groups(n)) * sizeof(unsigned int), 1024) + 1024; }   // (bytes from the counters' start)
+size_t iter_counter_bytes(int n) { return iter_gen_offset(n) + 1024; }   // [total | groups...] ... [generation word: on a line no counter shares, so that polls do not queue with the arrival atomics]
+
+// How many workgroups of the loop kernel the device holds at once; 0 if the query fails.  The occupancy query can be one high
+// when the SGPR count is what binds (MI355X_MICROARCH.md, "Residency and cooperative launch": admitted per CU =
+// min(query, 8, floor(800 / (ceil(sgpr/16)*16 + 16)))); at the architectural maximum of SGPRs that bound is 5, so the answer
+// is capped at 5 whatever the compiler allocated (the kernel is built for 4: __launch_bounds__(256, 4) and 37 KB of LDS).
+template <int L>
+static int loop_capacity_of() {
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, icp_loop_kernel<L>, 256, 0) != hipSuccess) return 0;
+    per = std::min(per, 5);
+    return per > 0 ? per * cus : 0;
+}
+
+int icp_loop_lanes(int n) { return n >= GR_ITER_FEW_LANES_FROM ? 4 : 8; }
+
+bool icp_loop_fits(int n) {
+    static thread_local int cap4 = -1, cap8 = -1;        // (one device per calling thread in practice; a query costs microseconds)
+    const int lanes = icp_loop_lanes(n);
+    int &cap = lanes == 4 ? cap4 : cap8;
+    if (cap < 0) cap = lanes == 4 ? loop_capacity_of<4>() : loop_capacity_of<8>();
+    const long blocks = ((long)n * lanes + 255) / 256;
+    return blocks <= cap;
+}
+
+// iterations first_it .. iters-1 in one launch (first_it >= 1: the launch before fitted A_est and left its matches in nn_prev)
+int icp_loop(double *mov, int n, const double *fix, int m, const void *grid_ws, const int32_t *nn_prev, int32_t *nn_last, int32_t *nn_all,
+             const double *origin6, double *leaf_partial, double *group_partial, unsigned int *counters, double *A_est, double *A_icp,
+             double *residuals, int32_t *status, int first_it, int iters, hipStream_t s) {
+    const GridWs Lw = grid_layout(m);
+    const char *base = (const char *)grid_ws;
+    LoopArgs la;
+    IterArgs &a = la.a;
+    a.mov = mov; a.n = n;
+    a.hd = (const GridHeader *)(base + Lw.header); a.start = (const int *)(base + Lw.start); a.pts = (const double4 *)(base + Lw.pts);
+    a.fix = fix; a.m = m;
+    a.nn_prev = nn_prev; a.nn_out = nullptr;
+    a.A_prev = A_est; a.origin6 = origin6;
+    a.leaf_partial = leaf_partial; a.group_partial = group_partial; a.counters = counters;
+    a.A_est = A_est; a.A_icp = A_icp; a.res_prev_out = nullptr; a.status = status;
+    a.leaves = iter_leaves(n); a.groups = iter_groups(n);
+    la.first_it = first_it; la.iters = iters; la.residuals = residuals; la.nn_all = nn_all; la.nn_last = nn_last;
+    la.gen = (unsigned int *)((char *)counters + iter_gen_offset(n));
+    la.spin_ticks = 200000000ull;                        // 2 s: only ever reached if the grid cannot become co-resident in that time
+    if (icp_loop_lanes(n) == 4) icp_loop_kernel<4><<<(n + 63) / 64, 256, 0, s>>>(la);
+    else icp_loop_kernel<8><<<(n + 31) / 32, 256, 0, s>>>(la);
+    return launch_status();
+}
 
 int icp_iteration(bool first, double *mov, int n, const double *fix, int m, const void *grid_ws, const int32_t *nn_prev, int32_t *nn_out,
                   const double *origin6, double *leaf_partial, double *group_partial, unsigned int *counters, double *A_est,

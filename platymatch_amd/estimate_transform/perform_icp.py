@@ -6,6 +6,14 @@ from .. import _native as nat
 from .find_transform import affine_pinv_host, apply_affine_host, similar_transform_host
 
 VERBOSE = True   # the reference prints one residual line per iteration (perform_icp.py:24)
+# Affine loop: one launch per iteration (pm_icp) by default.  ONE_LAUNCH = True runs iterations 1 .. n-1 in ONE launch of
+# persistent workgroups instead (pm_icp_one_launch: points, matches and the 4 x 4 stay in registers / LDS, search tables warm
+# in L2) — identical results, built and measured in round 3 and NOT faster on MI355X: a kernel boundary costs ~1.5 us, the
+# grid-wide hand-off that replaces it (782 workgroups at 50 000 points: arrival counters + a generation word every workgroup
+# polls) costs more, and every memory round trip of the reduction's tail takes about twice as long beside the resident,
+# waiting workgroups (profiles/r03_icp_stamps_*.txt: 24.8 us per iteration against 21.6 at 50 000 points, 13.3 against 11.4 at
+# 5 000).  Kept as an option for devices / drivers where the balance differs.
+ONE_LAUNCH = False
 
 
 def _icp_with_host_fits(m, f, iters, want_nn):
@@ -25,7 +33,7 @@ def _icp_with_host_fits(m, f, iters, want_nn):
     return A_icp.reshape(4, 4), res, (torch.stack(nn_l) if (want_nn and nn_l) else None)
 
 
-def perform_icp(moving, fixed, icp_iterations=50, transform='Affine', log=None):
+def perform_icp(moving, fixed, icp_iterations=50, transform='Affine', log=None, one_launch=None):
     """perform_icp.py:7-26 -> A_icp (4 x 4).
 
     'Affine': the whole loop (nearest neighbours, refit, apply, compose) is enqueued on the
@@ -47,7 +55,13 @@ def perform_icp(moving, fixed, icp_iterations=50, transform='Affine', log=None):
     if transform == 'Affine':
         start = m.clone()
         status = torch.zeros(1, dtype=torch.int32, device=m.device)
-        A, res, nn_all = K.icp(m, f, iters, want_nn=want_nn, status=status)
+        A, res, nn_all = K.icp(m, f, iters, want_nn=want_nn, status=status, one_launch=ONE_LAUNCH if one_launch is None else bool(one_launch))
+        if int(status.item()) == 2:
+            # the persistent launch gave up waiting for its own workgroups: other work held part of the device for seconds
+            # (include/platymatch_hip.h: pm_icp_one_launch's contract).  Same loop, one launch per iteration.
+            m.copy_(start)
+            status.zero_()
+            A, res, nn_all = K.icp(m, f, iters, want_nn=want_nn, status=status, one_launch=False)
         if int(status.item()) != 0 or not bool(torch.isfinite(A).all()):
             # a (nearly) planar moving cloud: the device's normal equations are singular where the reference's pinv
             # (find_transform.py:17) returns the minimum-norm fit.  Rerun with the search and the application on the

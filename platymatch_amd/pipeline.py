@@ -100,9 +100,9 @@ class GpuBackend:
     def apply_affine(self, A, xyz):
         return self.K.apply_affine(A.reshape(16).contiguous(), xyz)
 
-    def icp(self, mov, fix, iters, transform, log):
+    def icp(self, mov, fix, iters, transform, log, one_launch=None):
         from .estimate_transform.perform_icp import perform_icp
-        return perform_icp(mov, fix, iters, transform, log=log)
+        return perform_icp(mov, fix, iters, transform, log=log, one_launch=one_launch)
 
     def icp_grid(self, fix):
         """Bin the fixed cloud once per ICP run; the run owns the grid and hands it to icp_nn (no hidden backend state:
@@ -550,7 +550,7 @@ def _shared_device_seed(group, device):
 def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
                        ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, group=None,
                        backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS, private_rng=False, stream_hypotheses=None,
-                       accept_near_ties=False, sampler='auto'):
+                       accept_near_ties=False, sampler='auto', icp_one_launch=None):
     """Reproduces _dock_widget.py:526-718 -> (A_sc, A_icp, inliers[8]); final transform = A_icp @ A_sc (:428).
 
     moving, fixed   3 x N / 3 x M float64 (rows z, y, x), NumPy or torch
@@ -575,6 +575,9 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     accept_near_ties      for matrices beyond the reach of SciPy's dense algorithm (> 2^30 entries): if a hypothesis has a second
                           assignment within ~1e-11 of the optimal cost, which of the two SciPy's rounding would return cannot be
                           told; False raises, True takes the certified optimum (details['assignment']['routes'] says so)
+    icp_one_launch  None: perform_icp.ONE_LAUNCH decides (default False: one launch per iteration); True: iterations 1 .. n-1 of the
+                    Affine ICP loop in one launch of persistent workgroups (only for a device that does nothing else meanwhile;
+                    estimate_transform_batch always passes False: its workers keep several streams busy) — identical results
     details         optional dict filled with intermediate results (lsa, ransac_A, residuals)
     """
     import time
@@ -667,7 +670,10 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             details['residuals'] = res.cpu().numpy()
     else:
         log = {} if details is not None else None
-        A_icp = be.icp(moved, fix, int(icp_iterations), transform, log)             # :715-717
+        if icp_one_launch is None:
+            A_icp = be.icp(moved, fix, int(icp_iterations), transform, log)         # :715-717
+        else:
+            A_icp = be.icp(moved, fix, int(icp_iterations), transform, log, one_launch=icp_one_launch)
         if details is not None:
             details.update(residuals=log['residuals'], nn=log['nn'])
     t0 = mark("gpu_icp", t0)
@@ -760,6 +766,8 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
             reports[k] = {"routes": det.get("assignment", {}).get("routes"), "mode": det.get("assignment", {}).get("mode")}
         return out
 
+    if on_gpu and workers > 1 and len(ks) > 1 and "icp_one_launch" not in kwargs:
+        kwargs = dict(kwargs, icp_one_launch=False)       # several streams in flight: no persistent grid (perform_icp.ONE_LAUNCH)
     # largest first: the long Hungarian solves start early and the short pairs fill the gaps at the end
     cost = batch_costs([_pair_size(pairs[k]) for k in ks])
     order = [ks[i] for i in sorted(range(len(ks)), key=lambda i: (-cost[i], ks[i]))]

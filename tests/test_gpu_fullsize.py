@@ -99,23 +99,47 @@ def test_fused_icp_is_bit_reproducible_under_concurrent_load(big):
     """The fused iteration hands partial sums between workgroups inside one launch (write-through stores, arrival
     counters, L1-bypassing loads — no fence).  Such hand-offs must be tested under UNEVEN load: the same 40-iteration
     loop is run 12 times while another stream keeps the chip busy with cost-matrix tiles, and every run must reproduce
-    the quiet run bit for bit (a stale partial sum would change the fitted 4x4)."""
+    the quiet run bit for bit (a stale partial sum would change the fitted 4x4).  Both forms of the loop: one launch per
+    iteration (pm_icp), and iterations 1 .. 39 in one launch of persistent workgroups (pm_icp_one_launch) — which, next to a
+    busy stream, may have to wait for CUs and is allowed to give up (status 2, the mirror then reruns launch by launch); when
+    it reports success its bits must be the quiet run's.  The launch geometry spans all eight XCDs (782 workgroups)."""
     K, t = big["K"], big["t"]
     iters = 40
     quiet = big["start"].clone()
-    A0, res0, _ = K.icp(quiet, big["fix"], iters)
+    A0, res0, _ = K.icp(quiet, big["fix"], iters, one_launch=False)
+    q1 = big["start"].clone()
+    A1, res1, _ = K.icp(q1, big["fix"], iters, one_launch=True)
+    assert t.equal(A1, A0) and t.equal(res1, res0) and t.equal(q1, quiet)
+    assert (N + 63) // 64 >= 8 * 32                                    # workgroups on every XCD, several per CU
     hm = K.shape_context(big["mov"], *big["mov_stats"], 2, row0=0, nrows=1024)["hist"]
     hf = K.shape_context(big["fix"], *big["fix_stats"], 4, row0=0, nrows=8192)["hist"]
     noise_stream = t.cuda.Stream()
     out = t.empty((8, 1024, 8192), dtype=t.float64, device=hm.device)
     t.cuda.synchronize()
+    succeeded = 0
     for rep in range(12):
-        with t.cuda.stream(noise_stream):
-            for _ in range(3 + rep % 4):
-                K.chi2_cost8(hm, hf, out=out)                 # ~30 ms of VALU-bound tiles on every CU
-        work = big["start"].clone()
-        A, res, _ = K.icp(work, big["fix"], iters)
-        assert t.equal(A, A0) and t.equal(res, res0) and t.equal(work, quiet), rep
+        for one in (False, True):
+            with t.cuda.stream(noise_stream):
+                for _ in range(3 + rep % 4):
+                    K.chi2_cost8(hm, hf, out=out)                 # VALU-bound tiles on every CU
+            work = big["start"].clone()
+            status = t.zeros(1, dtype=t.int32, device=work.device)
+            A, res, _ = K.icp(work, big["fix"], iters, status=status, one_launch=one)
+            st = int(status.item())
+            assert st == 0 or (one and st == 2), (rep, one, st)
+            if st == 0:
+                assert t.equal(A, A0) and t.equal(res, res0) and t.equal(work, quiet), (rep, one)
+                succeeded += one
+    t.cuda.synchronize()
+    assert succeeded >= 1                                              # (the persistent form did run beside the busy stream)
+    # the mirror hides the difference: perform_icp's result beside a busy stream is the quiet one's
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    with t.cuda.stream(noise_stream):
+        for _ in range(4):
+            K.chi2_cost8(hm, hf, out=out)
+    A = pi.perform_icp(big["start"], big["fix"], iters)
+    assert t.equal(A.reshape(4, 4), A0.reshape(4, 4))
     t.cuda.synchronize()
 
 
