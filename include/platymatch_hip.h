@@ -413,6 +413,27 @@ int pm_icp_one_launch(double *mov, int n, const double *fix, int m, int iters, d
                       double *residuals, int32_t *nn_all, int32_t *status1, void *ws, size_t ws_bytes,
                       void *stream);
 
+/* ---- transform='Similar' ------------------------------------------------------------------------ */
+
+/* The O(N) part of get_similar_transform (find_transform.py:21-99) in NumPy's own arithmetic, so that the 4 x 4 quaternion
+ * matrix the host hands to np.linalg.eig is the reference's, bit for bit (its result hangs on the last bit: the fit takes
+ * ROW 0 of the eigenvector matrix, :60-66).  Pairs are (mov[:, i], fix[:, nn[i]]), or (mov[:, i], fix[:, i]) if nn is NULL.
+ *   out17 = { com_source[3] (:28), com_target[3] (:27), Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz (:43-53), D, Sp (:86-91) }
+ *   mov_sequential / fix_sequential: how np.mean adds that cloud up — 0: a C-ordered 3 x N array (rows contiguous: NumPy's
+ *   chunked pairwise sum, csrc/pm_pairwise.h), 1: a Fortran-ordered one (what fancy indexing makes of fixed[:, nn]: the
+ *   columns are added one after the other).  The nine sums are always pairwise (np.sum of fresh product vectors); D and Sp
+ *   are serial, their 3-vector dot products fused as BLAS ddot's x86 kernels fuse them.
+ * workspace: pm_similar_workspace(n) bytes, 256-byte aligned.  Everything is enqueued on `stream`; nothing is awaited. */
+size_t pm_similar_workspace(int n);
+int pm_similar_moments(const double *mov, int n, const double *fix, int m, const int32_t *nn, int mov_sequential,
+                       int fix_sequential, double *out17, void *ws, size_t ws_bytes, void *stream);
+
+/* mov <- (A . [mov; 1])[:3] in place as np.matmul computes it (apply_transform.py:14-17: BLAS dgemm, fused multiply-adds over
+ * k = 0 .. 3 starting from zero); if residual1 != NULL also np.mean(np.linalg.norm(mov - fix[:, nn], axis=0)) (get_error,
+ * utils.py:77-88) of the moved cloud.  A16: sixteen float64 on the device, row-major.  ws is needed only for the residual. */
+int pm_similar_apply(const double *A16, double *mov, int n, const double *fix, int m, const int32_t *nn,
+                     double *residual1, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -624,3 +624,50 @@ def icp(mov, fix, iters, want_nn=False, ws=None, status=None, one_launch=False):
         check(lib.pm_icp(ptr(mov), n, ptr(fix), m, iters, ptr(A), ptr(res), ptr(nn_all), ptr(_status(status)), ptr(ws), ws.numel(),
                          nat.stream_ptr()))
     return A, res[:iters], (nn_all[:iters] if want_nn else None)
+
+
+def similar_moments(mov, fix, nn=None, mov_sequential=False, fix_sequential=True, ws=None):
+    """The seventeen O(N) numbers of get_similar_transform in NumPy's arithmetic (pm_similar_moments) -> float64 GPU tensor [17]:
+    com_source[3], com_target[3], Sxx .. Szz [9], D, Sp.  Pairs (mov[:, i], fix[:, nn[i]]) (nn None: one to one)."""
+    torch = _t()
+    mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
+    n, m = mov.shape[1], fix.shape[1]
+    if nn is None:
+        if n != m:
+            raise ValueError("moving and fixed must pair up one to one")
+    else:
+        nn = _idx(nn, n, m, "nn")
+    lib = nat.load()
+    need = lib.pm_similar_workspace(n)
+    if ws is None or ws.numel() < need:
+        ws = nat.workspace(need, mov.device)
+    out = torch.empty(17, dtype=torch.float64, device=mov.device)
+    check(lib.pm_similar_moments(ptr(mov), n, ptr(fix), m, ptr(nn), int(bool(mov_sequential)), int(bool(fix_sequential)), ptr(out),
+                                 ptr(ws), ws.numel(), nat.stream_ptr()))
+    return out
+
+
+def similar_apply(A, mov, fix=None, nn=None, want_residual=True, ws=None):
+    """mov <- (A . [mov; 1])[:3] IN PLACE as np.matmul rounds it; -> np.mean(np.linalg.norm(mov - fix[:, nn], axis=0)) as a GPU
+    tensor [1] (None if not wanted): pm_similar_apply."""
+    torch = _t()
+    mov = _cloud(mov, "moving")
+    A = _vec(A, 16, "A")
+    n = mov.shape[1]
+    res = None
+    lib = nat.load()
+    if want_residual:
+        fix = _cloud(fix, "fixed")
+        if nn is None:
+            if fix.shape[1] != n:
+                raise ValueError("moving and fixed must pair up one to one")
+        else:
+            nn = _idx(nn, n, fix.shape[1], "nn")
+        need = lib.pm_similar_workspace(n)
+        if ws is None or ws.numel() < need:
+            ws = nat.workspace(need, mov.device)
+        res = torch.empty(1, dtype=torch.float64, device=mov.device)
+    check(lib.pm_similar_apply(ptr(A), ptr(mov), n, ptr(fix) if want_residual else None, fix.shape[1] if want_residual else 0,
+                               ptr(nn) if want_residual else None, ptr(res), ptr(ws) if want_residual else None,
+                               ws.numel() if want_residual else 0, nat.stream_ptr()))
+    return res

@@ -104,6 +104,10 @@ SIGNATURES = {
     "pm_icp_workspace": (_c_size_t, [_c_int, _c_int]),
     "pm_icp": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                         _c_size_t, _c_void_p]),
+    "pm_similar_workspace": (_c_size_t, [_c_int]),
+    "pm_similar_moments": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_size_t,
+                                    _c_void_p]),
+    "pm_similar_apply": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_icp_one_launch": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                    _c_size_t, _c_void_p]),
 }

@@ -187,6 +187,43 @@ def similar_transform_host(moving, fixed):
     return A
 
 
+def similar_from_moments(v):
+    """find_transform.py:55-99 from the seventeen numbers the device computed in NumPy's arithmetic (K.similar_moments:
+    com_source, com_target, the nine sums, D, Sp): the 4 x 4 quaternion matrix, np.linalg.eig, row 0 of the sorted
+    eigenvector matrix, R, s, t — the reference's own NumPy calls on bit-identical input, hence its own result.
+    Only these lines of get_similar_transform run on the host (the eigenvector-row quirk forces LAPACK: DESIGN.md §2)."""
+    v = np.asarray(v, dtype=np.float64)
+    cs, ct = v[0:3].reshape(3, 1), v[3:6].reshape(3, 1)
+    Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz = (v[k] for k in range(6, 15))
+    N = [[Sxx + Syy + Szz, Syz - Szy, -Sxz + Szx, Sxy - Syx],
+         [-Szy + Syz, Sxx - Szz - Syy, Sxy + Syx, Sxz + Szx],
+         [Szx - Sxz, Syx + Sxy, Syy - Szz - Sxx, Syz + Szy],
+         [-Syx + Sxy, Szx + Sxz, Szy + Syz, Szz - Syy - Sxx]]
+    w, V = np.linalg.eig(N)
+    V = V[:, w.argsort()[::-1]]
+    q0, q1, q2, q3 = V[0]                                      # row 0, as the reference has it
+    Qbar = [[q0, -q1, -q2, -q3], [q1, q0, q3, -q2], [q2, -q3, q0, q1], [q3, q2, -q1, q0]]
+    Q = [[q0, -q1, -q2, -q3], [q1, q0, -q3, q2], [q2, q3, q0, -q1], [q3, -q2, q1, q0]]
+    R = np.matmul(np.transpose(Qbar), Q)[1:, 1:]
+    sc = np.sqrt(v[15] / v[16])
+    t = ct - sc * np.matmul(R, cs)
+    A = np.zeros((4, 4))
+    A[:3, :3] = sc * R
+    A[:3, 3:4] = t
+    A[3, 3] = 1
+    return A
+
+
+def quaternion_matrix_from_moments(v):
+    """The 4 x 4 matrix N of find_transform.py:55-58 alone (tests compare it with the oracle's bit for bit)."""
+    v = np.asarray(v, dtype=np.float64)
+    Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz = (v[k] for k in range(6, 15))
+    return np.array([[Sxx + Syy + Szz, Syz - Szy, -Sxz + Szx, Sxy - Syx],
+                     [-Szy + Syz, Sxx - Szz - Syy, Sxy + Syx, Sxz + Szx],
+                     [Szx - Sxz, Syx + Sxy, Syy - Szz - Sxx, Syz + Szy],
+                     [-Syx + Sxy, Szx + Sxz, Szy + Syz, Szz - Syy - Sxx]])
+
+
 def apply_affine_host(moving, A):
     """apply_transform.py:3-17 on host arrays with the reference's own calls (vstack + np.matmul): the Similar-mode
     chain needs the moved cloud to the bit (see similar_transform_host)."""

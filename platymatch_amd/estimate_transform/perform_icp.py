@@ -3,7 +3,7 @@ import numpy as np
 
 from .. import _kernels as K
 from .. import _native as nat
-from .find_transform import affine_pinv_host, apply_affine_host, similar_transform_host
+from .find_transform import affine_pinv_host, similar_from_moments
 
 VERBOSE = True   # the reference prints one residual line per iteration (perform_icp.py:24)
 # Affine loop: one launch per iteration (pm_icp) by default.  ONE_LAUNCH = True runs iterations 1 .. n-1 in ONE launch of
@@ -40,9 +40,11 @@ def perform_icp(moving, fixed, icp_iterations=50, transform='Affine', log=None, 
     device in one call with no host synchronisation until the result is read; if the moving cloud turns out
     (nearly) planar — where the reference's pinv gives a minimum-norm fit the normal equations cannot — the loop is
     rerun with pinv fits on the host (_icp_with_host_fits).
-    'Similar': the nearest-neighbour search of every iteration runs on the device; the fit, the application and the
-    composition are the reference's own NumPy calls on the host (find_transform.similar_transform_host explains why
-    this mode can only be reproduced that way).
+    'Similar': everything O(N) of an iteration runs on the device in NumPy's own arithmetic — nearest neighbours, the two
+    centroids, the nine product sums, D and Sp (K.similar_moments), the application of the fit and the residual
+    (K.similar_apply); the host receives seventeen numbers per iteration and runs the reference's own NumPy lines on them for
+    the 4 x 4 eigen-decomposition and what follows (find_transform.similar_from_moments; similar_transform_host explains why
+    that part can only be reproduced by NumPy/LAPACK itself).
     `log`, if a dict, receives 'nn' [iters, N] int32, 'residuals' [iters] and 'moved' [3, N]."""
     torch = nat.torch_mod()
     m, f = nat.to_dev(moving), nat.to_dev(fixed)
@@ -69,26 +71,32 @@ def perform_icp(moving, fixed, icp_iterations=50, transform='Affine', log=None, 
             m = start
             A, res, nn_all = _icp_with_host_fits(m, f, iters, want_nn)
     elif transform == 'Similar':
-        # host copies in the layout the caller gave (np.mean's summation order follows the memory layout)
-        mh = moving.detach().cpu().numpy() if nat.is_torch(moving) else np.asarray(moving, dtype=np.float64)
-        fh = fixed.detach().cpu().numpy() if nat.is_torch(fixed) else np.asarray(fixed, dtype=np.float64)
-        mh, fh = mh[:3, :], fh[:3, :]
+        # Per iteration: nearest neighbours (device); the seventeen O(N) numbers of get_similar_transform in NumPy's own
+        # arithmetic (device: K.similar_moments -> 136 bytes to the host); the 4 x 4 eigen-decomposition and what follows it
+        # with the reference's own NumPy calls (host: similar_from_moments); application and residual as NumPy rounds them
+        # (device: K.similar_apply).  No cloud crosses PCIe inside the loop.
+        # np.mean adds a cloud up in the order its memory layout dictates: the caller's moving array decides for the first
+        # iteration (afterwards it is np.matmul's C-ordered result), the matches fixed[:, nn] are always Fortran-ordered.
+        first_sequential = False
+        if not nat.is_torch(moving):
+            mh0 = np.asarray(moving)
+            first_sequential = bool(mh0.flags["F_CONTIGUOUS"] and not mh0.flags["C_CONTIGUOUS"])
         A_h = np.identity(4)
         grid = K.icp_grid(f) if iters else None
+        ws = None
+        if iters:
+            lib = nat.load()
+            ws = nat.workspace(lib.pm_similar_workspace(m.shape[1]), m.device)
         res_l, nn_l = [], []
         for it in range(iters):
-            nn = K.icp_nn(m, f, want_dist=False, grid=grid)[0]
-            i2 = nn.cpu().numpy()
-            matched = fh[:, i2]                                  # perform_icp.py:20 (fancy index: column-ordered copy)
-            A_est = similar_transform_host(mh, matched)
-            mh = apply_affine_host(mh, A_est)                    # :23
-            res_l.append(np.mean(np.linalg.norm(mh - matched, axis=0)))      # get_error, utils.py:77-88
-            A_h = np.matmul(A_est, A_h)                          # :25
+            nn = K.icp_nn(m, f, want_dist=False, grid=grid)[0]               # perform_icp.py:15-16
+            v = K.similar_moments(m, f, nn, mov_sequential=(it == 0 and first_sequential), fix_sequential=True, ws=ws)
+            A_est = similar_from_moments(v.cpu().numpy())                     # :20 (the fit)
+            res_l.append(K.similar_apply(nat.to_dev(A_est, dev=m.device).reshape(16), m, f, nn, ws=ws))   # :23, :24 (get_error)
+            A_h = np.matmul(A_est, A_h)                                       # :25
             nn_l.append(nn)
-            if it + 1 < iters or log is not None:
-                m = nat.to_dev(np.ascontiguousarray(mh), dev=f.device)
         A = torch.as_tensor(A_h, device=f.device)
-        res = torch.as_tensor(np.asarray(res_l, dtype=np.float64), device=f.device)
+        res = torch.cat(res_l) if res_l else torch.empty(0, dtype=torch.float64, device=f.device)
         nn_all = torch.stack(nn_l) if (want_nn and nn_l) else None
     else:
         raise ValueError("transform must be 'Affine' or 'Similar'")
