@@ -116,11 +116,17 @@ int pm_shape_context(const double *xyz, int n, int row0, int nrows, const double
  * histogram per row is kept (frame 1) and frames 2..4 are written as its phi permutations.  Tiles holding a neighbour for
  * which that permutation does not hold exactly (on a sector edge or pole of the frame) are recomputed by pm_shape_context's
  * kernel inside the same call.  Outputs are identical to pm_shape_context's in every case.
- * workspace: pm_shape_context_workspace(nrows) bytes, 256-byte aligned (frames, thresholds, per-tile flags). */
+ *   edge_guard2  (device, may be NULL) two uint32 counters of (point, neighbour) pairs whose bin depends on the cloud statistics
+ *                beyond the accuracy they are known to: [0] distance within 4e-14 (relative) of a ring radius — the mean
+ *                pairwise distance agrees with the reference's to 1e-14 —, [1] azimuth within 1e-12 / sin(angle(axis, z)) of a
+ *                sector edge — the PCA axis agrees to 1e-12.  Zero for generic data: "the reference's histograms" then holds by
+ *                construction for this call, not only by the fixtures.
+ * workspace: pm_shape_context_workspace(nrows) bytes, 256-byte aligned (frames, thresholds, per-tile flags, counts). */
 size_t pm_shape_context_workspace(int nrows);
 int pm_shape_context_tiled(const double *xyz, int n, int row0, int nrows, const double *centroid3,
                            const double *x0_3, const double *mean_dist1, int n_frames, int32_t *counts,
-                           int32_t *totals, double *hist, void *workspace, size_t workspace_bytes, void *stream);
+                           int32_t *totals, double *hist, uint32_t *edge_guard2, void *workspace, size_t workspace_bytes,
+                           void *stream);
 
 /* get_shape_context (shape_context.py:10-42) on an explicit neighbour list already expressed in the
  * local frame: nb is n x 3 row-major (x_, y_, z_ per row, as the reference passes it); counts[360]

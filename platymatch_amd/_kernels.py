@@ -178,7 +178,9 @@ def label_moments(labels, n_labels=None):
 
 
 def shape_context(xyz, centroid3, x0_3, mean_dist1, n_frames, row0=0, nrows=None, want_counts=False, want_hist=True, path="tiled"):
-    """-> dict(hist=[F, nrows, 360] float64, counts=[F, nrows, 360] int32, totals=[F, nrows] int32).
+    """-> dict(hist=[F, nrows, 360] float64, counts=[F, nrows, 360] int32, totals=[F, nrows] int32, guard=int32 GPU [2] or None).
+    guard (tiled path): how many (point, neighbour) pairs sit so close to a ring radius / a sector edge that the tested agreement of
+    the mean distance (1e-14) / the PCA axis (1e-12) with the reference's does not settle their bin (include/platymatch_hip.h).
     path: "tiled" (default: pm_shape_context_tiled) or "general" (pm_shape_context, one workgroup per point: the kernel the
     tiled call itself falls back to for tiles with neighbours on a sector edge) — identical outputs."""
     torch = _t()
@@ -196,16 +198,18 @@ def shape_context(xyz, centroid3, x0_3, mean_dist1, n_frames, row0=0, nrows=None
     if not (want_hist or want_counts):
         raise ValueError("nothing requested")
     lib = nat.load()
+    guard = None
     if path == "general":
         check(lib.pm_shape_context(ptr(xyz), n, row0, nrows, ptr(c), ptr(a), ptr(md), n_frames, ptr(counts), ptr(totals),
                                    ptr(hist), nat.stream_ptr()))
     elif path == "tiled":
         ws = nat.workspace(lib.pm_shape_context_workspace(nrows), xyz.device)
+        guard = torch.zeros(2, dtype=torch.int32, device=xyz.device)
         check(lib.pm_shape_context_tiled(ptr(xyz), n, row0, nrows, ptr(c), ptr(a), ptr(md), n_frames, ptr(counts), ptr(totals),
-                                         ptr(hist), ptr(ws), ws.numel(), nat.stream_ptr()))
+                                         ptr(hist), ptr(guard), ptr(ws), ws.numel(), nat.stream_ptr()))
     else:
         raise ValueError("path must be 'tiled' or 'general'")
-    return {"hist": hist, "counts": counts, "totals": totals}
+    return {"hist": hist, "counts": counts, "totals": totals, "guard": guard}
 
 
 def shape_context_neighbors(nb, mean_dist):

@@ -55,8 +55,11 @@ class GpuBackend:
     def centroid_and_axis(self, xyz):
         return self.K.centroid(xyz), self.K.pca_axis(xyz)
 
-    def shape_context(self, xyz, c, md, x0, nf, row0, nrows):
-        return self.K.shape_context(xyz, c, x0, md, nf, row0=row0, nrows=nrows)["hist"]
+    def shape_context(self, xyz, c, md, x0, nf, row0, nrows, guards=None):
+        r = self.K.shape_context(xyz, c, x0, md, nf, row0=row0, nrows=nrows)
+        if guards is not None:
+            guards.append(r["guard"])         # int32 GPU [2]: neighbours too close to a ring radius / sector edge (edge guard)
+        return r["hist"]
 
     def symmetry_flag(self, sc_m, sc_f):
         return self.K.chi2_symmetry_flag(sc_m, sc_f)
@@ -223,9 +226,10 @@ def gather_fixed_descriptors(be, sc_m_loc, sc_f_loc, bounds, group=None):
     return all_gather_rows(sc_f_loc, bounds, 1, group)
 
 
-def build_descriptors(be, mov, fix, group=None):
+def build_descriptors(be, mov, fix, group=None, guards=None):
     """Stages 526-545 of the widget: statistics and get_unary for both clouds.
-    -> (sc_m [2, rows_g, 360], sc_f [4, M, 360] complete (or [1, M, 360], see gather_fixed_descriptors), moving row bounds)."""
+    -> (sc_m [2, rows_g, 360], sc_f [4, M, 360] complete (or [1, M, 360], see gather_fixed_descriptors), moving row bounds).
+    guards (optional list): receives the edge-guard counters of the two launches (this rank's rows), moving first."""
     rank, world = _world(group)
     n, m = mov.shape[1], fix.shape[1]
     if world > min(n, m):        # every rank sees the same clouds: all raise, before the first collective
@@ -233,8 +237,12 @@ def build_descriptors(be, mov, fix, group=None):
     cm, mdm, x0m = cloud_statistics(be, mov, group)
     cf, mdf, x0f = cloud_statistics(be, fix, group)
     bn, bm = shard_bounds(n, world), shard_bounds(m, world)
-    sc_m = be.shape_context(mov, cm, mdm, x0m, 2, bn[rank], bn[rank + 1] - bn[rank])
-    sc_f_loc = be.shape_context(fix, cf, mdf, x0f, 4, bm[rank], bm[rank + 1] - bm[rank])
+    if guards is not None and getattr(be, "device_sampler", False):       # (the GPU backend; test doubles have no guard)
+        sc_m = be.shape_context(mov, cm, mdm, x0m, 2, bn[rank], bn[rank + 1] - bn[rank], guards=guards)
+        sc_f_loc = be.shape_context(fix, cf, mdf, x0f, 4, bm[rank], bm[rank + 1] - bm[rank], guards=guards)
+    else:
+        sc_m = be.shape_context(mov, cm, mdm, x0m, 2, bn[rank], bn[rank + 1] - bn[rank])
+        sc_f_loc = be.shape_context(fix, cf, mdf, x0f, 4, bm[rank], bm[rank + 1] - bm[rank])
     sc_f = gather_fixed_descriptors(be, sc_m, sc_f_loc, bm, group)
     return sc_m, sc_f, bn
 
@@ -578,7 +586,8 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     icp_one_launch  None: perform_icp.ONE_LAUNCH decides (default False: one launch per iteration); True: iterations 1 .. n-1 of the
                     Affine ICP loop in one launch of persistent workgroups (only for a device that does nothing else meanwhile;
                     estimate_transform_batch always passes False: its workers keep several streams busy) — identical results
-    details         optional dict filled with intermediate results (lsa, ransac_A, residuals)
+    details         optional dict filled with intermediate results (lsa, ransac_A, residuals, edge_guard: how many neighbours lie so
+                    close to a ring radius or sector edge that the tested accuracy of the cloud statistics does not settle their bin)
     """
     import time
     import torch
@@ -607,7 +616,8 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                              seed, private_rng)
         a_info = None if details is None else details.setdefault("assignment", {})
         try:
-            sc_m, sc_f, bn = build_descriptors(be, mov, fix, group)
+            guards = [] if details is not None else None
+            sc_m, sc_f, bn = build_descriptors(be, mov, fix, group, guards=guards)
             # all eight matrices at once when they fit (four assignments then run side by side); otherwise two at a time
             need = cost_bytes(sc_m.shape[1], mov.shape[1], sc_f.shape[1], world)
             if stream_hypotheses is not None:
@@ -651,6 +661,11 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         t0 = mark("gpu_ransac", t0)
         if details is not None:
             details.update(lsa=lsa, ransac_A=torch.stack(A_h).cpu().numpy())
+            if guards:
+                # neighbours (of this rank's rows) whose bin the tested accuracy of the mean distance / PCA axis does not settle:
+                # 0 everywhere = the integer histograms are the reference's by construction for this call
+                gm, gf = (g.cpu().numpy() for g in guards[:2])
+                details["edge_guard"] = {"moving": {"ring": int(gm[0]), "sector": int(gm[1])}, "fixed": {"ring": int(gf[0]), "sector": int(gf[1])}}
     elif mode == 'supervised':
         if keypoints is None:
             raise ValueError("supervised mode needs keypoints=(moving_keypoints, fixed_keypoints)")

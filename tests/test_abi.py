@@ -80,9 +80,9 @@ def test_every_entry_point_rejects_bad_arguments_before_touching_the_device(lib_
     assert lib.pm_chi2_sym_workspace_bytes(10, 20) == 512 + 3600 + 7200
     assert lib.pm_shape_context(fake, 10, 8, 5, fake, fake, fake, 4, fake, None, None, None) == -1     # row block outside the cloud
     assert lib.pm_shape_context(fake, 10, 0, 5, fake, fake, fake, 3, fake, None, None, None) == -1     # 3 frames do not exist
-    assert lib.pm_shape_context_tiled(fake, 10, 0, 5, fake, fake, fake, 4, fake, None, None, None, 0, None) == -2   # workspace missing
-    assert lib.pm_shape_context_tiled(fake, 10, 0, 5, fake, fake, fake, 4, fake, None, None, fake, 16, None) == -2   # ... or too small
-    assert lib.pm_shape_context_tiled(fake, 10, 8, 5, fake, fake, fake, 4, fake, None, None, fake, 1 << 20, None) == -1
+    assert lib.pm_shape_context_tiled(fake, 10, 0, 5, fake, fake, fake, 4, fake, None, None, None, None, 0, None) == -2   # workspace missing
+    assert lib.pm_shape_context_tiled(fake, 10, 0, 5, fake, fake, fake, 4, fake, None, None, None, fake, 16, None) == -2   # ... or too small
+    assert lib.pm_shape_context_tiled(fake, 10, 8, 5, fake, fake, fake, 4, fake, None, None, None, fake, 1 << 20, None) == -1
     assert lib.pm_ransac_draw(10, 11, 5, 1, 0, fake, None) == -1                                      # more samples than pairs
     assert lib.pm_ransac_affine_draw(fake, 10, fake, 10, None, None, 10, 3, 5, 1, 0, 1.0, fake, fake, fake, None, None) == -4
     assert lib.pm_chi2_cost(fake, 4, fake, 4, fake, 3, None) == -1                                     # ld < columns

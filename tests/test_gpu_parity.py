@@ -49,10 +49,12 @@ def test_statistics(gpu, oracle, name):
         x = gpu.d(d[key])
         c, md, x0 = gpu.K.centroid(x), gpu.K.mean_distance(x), gpu.K.pca_axis(x)
         assert relerr(c.cpu().numpy(), oracle.get_centroid(d[key], transposed=False).ravel()) < 1e-14
-        assert abs(md.item() / oracle.get_mean_distance(d[key], transposed=False) - 1) < 1e-13
-        assert np.abs(x0.cpu().numpy() - oracle.pca_axis(d[key].T)).max() < 1e-11
-    assert abs(gpu.K.mean_distance(gpu.d(d["moving"])).item() / d["mean_dist_m"] - 1) < 1e-13   # vs the reference itself
-    assert np.abs(gpu.K.pca_axis(gpu.d(d["fixed"])).cpu().numpy() - d["x0_f"]).max() < 1e-11
+        assert abs(md.item() / oracle.get_mean_distance(d[key], transposed=False) - 1) < 1e-14   # (observed: <= 4e-16; the edge guard assumes 4e-14)
+        assert np.abs(x0.cpu().numpy() - oracle.pca_axis(d[key].T)).max() < 1e-12                # (observed: <= 9e-14; the edge guard assumes 1e-12)
+    assert abs(gpu.K.mean_distance(gpu.d(d["moving"])).item() / d["mean_dist_m"] - 1) < 1e-14   # vs the reference itself
+    assert abs(gpu.K.mean_distance(gpu.d(d["fixed"])).item() / d["mean_dist_f"] - 1) < 1e-14
+    assert np.abs(gpu.K.pca_axis(gpu.d(d["fixed"])).cpu().numpy() - d["x0_f"]).max() < 1e-12
+    assert np.abs(gpu.K.pca_axis(gpu.d(d["moving"])).cpu().numpy() - d["x0_m"]).max() < 1e-12
 
 
 def test_mean_distance_shared_out_over_ranks_is_bit_identical(gpu):
@@ -79,7 +81,7 @@ def test_statistics_ragged_sizes(gpu, oracle):
         mv, _, _ = synth_pair(n, n)
         x = gpu.d(mv)
         assert relerr(gpu.K.centroid(x).cpu().numpy(), mv.mean(1)) < 1e-14
-        assert abs(gpu.K.mean_distance(x).item() / oracle.get_mean_distance(mv, transposed=False) - 1) < 1e-13
+        assert abs(gpu.K.mean_distance(x).item() / oracle.get_mean_distance(mv, transposed=False) - 1) < 1e-14
 
 
 # ------------------------------------------------------------------------------------------------ shape context
@@ -908,9 +910,51 @@ def test_tile_kernel_argument_errors(gpu):
     need = lib.pm_shape_context_workspace(64)
     ws = gpu.nat.workspace(need, gpu.dev)
     p = gpu.nat.ptr
-    call = lambda wsp, nbytes, nf=2: lib.pm_shape_context_tiled(p(xyz), 64, 0, 64, p(v3), p(v3), p(v1), nf, None, None, p(hist), wsp, nbytes, None)
+    call = lambda wsp, nbytes, nf=2: lib.pm_shape_context_tiled(p(xyz), 64, 0, 64, p(v3), p(v3), p(v1), nf, None, None, p(hist), None, wsp, nbytes, None)
     assert call(p(ws), need) == 0
     assert call(p(ws), need - 1) == -2 and call(None, need) == -2                  # PM_ERR_WORKSPACE
     assert call(p(ws), need, nf=3) == -1                                            # PM_ERR_INVALID_ARG
     assert lib.pm_shape_context_workspace(0) == 0 and lib.pm_shape_context_workspace(1) >= 256
     gpu.t.cuda.synchronize()
+
+
+def test_edge_guard_is_zero_on_every_fixture_and_counts_constructed_cases(gpu, oracle):
+    """The two inputs of the exactness chain that agree with the reference 'by test' (mean distance 1e-14, PCA axis 1e-12: test_statistics) can only
+    change a neighbour's bin if it lies that close to a ring radius / sector edge: the tile kernel counts such neighbours per
+    launch.  Zero on all reference fixtures and on the 50 000-point bench cloud; non-zero where a neighbour is placed there."""
+    import bench
+    for name in SCENARIOS:
+        d = load_golden(name)
+        for cloud, c, md, x0, nf in ((d["moving"], d["centroid_m"], float(d["mean_dist_m"]), d["x0_m"], 2),
+                                     (d["fixed"], d["centroid_f"], float(d["mean_dist_f"]), d["x0_f"], 4)):
+            r = gpu.K.shape_context(gpu.d(np.ascontiguousarray(cloud[:3])), gpu.d(np.asarray(c).reshape(3)), gpu.d(np.asarray(x0).reshape(3)),
+                                    gpu.d(np.array([md])), nf)
+            assert r["guard"].cpu().tolist() == [0, 0], (name, nf)
+    mv, fx, _ = bench.synth(50000)
+    for cloud, nf in ((mv, 2), (fx, 4)):
+        xyz = gpu.d(cloud)
+        c, x0, md = gpu.K.centroid(xyz), gpu.K.pca_axis(xyz), gpu.K.mean_distance(xyz)
+        assert gpu.K.shape_context(xyz, c, x0, md, nf)["guard"].cpu().tolist() == [0, 0]
+    # constructed: point 1 at exactly md / 4 from point 0 (ring radius 1); point 2 on the x axis of point 0's frame (sector edge)
+    rng = np.random.default_rng(0)
+    cloud = rng.normal(size=(3, 200)) * 30 + 100
+    c = np.zeros(3)
+    x0 = np.array([0.0, 0.0, 1.0])
+    md = 40.0
+    p0 = cloud[:, 0]
+    z = p0 / np.linalg.norm(p0)
+    x = x0 - z * (x0 @ z)
+    x /= np.linalg.norm(x)
+    u = rng.normal(size=3)
+    u /= np.linalg.norm(u)
+    cloud[:, 1] = p0 + u * (md * 0.25000000000000006)                 # np.logspace's second edge times md
+    cloud[:, 2] = p0 + 7.0 * x + 3.0 * z                               # azimuth 0 in point 0's frame: on a sector edge
+    r = gpu.K.shape_context(gpu.d(np.ascontiguousarray(cloud)), gpu.d(c), gpu.d(x0), gpu.d(np.array([md])), 4)
+    ring, sector = r["guard"].cpu().tolist()
+    assert ring >= 1 and sector >= 1
+    # ... and the driver reports it
+    from platymatch_amd import pipeline as P
+    d = load_golden("synth128")
+    det = {}
+    P.estimate_transform(d["moving"], d["fixed"], ransac_trials=50, icp_iterations=2, seed=1, details=det)
+    assert det["edge_guard"] == {"moving": {"ring": 0, "sector": 0}, "fixed": {"ring": 0, "sector": 0}}
