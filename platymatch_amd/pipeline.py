@@ -75,6 +75,10 @@ class GpuBackend:
         sym = sc_f.shape[0] == 1 or self.K.chi2_symmetric(sc_m, sc_f)
         return self.K.chi2_cost_pair(sc_m, sc_f, pairing, sym, out=out)
 
+    def chi2_cost_single(self, scA, scB):
+        """One matrix chi2(scA[i], scB[j]) for any two descriptor sets [*, 360] (pm_chi2_cost)."""
+        return self.K.chi2_cost(scA.contiguous(), scB.contiguous())
+
     def free_bytes(self):
         """Device memory a new allocation can draw on: what the driver reports free plus what torch's caching allocator holds
         without using (the eight matrices of a previous registration sit there: counting them as taken would send the next
@@ -253,6 +257,22 @@ def build_costs(be, mov, fix, group=None):
     return be.chi2_cost8(sc_m, sc_f), bn
 
 
+_PHI = None
+
+
+def expand_frames(sc1, n_frames):
+    """Frames 1..n_frames of get_unary from frame 1 alone [rows, 360] -> [n_frames, rows, 360]: frames 2..4 permute the twelve
+    phi sectors of every (ring, theta) shell (shape_context.py:172-181; csrc/pm_binning.h: pm_phi_perm) — exact copies, made
+    by an index gather.  Only valid where gather_fixed_descriptors' bit-for-bit check of that relation has passed."""
+    global _PHI
+    import torch
+    if _PHI is None:
+        q = np.arange(12)
+        perms = [q, (q + 6) % 12, 11 - q, (5 - q) % 12]        # frame f's sector p reads frame 1's sector perms[f][p] (involutions / half turn)
+        _PHI = [np.concatenate([s * 12 + p for s in range(30)]) for p in perms]
+    return torch.stack([sc1[:, torch.as_tensor(_PHI[f], device=sc1.device)] for f in range(n_frames)])
+
+
 def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=None, accept_near_ties=False):
     """Cost matrices and assignments two matrices at a time, for clouds whose eight matrices (64 N M bytes per rank-block) do not
     fit in HBM together: for each pairing t the hypothesis and its twin are built (be.chi2_cost_pair: a quarter of the
@@ -265,6 +285,37 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
     out = [None] * 8
     routes = [None] * 8
     buf = None
+    if world > 1 and n > m:
+        # More moving than fixed nuclei: the solver wants the short side as its rows (SciPy transposes likewise), and the rows must
+        # be what is sharded.  chi-square is symmetric in its two descriptors BIT FOR BIT ((a - b)^2 = (b - a)^2, a + b = b + a,
+        # same bin order: test_cost_symmetry_property_large), so the transposed matrices are simply built with the roles
+        # swapped: every rank gathers the moving descriptors (2 frames x N x 2 880 B), keeps its block of FIXED rows and fills
+        # U_h^T [M_g, N] for the pairing's hypothesis and twin with the one-matrix kernel; the sharded solve then runs on fixed-row
+        # blocks.  (Twice the arithmetic of the frame-symmetric kernel — only this orientation pays it.)
+        from .lsap_sharded import solve_pair_sharded
+        lm = local_matrix or lsap.DeviceMatrix
+        bm = shard_bounds(m, world)
+        sc_m_full = all_gather_rows(sc_m, bounds, 1, group)                           # [2, N, 360]
+        f_all = sc_f if sc_f.shape[0] == 4 else expand_frames(sc_f[0], 4)             # (frame 1 only travelled: derive 2..4)
+        f_loc = f_all[:, bm[rank]:bm[rank + 1]]
+        for t, (h, twin) in enumerate(((0, 5), (1, 4), (2, 7), (3, 6))):
+            (ah, bh), (at, bt) = ((int(c) - 1 for c in HYPOTHESES[h]), (int(c) - 1 for c in HYPOTHESES[twin]))
+            UT_h = be.chi2_cost_single(f_loc[bh], sc_m_full[ah])                      # [M_g, N] = U_h[:, block]^T
+            UT_t = be.chi2_cost_single(f_loc[bt], sc_m_full[at])
+            ih = {}
+            c_h, c_t = solve_pair_sharded(lm(UT_h), lm(UT_t), bm, n, group, h % world, ih, accept_near_ties=accept_near_ties)
+            del UT_h, UT_t
+            for idx, c4r in ((h, c_h), (twin, c_t)):
+                if c4r is None:
+                    raise RuntimeError("hypothesis %s: the assignment could not be certified unique (an alternative within ~1e-11 of the "
+                                       "optimum, exact ties or non-finite costs) and the matrix is too large for the dense solver; "
+                                       "accept_near_ties=True takes the certified optimum as it is" % HYPOTHESES[idx])
+                out[idx] = lsap._answer(np.asarray(c4r), n, m)                       # fixed j -> moving i, as SciPy reports an N > M problem
+                routes[idx] = "sharded device (transposed: fixed rows sharded)"
+        if info is not None:
+            info["routes"] = routes
+            info["mode"] = "streamed: two matrices resident at a time"
+        return out
     for t, (h, twin) in enumerate(((0, 5), (1, 4), (2, 7), (3, 6))):
         U2 = be.chi2_cost_pair(sc_m, sc_f, t, out=buf)
         buf = U2
@@ -275,8 +326,6 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
         else:
             from .lsap_sharded import solve_pair_sharded
             lm = local_matrix or lsap.DeviceMatrix
-            if n > m:
-                raise NotImplementedError("sharded streamed assignment needs N <= M (rows are the sharded side)")
             c_h, c_t = solve_pair_sharded(lm(U2[0]), lm(U2[1]), bounds, m, group, h % world, ih, accept_near_ties=accept_near_ties)
             rows = np.arange(n, dtype=np.int64)
             got = [None if c_h is None else (rows, np.asarray(c_h, dtype=np.int64)),
