@@ -10,8 +10,9 @@ row-sharded (strong scaling): descriptors and cost rows by block with one all-ga
 descriptors over RCCL; the ICP refinement (1 % of the step with the grid search) is run whole by every rank.  The Hungarian solve is not
 part of the step: at 50k it needs hours and 20 GB of host memory per matrix.
 
-Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
-         python -m torch.distributed.run --nproc-per-node G ... bench.py --gpus G ...
+Launch:  python bench.py [--gpus N] [--steps K] [--warmup W]     (N > 1 and no WORLD_SIZE in the environment: the script starts its
+                                                                  own N ranks, one per GPU, before anything touches a GPU)
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -49,8 +50,10 @@ def synth(n, seed=0):
     return np.ascontiguousarray(mv), fx, np.ascontiguousarray(start)
 
 
-def _cpu_per_pair(oracle, mv, fx, start, threads, sub, rows, nn_rows):
-    """Per-point-pair costs (seconds) of the oracle's stages with `threads` threads on a bounded sample."""
+def _cpu_per_pair(oracle, mv, fx, start, threads, sub, rows, nn_rows, real=None):
+    """Per-point-pair costs (seconds) of the oracle's stages with `threads` threads on a bounded sample.
+    real = (um [2, r, 360], uf [4, M, 360]): the chi-square leg runs on these descriptors of the REAL clouds (r rows against all M
+    columns, eight matrices) instead of on the subsample's."""
     m = fx.shape[1]
     oracle.set_threads(threads)
     cm, cf = oracle.get_centroid(mv, False), oracle.get_centroid(fx, False)
@@ -63,12 +66,20 @@ def _cpu_per_pair(oracle, mv, fx, start, threads, sub, rows, nn_rows):
     cnt_f, tot_f = oracle.shape_context_counts(cf, mdm, fx[:, :sub], "fixed", x0=x0f)
     t_sc = (time.perf_counter() - t) / (6.0 * sub * sub)                       # s per (ordered pair, frame)
     um, uf = oracle.normalise_counts(cnt_m, tot_m), oracle.normalise_counts(cnt_f, tot_f)
-    rows = min(rows, sub)
-    t = time.perf_counter()
-    for a in range(2):
-        for b in range(4):
-            oracle.unary_distance_matrix(um[a][:rows], uf[b][:sub // 2])
-    t_chi = (time.perf_counter() - t) / (8.0 * rows * (sub // 2))              # s per (pair, matrix)
+    if real is not None:
+        rum, ruf = real
+        t = time.perf_counter()
+        for a in range(2):
+            for b in range(4):
+                oracle.unary_distance_matrix(rum[a], ruf[b])
+        t_chi = (time.perf_counter() - t) / (8.0 * rum.shape[1] * ruf.shape[1])    # s per (pair, matrix)
+    else:
+        rows = min(rows, sub)
+        t = time.perf_counter()
+        for a in range(2):
+            for b in range(4):
+                oracle.unary_distance_matrix(um[a][:rows], uf[b][:sub // 2])
+        t_chi = (time.perf_counter() - t) / (8.0 * rows * (sub // 2))          # s per (pair, matrix)
     nn_rows = min(nn_rows, start.shape[1])
     t = time.perf_counter()
     oracle.nn_argmin(start[:, :nn_rows], fx)
@@ -77,7 +88,7 @@ def _cpu_per_pair(oracle, mv, fx, start, threads, sub, rows, nn_rows):
     return t_md, t_sc, t_chi, t_nn
 
 
-def cpu_baseline(mv, fx, start, icp_iters):
+def cpu_baseline(mv, fx, start, icp_iters, real=None):
     """The oracle (C port of the reference's loops, oracle/pm_oracle.c) on the GPU box's host cores, on a bounded sample of
     the same workload (~10-30 s of CPU work), per-pair costs extrapolated to the full N x M problem.  `value` uses every
     core this process may run on (row loops under OpenMP: rows are independent, results do not depend on the thread
@@ -95,12 +106,15 @@ def cpu_baseline(mv, fx, start, icp_iters):
     scale = max(1, min(cores, 64))
     subT = min(n, 3072 * max(1, int(scale ** 0.5)))
     rowsT, nnT = 128 * scale, 1024 * scale
-    allc = _cpu_per_pair(oracle, mv, fx, start, cores, subT, rowsT, nnT) if cores > 1 else one
+    allc = _cpu_per_pair(oracle, mv, fx, start, cores, subT, rowsT, nnT, real=real) if (cores > 1 or real is not None) else one
+    chi_note = ("8 chi2 blocks of %d x %d = %.2f %% of the real N x M pairs per matrix, on the descriptors of the full clouds"
+                % (real[0].shape[1], real[1].shape[1], 100.0 * real[0].shape[1] / n) if real is not None
+                else "8 chi2 blocks of %d x %d" % (min(rowsT, subT), subT // 2))
     names = ("mean_distance", "shape_context_per_frame", "chi2_per_matrix", "icp_nn_per_iteration")
     return {"value": 1.0 / extrapolate(*allc), "unit": "point-pairs/s", "cores": cores, "kind": "port",
             "sample": "oracle/pm_oracle.c, row loops on %d threads (OpenMP; os.cpu_count() = %s): mean distance + descriptors of a "
-                      "%d-point subsample, 8 chi2 blocks of %d x %d, 1 NN pass of %d x %d; per-pair costs extrapolated to N=M=%d, "
-                      "%d ICP iterations" % (cores, os.cpu_count(), subT, min(rowsT, subT), subT // 2, min(nnT, n), m, n, icp_iters),
+                      "%d-point subsample, %s, 1 NN pass of %d x %d; per-pair costs extrapolated to N=M=%d, "
+                      "%d ICP iterations" % (cores, os.cpu_count(), subT, chi_note, min(nnT, n), m, n, icp_iters),
             "per_pair_ns": dict(zip(names, (x * 1e9 for x in allc))),
             "one_core": {"value": 1.0 / extrapolate(*one), "cores": 1, "per_pair_ns": dict(zip(names, (x * 1e9 for x in one))),
                          "sample": "%d-point subsample, chi2 blocks %d x %d, NN %d x %d" % (sub1, rows1, sub1 // 2, nn1, m)},
@@ -335,6 +349,7 @@ def main():
     ns_per_instr = chi2_ms * 1e6 / (instr / 1024.0)                          # per SIMD (256 CUs x 4)
     issue_bound_ms = issue_cycles / 2.4e9 * 1e3                              # at the 2.4 GHz maximum clock
 
+    add_floor_s = 8.0 * 360.0 * rows * m / 64.0 / 1024.0 * 4.0 / 2.4e9      # the running-sum adds alone (183 ms at 50k)
     # HBM traffic of that launch: from the committed rocprofv3 PMC passes of this configuration (1 GPU, this N), else null
     traffic, traffic_src = pmc_traffic("chi2_sym_kernel" if sym else "chi2_kernel<", n) if world == 1 else (None, None)
 
@@ -346,13 +361,14 @@ def main():
     icp_ms = float(stage[3])
     stage_roofline = {
         "shape_context": {
-            "kernel": "pm::shape_context_kernel<2>, <4>", "bound": "hbm", "achieved": sc_bytes / (sc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+            "kernel": "pm::sc_tile_kernel<2>, <4> (+ sc_prepare / sc_finish)", "bound": "hbm", "achieved": sc_bytes / (sc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": sc_bytes / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": sc_bytes,
-            "binding_bound": "float64 VALU: ~140 instructions per ordered pair for up to four frames (exact ring / theta / phi "
-                             "classification by comparison, DESIGN.md §5); no LDS staging of the cloud: every workgroup streams the "
-                             "1.2 MB SoA cloud from L2",
+            "binding_bound": "VALU issue: ~70 vector instructions per ordered pair (6 float64, the rest float32 / integer: the neighbour is "
+                             "pre-classified in float32 and decided in float64 only when within float32's reach of a bin boundary, "
+                             "DESIGN.md §4.5), 16 queries per workgroup share every neighbour load, one histogram per query (frames 2..4 are "
+                             "its phi permutations); round 2's kernel: ~140 float64 instructions per pair, 17.4 ms",
             "ns_per_pair": sc_ms * 1e6 / sc_pairs,
-            "valu_issue_estimate_ms": (140.0 * 4.0 / 2.4e9) * sc_pairs / 64.0 / 1024.0 * 1e3},
+            "valu_issue_estimate_ms": ((6 * 4.0 + 64 * 2.0) / 2.4e9) * sc_pairs / 64.0 / 1024.0 * 1e3},
         "icp": {
             "kernel": "pm::icp_iter_kernel (one launch per iteration: apply + residual + bounded search + moment tree + solve)", "bound": "hbm",
             "achieved": icp_bytes_iter * args.icp_iters / (icp_ms * 1e-3) / 1e9 if args.icp_iters else None, "peak": HBM_PEAK_GBS,
@@ -394,11 +410,20 @@ def main():
                        "n": n, "m": m, "chi2_matrices": 8, "icp_iterations": args.icp_iters, "pairs_per_step": n * m,
                        "sharding": "rows/%d" % world},
             "stage_ms": {"statistics": float(stage[0]), "shape_context": float(stage[1]), "chi2_cost8": chi2_ms, "icp": float(stage[3])},
-            "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "GB per launch", "traffic_source": traffic_src,
+            # the dominant kernel is bound by float64 VALU issue, not by HBM: the headline `frac` is the fraction of
+            # the vector-float64 peak; the HBM view of the same launch stands beside it (hbm_*), with the most any kernel that adds
+            # the reference's 360 terms per (pair, matrix) one after the other in float64 could reach (attainable_hbm_frac_upper_bound)
+            "roofline": {"kernel": kernel_name, "bound": "fp64_valu", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+                         "hbm_achieved": achieved, "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s", "hbm_frac": achieved / HBM_PEAK_GBS,
+                         "attainable_hbm_frac_upper_bound": (algo_bytes / (HBM_PEAK_GBS * 1e9)) / add_floor_s,
+                         "attainable_note": "the eight running sums of a pair take 8 x 360 dependent float64 adds: %.0f ms per launch at 4 "
+                                            "cycles per wave-instruction on 1 024 SIMDs at 2.4 GHz, against %.1f ms for the bytes at 8 TB/s "
+                                            "(every term free)" % (add_floor_s * 1e3, algo_bytes / (HBM_PEAK_GBS * 1e9) * 1e3),
+                         "traffic": traffic, "traffic_unit": "GB per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes": algo_bytes,
                          "tabled_shells": tabled if sym else None,
-                         "note": "compulsory bytes / measured launch time.  The >=70 %-of-HBM target of north_star is NOT reachable "
+                         "note": "hbm_achieved = compulsory bytes / measured launch time.  The >=70 %-of-HBM target of north_star is NOT reachable "
                                  "with bit-identical float64 costs: 360 correctly rounded divisions per pair and matrix need ~70x "
                                  "more float64-VALU time than the 20 ms the bytes need.  Round 2 takes the terms of the sparsely "
                                  "filled shells (tabled_shells of 30) from a count-indexed table in LDS instead of dividing; the "
@@ -414,7 +439,11 @@ def main():
             "assignment_extra": assignment,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mv_h, fx_h, start_h, args.icp_iters)
+            # the chi-square leg of the CPU baseline runs on the real clouds' descriptors (the GPU's, verified equal to the oracle's
+            # by the parity tests): >= 1 % of the N x M pairs of every matrix
+            r_rows = max(1, min(n, (n + 99) // 100 + 12))
+            real = (sc_m_last[0][:, :r_rows].cpu().numpy(), (sc_f_last[0] if sc_f_last[0].shape[0] == 4 else P.expand_frames(sc_f_last[0][0], 4)).cpu().numpy())
+            out["cpu_baseline"] = cpu_baseline(mv_h, fx_h, start_h, args.icp_iters, real=real)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(group=group)
