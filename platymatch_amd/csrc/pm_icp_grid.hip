@@ -19,11 +19,17 @@ namespace pm {
 constexpr int GR_MAX_DIM = 512;
 // Cells per point.  Nucleus clouds are blobs, not uniform boxes: the bounding box is mostly empty and the core is
 // ~30x denser than the box average, so the grid is sized for ~1/8 point per cell on average (~4 in the core).
-constexpr int GR_CELLS_PER_POINT = 8;    // measured on the 50k blob: 1 -> 234, 2 -> 146, 4 -> 97, 8 -> 77, 16 -> 75 us per ICP iteration
+#ifndef PM_GR_CELLS_PER_POINT
+#define PM_GR_CELLS_PER_POINT 8
+#endif
+constexpr int GR_CELLS_PER_POINT = PM_GR_CELLS_PER_POINT;    // measured on the 50k blob: 1 -> 234, 2 -> 146, 4 -> 97, 8 -> 77, 16 -> 75 us per ICP iteration
 constexpr int GR_RING_CAP = 6;            // beyond this ring radius a group scans the whole cloud instead (sparse outliers)
 constexpr int GR_BATCH = 4;               // cells per lane whose ranges are fetched together
 #ifndef GR_INFLIGHT
 #define GR_INFLIGHT 2                     // candidate records a lane requests before it compares them
+#endif
+#ifndef GR_FLAT
+#define GR_FLAT 4                         // candidate records in flight in the flattened scan of the bounded search
 #endif
 constexpr int GR_BALL_RUNS = 36;          // largest box (in runs of x-adjacent cells) the bounded search of the fused ICP iteration takes on
 // Lanes per moving point once the previous match bounds the search (a handful of cells): 8, or 4 for large clouds so that
@@ -378,17 +384,65 @@ struct GridSearch {
     // (the point -> cell map is monotone per axis, so no slack beyond rad >= the true distance is needed).  The box is
     // ny * nz runs of x-adjacent cells; lanes share the runs (several lanes per run while there are fewer runs than lanes).
     // Returns false (nothing scanned) if the box has more than GR_BALL_RUNS runs: rings() is the better plan then.
+    // candidates of up to three index ranges [a_b, e_b) (stride `step` each) as ONE sequence, GR_FLAT records in flight at a time: a
+    // lane that owns several runs of cells pays one round trip per GR_FLAT candidates instead of one (or more) per run
+    __device__ __forceinline__ void scan3(int a0, int e0, int a1, int e1, int a2, int e2, int lg) {     // stride 1 << lg
+        const int step = 1 << lg;
+        const int c0 = max(0, (e0 - a0 + step - 1) >> lg), c1 = max(0, (e1 - a1 + step - 1) >> lg), c2 = max(0, (e2 - a2 + step - 1) >> lg);
+        const int total = c0 + c1 + c2;
+        for (int t = 0; t < total; t += GR_FLAT) {
+            double4 f[GR_FLAT];
+#pragma unroll
+            for (int u = 0; u < GR_FLAT; ++u) {
+                const int tt = min(t + u, total - 1);                 // a clamped repeat of the last candidate changes nothing
+                const int q = tt < c0 ? a0 + (tt << lg) : (tt < c0 + c1 ? a1 + ((tt - c0) << lg) : a2 + ((tt - c0 - c1) << lg));
+                f[u] = pts[q];
+            }
+#pragma unroll
+            for (int u = 0; u < GR_FLAT; ++u) {
+                const double d0 = f[u].x - p0, d1 = f[u].y - p1, d2 = f[u].z - p2;
+                const double s = (d0 * d0 + d1 * d1) + d2 * d2;
+                const int j = (int)__double_as_longlong(f[u].w);
+                if (grid_better(s, j, bS, bI)) {
+                    bS = s; bI = j;
+                    if (TRACK) { bX = f[u].x; bY = f[u].y; bZ = f[u].z; }
+                }
+            }
+        }
+    }
+
+    // The same answer when a candidate at squared distance bS is already known (ICP: the previous iteration's match): every
+    // point that could beat or tie it lies within sqrt(bS) of the query, hence in the cells the box query +- rad covers
+    // (the point -> cell map is monotone per axis, so no slack beyond rad >= the true distance is needed).  The box is
+    // ny * nz runs of x-adjacent cells; lanes share the runs (several lanes per run while there are fewer runs than lanes).
+    // A lane's runs are taken three at a time: their six range ends in one round trip, then their candidates as one sequence
+    // (round 3: the slowest point of a launch — a large box, nine runs per lane — set the pace of every iteration).
+    // Returns false (nothing scanned) if the box has more than GR_BALL_RUNS runs: rings() is the better plan then.
     __device__ __forceinline__ bool ball(double rad) {
         const int x0 = cell_coord(p0 - rad, hd.lo[0], hd.inv_h, hd.g[0]), x1 = cell_coord(p0 + rad, hd.lo[0], hd.inv_h, hd.g[0]);
         const int y0 = cell_coord(p1 - rad, hd.lo[1], hd.inv_h, hd.g[1]), y1 = cell_coord(p1 + rad, hd.lo[1], hd.inv_h, hd.g[1]);
         const int z0 = cell_coord(p2 - rad, hd.lo[2], hd.inv_h, hd.g[2]), z1 = cell_coord(p2 + rad, hd.lo[2], hd.inv_h, hd.g[2]);
         const int ny = y1 - y0 + 1, nruns = ny * (z1 - z0 + 1);
         if (nruns > GR_BALL_RUNS || nruns < 1) return false;
-        const int per = (nruns < L) ? L / nruns : 1;     // lanes per run
-        const int part = sub % per;
-        for (int run = sub / per; run < nruns; run += L / per) {
-            const int row = ((z0 + run / ny) * hd.g[1] + (y0 + run % ny)) * hd.g[0];
-            scan(start[row + x0] + part, start[row + x1 + 1], per);
+        // lanes per run: the largest power of two <= L / nruns (no integer division in this loop: the search is bound by
+        // instruction issue — three waves per SIMD, ~1 000 vector instructions per point — not by its memory round trips)
+        int lg = 0;
+        while ((2 << lg) * nruns <= L) ++lg;
+        const int part = sub & ((1 << lg) - 1), stride = L >> lg;
+        const unsigned int inv_ny = (65536u + (unsigned int)ny - 1u) / (unsigned int)ny;      // floor(r / ny) = (r * inv_ny) >> 16 for r < 64
+        for (int run = sub >> lg; run < nruns; run += 3 * stride) {
+            int a[3], e[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int r = run + b * stride;
+                const bool have = r < nruns;
+                const int rr = have ? r : run;
+                const int rz = (int)(((unsigned int)rr * inv_ny) >> 16), ry = rr - rz * ny;
+                const int row = ((z0 + rz) * hd.g[1] + (y0 + ry)) * hd.g[0];
+                a[b] = start[row + x0] + part;
+                e[b] = have ? start[row + x1 + 1] : a[b];           // (an absent run: empty range)
+            }
+            scan3(a[0], e[0], a[1], e[1], a[2], e[2], lg);
         }
         merge();
         return true;

@@ -50,6 +50,16 @@ assert lib.pm_debug_set_icp_stamps(stamps.data_ptr()) == 0
 K.icp(st.clone(), fix, iters, ws=ws, one_launch=one)
 torch.cuda.synchronize()
 assert lib.pm_debug_set_icp_stamps(None) == 0
+best = 1e9
+for rep in range(4):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    w_ = st.clone()
+    e0.record()
+    K.icp(w_, fix, 200, ws=ws, one_launch=one)
+    e1.record()
+    torch.cuda.synchronize()
+    best = min(best, e0.elapsed_time(e1))
+print("TIMING n=%d defines=%s: %.1f us per iteration (200 iterations, stamps off)" % (n, " ".join(extra) or "-", best * 1e3 / 200), flush=True)
 few_from = 32768
 for d in extra:
     if d.startswith("-DPM_GR_FEW_FROM="):
