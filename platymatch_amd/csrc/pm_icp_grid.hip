@@ -424,8 +424,10 @@ struct GridSearch {
         const int z0 = cell_coord(p2 - rad, hd.lo[2], hd.inv_h, hd.g[2]), z1 = cell_coord(p2 + rad, hd.lo[2], hd.inv_h, hd.g[2]);
         const int ny = y1 - y0 + 1, nruns = ny * (z1 - z0 + 1);
         if (nruns > GR_BALL_RUNS || nruns < 1) return false;
-        // lanes per run: the largest power of two <= L / nruns (no integer division in this loop: the search is bound by
-        // instruction issue — three waves per SIMD, ~1 000 vector instructions per point — not by its memory round trips)
+        // lanes per run: the largest power of two <= L / nruns (no integer division in this loop; counters of the 50 000-point
+        // launch, profiles/r03_icp_iter_pmc.txt: ~870 vector instructions per wave, waves waiting 53 % of their cycles, issue
+        // stalls 24 %, the VALU busy 21 % of the launch — neither more loads in flight, nor more lanes per point, nor a finer
+        // grid moved the 6 us this phase takes: profiles/r03_icp_stamps_per_launch_variants.txt, r03_icp_grid_resolution_sweep.txt)
         int lg = 0;
         while ((2 << lg) * nruns <= L) ++lg;
         const int part = sub & ((1 << lg) - 1), stride = L >> lg;

@@ -26,6 +26,48 @@ from .lsap import linear_sum_assignment, solve_many
 HYPOTHESES = ("11", "12", "13", "14", "21", "22", "23", "24")
 _RNG_LOCK = threading.RLock()
 
+# The eight cost matrices of a large registration (160 GB at 50 000 x 50 000) are kept by THIS module between calls, one buffer
+# per (device, stream), instead of being handed back to torch's caching allocator: a freed block of that size is the only one
+# large enough for any later request of more than a megabyte that finds no exact fit, gets split for it, and — with a live
+# piece inside — can neither serve the next registration nor be returned to the driver (round 3: the fifth 50 000-point
+# registration of a process ran out of memory with 149 GB "reserved but unallocated").  Buffers below COST_CACHE_MIN_BYTES
+# (and every registration of a batch) go through the allocator as before.  release_cost_buffers() gives the memory back.
+COST_CACHE_MIN_BYTES = 8 << 30
+_COST_CACHE = {}
+_COST_LOCK = threading.Lock()
+
+
+def _cost_key(device):
+    import torch
+    return (device.index, torch.cuda.current_stream(device).cuda_stream)
+
+
+def cost_buffer(device, shape):
+    """A float64 [shape] view of this (device, stream)'s kept buffer, grown if it is too small (the old one is released first)."""
+    import torch
+    need = int(np.prod(shape))
+    key = _cost_key(device)
+    with _COST_LOCK:
+        t = _COST_CACHE.get(key)
+        if t is None or t.numel() < need:
+            _COST_CACHE.pop(key, None)
+            t = None                                       # (released before the larger one is asked for)
+            t = torch.empty(need, dtype=torch.float64, device=device)
+            _COST_CACHE[key] = t
+    return t[:need].view(*shape)
+
+
+def kept_cost_bytes(device):
+    with _COST_LOCK:
+        t = _COST_CACHE.get(_cost_key(device))
+    return 0 if t is None else t.numel() * 8
+
+
+def release_cost_buffers():
+    """Hand every kept cost buffer back to torch's allocator (and, with torch.cuda.empty_cache(), to the driver)."""
+    with _COST_LOCK:
+        _COST_CACHE.clear()
+
 
 class GpuBackend:
     """The product's only compute backend: the HIP kernels behind libplatymatch_hip.so."""
@@ -85,7 +127,7 @@ class GpuBackend:
         registration of the same size into the streamed mode)."""
         import torch
         cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
-        return torch.cuda.mem_get_info(self.device)[0] + max(int(cached), 0)
+        return torch.cuda.mem_get_info(self.device)[0] + max(int(cached), 0) + kept_cost_bytes(self.device)   # (+ this stream's kept buffer: it IS the room)
 
     def row_argmin(self, U):
         return self.K.row_argmin(U)
@@ -607,7 +649,7 @@ def _shared_device_seed(group, device):
 def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
                        ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, group=None,
                        backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS, private_rng=False, stream_hypotheses=None,
-                       accept_near_ties=False, sampler='auto', icp_one_launch=None):
+                       accept_near_ties=False, sampler='auto', icp_one_launch=None, keep_cost_buffer=True):
     """Reproduces _dock_widget.py:526-718 -> (A_sc, A_icp, inliers[8]); final transform = A_icp @ A_sc (:428).
 
     moving, fixed   3 x N / 3 x M float64 (rows z, y, x), NumPy or torch
@@ -632,6 +674,9 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     accept_near_ties      for matrices beyond the reach of SciPy's dense algorithm (> 2^30 entries): if a hypothesis has a second
                           assignment within ~1e-11 of the optimal cost, which of the two SciPy's rounding would return cannot be
                           told; False raises, True takes the certified optimum (details['assignment']['routes'] says so)
+    keep_cost_buffer  large registrations (eight matrices >= 8 GiB) write their cost matrices into a buffer this module keeps per
+                    (device, stream) between calls (see COST_CACHE_MIN_BYTES above; release_cost_buffers() frees it); False: a fresh
+                    allocation per call, returned to torch's allocator afterwards
     icp_one_launch  None: perform_icp.ONE_LAUNCH decides (default False: one launch per iteration); True: iterations 1 .. n-1 of the
                     Affine ICP loop in one launch of persistent workgroups (only for a device that does nothing else meanwhile;
                     estimate_transform_batch always passes False: its workers keep several streams busy) — identical results
@@ -676,7 +721,12 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                 # free memory and row counts differ from rank to rank: near the threshold ranks would take different branches,
                 # i.e. different sequences of collectives.  One rank that must stream makes all of them stream.
                 streamed = bool(agree_max(1 if streamed else 0, group, mov.device))
-            U = None if streamed else be.chi2_cost8(sc_m, sc_f)
+            if streamed:
+                U = None
+            elif keep_cost_buffer and mov.is_cuda and need >= COST_CACHE_MIN_BYTES and world == 1:
+                U = be.chi2_cost8(sc_m, sc_f, out=cost_buffer(mov.device, (8, sc_m.shape[1], sc_f.shape[1])))
+            else:
+                U = be.chi2_cost8(sc_m, sc_f)
         except BaseException:
             draws.thread.join()
             raise
@@ -832,6 +882,8 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
 
     if on_gpu and workers > 1 and len(ks) > 1 and "icp_one_launch" not in kwargs:
         kwargs = dict(kwargs, icp_one_launch=False)       # several streams in flight: no persistent grid (perform_icp.ONE_LAUNCH)
+    if on_gpu and workers > 1 and len(ks) > 1 and "keep_cost_buffer" not in kwargs:
+        kwargs = dict(kwargs, keep_cost_buffer=False)     # (a buffer kept per worker stream would pin memory the HBM gate counts as free)
     # largest first: the long Hungarian solves start early and the short pairs fill the gaps at the end
     cost = batch_costs([_pair_size(pairs[k]) for k in ks])
     order = [ks[i] for i in sorted(range(len(ks)), key=lambda i: (-cost[i], ks[i]))]

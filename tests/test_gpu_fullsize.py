@@ -260,3 +260,32 @@ def test_config4_rank_slice_row_argmins_equal_cpu():
         want = oracle.unary_distance_matrix(hm_h[int(name[0]) - 1], hf_h[int(name[1]) - 1])     # 4 x 200000, exact float64
         assert np.array_equal(want, U[h, rows_m].cpu().numpy()), name
         assert np.array_equal(want.argmin(1), idx[h, rows_m].cpu().numpy()), name
+
+
+def test_repeated_large_registrations_keep_their_cost_buffer_and_do_not_run_out_of_memory():
+    """Round 3: the fifth 50 000-point registration of one process failed with 149 GB "reserved but unallocated" — torch's caching
+    allocator had split the freed 160 GB block for a small request.  The eight matrices of a large registration now live in a
+    buffer pipeline keeps per (device, stream): six registrations in a row (seeded and not, two sizes, one with more moving than
+    fixed points), the buffer allocated once, device memory in use unchanged from the second call on."""
+    import torch
+    import bench
+    from platymatch_amd import pipeline as P
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    torch.cuda.empty_cache()
+    P.release_cost_buffers()
+    mv, fx, _ = bench.synth(N, seed=2)
+    dev = torch.device("cuda:0")
+    used = []
+    kw = dict(ransac_trials=2000, ransac_error=16, icp_iterations=10)
+    runs = [(N, N, 0), (N, N, None), (47000, N, 1), (N, N, None), (N, 47000, None), (N, N, 2)]
+    for n, m, seed in runs:
+        A_sc, A_icp, inl = P.estimate_transform(np.ascontiguousarray(mv[:, :n]), np.ascontiguousarray(fx[:, :m]), seed=seed, **kw)
+        assert inl.max() > 0.8 * min(n, m)                                      # the right hypothesis was found every time
+        torch.cuda.synchronize()
+        used.append((P.kept_cost_bytes(dev), torch.cuda.memory_reserved(dev)))
+    assert all(k == 64 * N * N for k, _ in used)                                # allocated once, for the largest pair
+    assert max(r for _, r in used[1:]) - min(r for _, r in used[1:]) < (8 << 30)  # no second 160 GB block, no growth
+    P.release_cost_buffers()
+    torch.cuda.empty_cache()
+    assert P.kept_cost_bytes(dev) == 0
