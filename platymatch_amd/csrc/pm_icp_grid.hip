@@ -82,19 +82,36 @@ __device__ __forceinline__ int cell_coord(double x, double lo, double inv_h, int
 __global__ __launch_bounds__(1024) void grid_plan_kernel(const double *__restrict__ fix, int m, int max_cells, GridHeader *hd) {
     __shared__ double smin[3][16], smax[3][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = 0; c < 3; ++c) {
-        double lo = INFINITY, hi = -INFINITY;
-        for (int j = threadIdx.x; j < m; j += 1024) {
-            const double v = fix[(size_t)c * m + j];
-            lo = v < lo ? v : lo;
-            hi = v > hi ? v : hi;
+    {
+        // bounding box: the three coordinate rows in ONE sweep, four points per thread and step (twelve independent loads in flight:
+        // one coordinate after the other, one load per step, this single workgroup spent ~150 dependent round trips, 40-77 us)
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int j0 = threadIdx.x; j0 < m; j0 += 4 * 1024) {
+            double v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(j0 + u * 1024, m - 1);              // (a clamped repeat changes no minimum or maximum)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[u][c] = fix[(size_t)c * m + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    lo[c] = v[u][c] < lo[c] ? v[u][c] : lo[c];
+                    hi[c] = v[u][c] > hi[c] ? v[u][c] : hi[c];
+                }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const double a = __shfl_down(lo, off, 64), b = __shfl_down(hi, off, 64);
-            lo = a < lo ? a : lo;
-            hi = b > hi ? b : hi;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double a = lo[c], b = hi[c];
+            for (int off = 32; off > 0; off >>= 1) {
+                const double a2 = __shfl_down(a, off, 64), b2 = __shfl_down(b, off, 64);
+                a = a2 < a ? a2 : a;
+                b = b2 > b ? b2 : b;
+            }
+            if (lane == 0) { smin[c][wave] = a; smax[c][wave] = b; }
         }
-        if (lane == 0) { smin[c][wave] = lo; smax[c][wave] = hi; }
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -514,3 +514,33 @@ def test_sharded_streamed_assignment_with_more_moving_than_fixed_points(tmp_path
     f1 = torch.as_tensor(np.arange(5 * 360, dtype=np.float64).reshape(5, 360))
     want = OracleBackend._frames_from_first(f1.numpy())
     assert np.array_equal(P.expand_frames(f1, 4).numpy(), want)
+
+
+def _seed_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from platymatch_amd import pipeline as P
+        np.random.seed(100 + rank)                            # every rank's global generator is in another state
+        seeds = [P._shared_device_seed(dist.group.WORLD, None) for _ in range(3)]
+        flags = [P.agree_max(1 if rank == k else 0, dist.group.WORLD) for k in range(world)] + [P.agree_max(0, dist.group.WORLD)]
+        np.save(out_path % rank, np.array(seeds + flags, dtype=np.uint64))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_unseeded_ranks_share_one_sampler_key_and_decisions_are_collective(tmp_path):
+    """Round 3: an unseeded sharded run draws its RANSAC index sets on the device from a 64-bit key — rank 0's, broadcast (ranks
+    drawing their own would silently register different things); and a decision any rank could take differently (stream the
+    hypotheses or not: free memory differs per GPU) is settled by a MAX all-reduce."""
+    out = str(tmp_path / "s%d.npy")
+    mp.spawn(_seed_worker, args=(3, _free_port(), out), nprocs=3, join=True)
+    r = [np.load(out % k) for k in range(3)]
+    assert np.array_equal(r[0], r[1]) and np.array_equal(r[0], r[2])
+    assert len(set(r[0][:3].tolist())) == 3                   # a fresh key per registration
+    rs = np.random.RandomState(100)
+    lo, hi = (int(v) for v in rs.randint(0, 2 ** 32, size=2, dtype=np.uint64))
+    assert int(r[0][0]) == (hi << 32) | lo                    # rank 0's generator supplied it
+    assert r[0][3:].tolist() == [1, 1, 1, 0]
