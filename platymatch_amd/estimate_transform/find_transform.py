@@ -234,17 +234,35 @@ def apply_affine_host(moving, A):
     return np.matmul(A, hom)[:3, :]
 
 
+DEVICE_MOMENTS_FROM = 4096        # clouds from this size on have their O(N) sums taken on the device (NumPy inputs; GPU tensors always)
+
+
+def _sequential(x):
+    """Does np.mean(x, 1) add this 2-D array's columns one after the other (Fortran order) rather than pairwise along its rows?"""
+    return bool(x.flags["F_CONTIGUOUS"] and not x.flags["C_CONTIGUOUS"])
+
+
 def get_similar_transform(moving, fixed):
-    """find_transform.py:21-99 -> 4 x 4.  Host NumPy, the reference's operations in the reference's order (see
-    similar_transform_host); GPU tensors are brought to the host and the result returned as a tensor."""
+    """find_transform.py:21-99 -> 4 x 4.  The O(N) arithmetic — centroids, the nine product sums, D, Sp — runs on the device in
+    NumPy's own order for GPU tensors and for clouds of DEVICE_MOMENTS_FROM points or more (K.similar_moments; the memory order
+    of a NumPy input decides how its centroid is summed, as it does in np.mean); the 4 x 4 eigen-decomposition and what follows
+    are the reference's own NumPy calls on the host (similar_from_moments).  Smaller NumPy inputs take the literal host sequence
+    (similar_transform_host).  Same bits either way (tests/test_gpu_similar.py)."""
     torch = nat.torch_mod()
     if nat.is_torch(moving) or nat.is_torch(fixed):
-        m = moving.detach().cpu().numpy() if nat.is_torch(moving) else np.asarray(moving)
-        f = fixed.detach().cpu().numpy() if nat.is_torch(fixed) else np.asarray(fixed)
-        A = similar_transform_host(m, f)
-        dev = moving.device if nat.is_torch(moving) else fixed.device
-        return torch.as_tensor(A, device=dev)
+        m, f = nat.to_dev(moving), nat.to_dev(fixed)
+        if m.dim() != 2 or f.dim() != 2 or m.shape[1] != f.shape[1] or m.shape[0] < 3 or f.shape[0] < 3:
+            raise ValueError("moving and fixed must be 3 x N")
+        # a torch tensor's rows are what get summed: row-major (C order) unless it is a transposed view
+        seq_m = bool(m.stride(0) == 1 and m.shape[1] > 1 and m.stride(1) != 1)
+        seq_f = bool(f.stride(0) == 1 and f.shape[1] > 1 and f.stride(1) != 1)
+        v = K.similar_moments(m[:3].contiguous(), f[:3].contiguous(), None, mov_sequential=seq_m, fix_sequential=seq_f)
+        return torch.as_tensor(similar_from_moments(v.cpu().numpy()), device=m.device)
     m, f = np.asarray(moving), np.asarray(fixed)
     if m.ndim != 2 or f.ndim != 2 or m.shape[1] != f.shape[1] or m.shape[0] < 3 or f.shape[0] < 3:
         raise ValueError("moving and fixed must be 3 x N")
+    if m.shape[1] >= DEVICE_MOMENTS_FROM and m.dtype == np.float64 and f.dtype == np.float64 and m.shape[0] == 3 and f.shape[0] == 3:
+        md, fd = nat.to_dev(np.ascontiguousarray(m)), nat.to_dev(np.ascontiguousarray(f))
+        v = K.similar_moments(md, fd, None, mov_sequential=_sequential(m), fix_sequential=_sequential(f))
+        return similar_from_moments(v.cpu().numpy())
     return similar_transform_host(m, f)

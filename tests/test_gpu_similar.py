@@ -128,3 +128,21 @@ def test_similar_icp_at_20k_points_follows_the_oracle_and_keeps_the_cloud_on_the
     # a Fortran-ordered moving array: the first iteration's centroid is summed column by column, as np.mean does it
     A_f = pi.perform_icp(np.asfortranarray(start), fx, 3, "Similar")
     assert np.array_equal(A_f, oracle.perform_icp(np.asfortranarray(start), fx, 3, "Similar"))
+
+
+def test_get_similar_transform_by_the_device_route_equals_the_literal_host_sequence(g, oracle):
+    """The mirror's get_similar_transform on large NumPy clouds and on GPU tensors (O(N) sums on the device) against the oracle's
+    literal NumPy sequence: identical 4 x 4, for C-ordered and Fortran-ordered inputs (np.mean sums them differently)."""
+    from platymatch_amd.estimate_transform import find_transform as ft
+    rng = np.random.default_rng(5)
+    n = 20000
+    mv = np.ascontiguousarray(rng.normal(size=(3, n)) * np.array([[60.0], [40.0], [25.0]]) + 200.0)
+    R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    fx = np.ascontiguousarray(1.03 * R @ mv + rng.normal(scale=0.5, size=(3, n)) + 7.0)
+    assert n >= ft.DEVICE_MOMENTS_FROM
+    for a, b in ((mv, fx), (np.asfortranarray(mv), fx), (mv, np.asfortranarray(fx))):
+        assert np.array_equal(ft.get_similar_transform(a, b), oracle.get_similar_transform(a, b))
+    got = ft.get_similar_transform(g.nat.to_dev(mv, dev=g.dev), g.nat.to_dev(fx, dev=g.dev))
+    assert np.array_equal(got.cpu().numpy(), oracle.get_similar_transform(mv, fx))
+    small = slice(0, 500)                                                 # below the threshold: the literal host sequence
+    assert np.array_equal(ft.get_similar_transform(mv[:, small], fx[:, small]), oracle.get_similar_transform(mv[:, small], fx[:, small]))
