@@ -51,20 +51,26 @@ int pm_last_hip_error(void); /* hipError_t of the calling thread's most recent P
 
 /* ---- cloud statistics --------------------------------------------------------------------- */
 
-/* get_centroid (utils/utils.py:48-56): out[3] = mean of each coordinate row. */
+/* get_centroid (utils/utils.py:48-56): out[3] = mean of each coordinate row, in NumPy's own summation order (np.mean over
+ * the rows of the 3 x N array the widget passes: pieces of 8 192 elements, pairwise inside a piece — csrc/pm_pairwise.h), so
+ * the centroid has the reference's bits.  pm_centroid_sequential: the order np.mean takes over axis 0 of an N x 3 array
+ * (transposed=True): one point after the other. */
 size_t pm_centroid_workspace(int n);
 int pm_centroid(const double *xyz, int n, double *out3, void *ws, size_t ws_bytes, void *stream);
+int pm_centroid_sequential(const double *xyz, int n, double *out3, void *stream);
 
-/* get_mean_distance (utils/utils.py:58-75): out[1] = mean of ||p_i - p_j|| over all i < j.
- * Deterministic (fixed reduction tree); equal to the reference to ~1e-14 relative. */
+/* get_mean_distance (utils/utils.py:58-75): out[1] = np.average of [np.linalg.norm(p_i - p_j) for i < j], restated exactly:
+ * the norm as BLAS ddot's x86-64 kernels round it (fused multiply-adds), the mean in NumPy's summation order over the
+ * lexicographic pair list (pieces of 8 192, pairwise inside a piece).  Bit-identical to the reference (all fixtures).
+ * workspace: one float64 per piece (pm_mean_distance_workspace).  n <= 2 000 000. */
 size_t pm_mean_distance_workspace(int n);
 int pm_mean_distance(const double *xyz, int n, double *out1, void *ws, size_t ws_bytes, void *stream);
 
 /* The same in two steps, for a run sharded over G devices: pm_mean_distance_rows zeroes `partials`
- * (pm_mean_distance_workspace(n) bytes: one float64 per 256 x 256 tile) and fills the tile rows row_offset,
- * row_offset + row_stride, ... (rank g passes g, G); the ranks' buffers are then summed element-wise (an all-reduce:
- * every entry is non-zero on one rank only, so the sum is exact) and pm_mean_distance_finish adds the tiles in the
- * fixed order of pm_mean_distance — the result is bit-identical to the one-device call, whatever G. */
+ * (pm_mean_distance_workspace(n) bytes: one float64 per 8 192-element piece of the pair list) and fills the pieces
+ * row_offset, row_offset + row_stride, ... (rank g passes g, G); the ranks' buffers are then summed element-wise (an
+ * all-reduce: every entry is non-zero on one rank only, so the sum is exact) and pm_mean_distance_finish adds the pieces
+ * first to last as pm_mean_distance does — the result is bit-identical to the one-device call, whatever G. */
 int pm_mean_distance_rows(const double *xyz, int n, int row_offset, int row_stride, double *partials, size_t partial_bytes,
                           void *stream);
 int pm_mean_distance_finish(const double *partials, int n, double *out1, void *stream);

@@ -96,23 +96,67 @@ int pmo_set_threads(int t) {
 }
 int pmo_max_threads(void) { return omp_get_num_procs(); }
 
-/* get_mean_distance (utils/utils.py:58-75): mean of ||p_i - p_j|| over i<j.
- * The reference averages a Python list with np.average (pairwise summation);
- * this restatement sums per row then over rows — equal to ~1e-14 relative. */
+/* get_mean_distance (utils/utils.py:58-75): np.average of the list [np.linalg.norm(p_i - p_j) for i < j] — restated exactly
+ * (round 3; bit-identical to the reference on every fixture, tests/test_oracle_golden.py):
+ *   np.linalg.norm of a 3-vector = sqrt(x.dot(x)); the dot product is BLAS ddot, whose x86-64 kernels accumulate with fused
+ *   multiply-adds (established against NumPy on the build host: tests/test_oracle_golden.py pins it through the fixtures);
+ *   np.average -> np.add.reduce in pieces of 8 192 elements (np.getbufsize()), each piece summed pairwise (numpy/_core/src/
+ *   umath/loops_utils.h.src: blocks of <= 128 with eight interleaved partial sums), the pieces added first to last; / count. */
+static double np_pairwise(const double *a, long n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (long i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        long i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    long half = n / 2;
+    half -= half % 8;
+    return np_pairwise(a, half) + np_pairwise(a + half, n - half);
+}
+
 int pmo_mean_distance(const double *xyz, int n, double *out) {
     const double *X = xyz, *Y = xyz + n, *Z = xyz + 2 * (size_t)n;
-    double *rows = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
-    if (!rows) return -1;
-#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
-    for (int i = 0; i < n; ++i) {
-        double row = 0.0;
-        for (int j = i + 1; j < n; ++j) row += norm3(X[i] - X[j], Y[i] - Y[j], Z[i] - Z[j]);
-        rows[i] = row;
+    const long long P = (long long)n * (n - 1) / 2;
+    if (P <= 0) { *out = 0.0 / 0.0; return 0; }                 /* np.average([]) */
+    const long long nchunks = (P + 8191) / 8192;
+    double *piece = (double *)malloc(sizeof(double) * (size_t)nchunks);
+    if (!piece) return -1;
+#pragma omp parallel num_threads(g_threads)
+    {
+        double *buf = (double *)malloc(sizeof(double) * 8192);
+#pragma omp for schedule(dynamic, 16)
+        for (long long c = 0; c < nchunks; ++c) {
+            const long long e0 = c * 8192;
+            const long len = (long)((P - e0 < 8192) ? P - e0 : 8192);
+            /* element e0 -> (i, j): row i starts at i (n - 1) - i (i - 1) / 2 */
+            long long i = (long long)(((2.0 * n - 1.0) - sqrt(fmax((2.0 * n - 1.0) * (2.0 * n - 1.0) - 8.0 * (double)e0, 0.0))) * 0.5);
+            if (i < 0) i = 0;
+            if (i > n - 2) i = n - 2;
+            while (i < n - 2 && (i + 1) * (long long)(n - 1) - (i + 1) * i / 2 <= e0) ++i;
+            while (i > 0 && i * (long long)(n - 1) - i * (i - 1) / 2 > e0) --i;
+            long long j = i + 1 + (e0 - (i * (long long)(n - 1) - i * (i - 1) / 2));
+            for (long t = 0; t < len; ++t) {
+                const double d0 = X[i] - X[j], d1 = Y[i] - Y[j], d2 = Z[i] - Z[j];
+                buf[t] = sqrt(fma(d2, d2, fma(d1, d1, d0 * d0)));
+                if (++j >= n) { ++i; j = i + 1; }
+            }
+            piece[c] = np_pairwise(buf, len);
+        }
+        free(buf);
     }
-    double total = 0.0;
-    for (int i = 0; i < n; ++i) total += rows[i];       /* row sums added in row order: the same value for any thread count */
-    free(rows);
-    *out = total / (0.5 * (double)n * (double)(n - 1));
+    double total = piece[0];
+    for (long long c = 1; c < nchunks; ++c) total += piece[c];   /* the same value for any thread count */
+    free(piece);
+    *out = total / (double)P;
     return 0;
 }
 

@@ -54,10 +54,15 @@ def _idx(x, n, hi, name, trusted=False):
     return x
 
 
-def centroid(xyz):
+def centroid(xyz, sequential=False):
+    """Mean of each coordinate row in NumPy's own summation order (the reference's bits): pairwise pieces for the 3 x N layout,
+    one point after the other (sequential=True) for what np.mean does with an N x 3 array."""
     xyz = _cloud(xyz)
     out = _t().empty(3, dtype=_t().float64, device=xyz.device)
-    check(nat.load().pm_centroid(ptr(xyz), xyz.shape[1], ptr(out), 0, 0, nat.stream_ptr()))
+    if sequential:
+        check(nat.load().pm_centroid_sequential(ptr(xyz), xyz.shape[1], ptr(out), nat.stream_ptr()))
+    else:
+        check(nat.load().pm_centroid(ptr(xyz), xyz.shape[1], ptr(out), 0, 0, nat.stream_ptr()))
     return out
 
 

@@ -27,6 +27,7 @@ SIGNATURES = {
     "pm_last_hip_error": (_c_int, []),
     "pm_centroid_workspace": (_c_size_t, [_c_int]),
     "pm_centroid": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_centroid_sequential": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),
     "pm_mean_distance_workspace": (_c_size_t, [_c_int]),
     "pm_mean_distance": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_pca_axis_workspace": (_c_size_t, [_c_int]),

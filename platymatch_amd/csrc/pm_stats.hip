@@ -2,64 +2,240 @@
 // Reference: utils/utils.py:48-56 (get_centroid), :58-75 (get_mean_distance),
 // shape_context.py:162-165 (PCA(3).fit(detections).components_[0]).
 #include "pm_common.h"
+#include "pm_pairwise.h"
 
 namespace pm {
 
 constexpr int STAT_THREADS = 1024;
 constexpr int MD_TILE = 256;
 
-// ---- centroid: one block, fixed reduction tree --------------------------------------------------
-__global__ __launch_bounds__(STAT_THREADS) void centroid_kernel(const double *__restrict__ xyz, int n,
-                                                                double *__restrict__ out3) {
-    __shared__ double scratch[STAT_THREADS / 64];
-    for (int c = 0; c < 3; ++c) {
-        const double *row = xyz + (size_t)c * n;
-        double s = 0.0;
-        for (int i = threadIdx.x; i < n; i += STAT_THREADS) s += row[i];
-        double tot = block_sum(s, scratch);
-        if (threadIdx.x == 0) out3[c] = tot / (double)n;
-    }
-}
-
-// ---- mean pairwise distance: upper-triangle tiles, then an ordered sum of the tile partials -------
-// One thread owns point i of tile bi and walks tile bj (staged in LDS, broadcast reads).
-// Tile rows row_offset, row_offset + row_stride, ... (ranks of a sharded run interleave the rows: row bi holds T - bi tiles).
-__global__ __launch_bounds__(MD_TILE) void mean_distance_tiles(const double *__restrict__ xyz, int n,
-                                                               double *__restrict__ partial, int row_offset, int row_stride) {
-    const int bi = row_offset + blockIdx.y * row_stride, bj = blockIdx.x, T = gridDim.x;
-    if (bj < bi) return;  // partial[] for these is never read
-    __shared__ double tj[3][MD_TILE];
-    __shared__ double scratch[MD_TILE / 64];
-    const int tid = threadIdx.x;
-    const int gi = bi * MD_TILE + tid, gj0 = bj * MD_TILE;
-    for (int c = 0; c < 3; ++c) tj[c][tid] = (gj0 + tid < n) ? xyz[(size_t)c * n + gj0 + tid] : 0.0;
-    double p0 = 0, p1 = 0, p2 = 0;
-    if (gi < n) { p0 = xyz[gi]; p1 = xyz[(size_t)n + gi]; p2 = xyz[2 * (size_t)n + gi]; }
-    __syncthreads();
-    double s = 0.0;
-    const int jn = min(MD_TILE, n - gj0);
-    if (gi < n) {
-        for (int j = 0; j < jn; ++j) {
-            double d0 = p0 - tj[0][j], d1 = p1 - tj[1][j], d2 = p2 - tj[2][j];
-            double d = __builtin_sqrt((d0 * d0 + d1 * d1) + d2 * d2);
-            s += (gj0 + j > gi) ? d : 0.0;
+// ---- centroid in NumPy's own summation order (round 3) ------------------------------------------------------------------
+// get_centroid (utils/utils.py:48-56) is np.mean(detections[:3, :], 1) for the 3 x N layout the widget passes: each row goes
+// through np.add.reduce in pieces of 8 192 elements, a piece summed pairwise (csrc/pm_pairwise.h), the pieces added first to
+// last, divided by N — restated here so that the centroid (hence every local frame's z axis) has the reference's bits.
+// Wave r owns coordinate row r; in a full piece lane l adds up leaf l (128 consecutive elements, eight interleaved partial
+// sums) and the 64 leaf sums meet in a balanced shuffle tree; the partial last piece takes the plan / leaf / combine route.
+// sequential != 0: the N x 3 layout (transposed=True) — np.mean over axis 0 adds the points one after the other.
+__global__ __launch_bounds__(192) void centroid_kernel(const double *__restrict__ xyz, int n, int sequential, double *__restrict__ out3) {
+    __shared__ int s_off[3][160];
+    __shared__ int s_cf[3][4];
+    __shared__ double s_leaf[3][160];
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const double *row = xyz + (size_t)r * n;
+    double acc = 0.0;
+    if (sequential) {
+        if (lane == 0) {
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+                const double t0 = row[i], t1 = row[i + 1], t2 = row[i + 2], t3 = row[i + 3], t4 = row[i + 4], t5 = row[i + 5], t6 = row[i + 6], t7 = row[i + 7];
+                acc += t0; acc += t1; acc += t2; acc += t3; acc += t4; acc += t5; acc += t6; acc += t7;
+            }
+            for (; i < n; ++i) acc += row[i];
+            out3[r] = acc / (double)n;
         }
+        return;
     }
-    double tot = block_sum(s, scratch);
-    if (tid == 0) partial[(size_t)bi * T + bj] = tot;
+    for (int c0 = 0; c0 < n; c0 += PM_PW_CHUNK) {
+        const int len = min(PM_PW_CHUNK, n - c0);
+        double piece;
+        if (len == PM_PW_CHUNK) {
+            double keep = pm_pw_leaf_sum(row + c0 + lane * PM_PW_LEAF, PM_PW_LEAF);
+#pragma unroll
+            for (int st = 1; st < 64; st <<= 1) keep = keep + __shfl_down(keep, st, 64);
+            piece = keep;
+        } else {
+            if (lane == 0) s_cf[r][3] = pm_pw_plan(len, s_off[r], 160, s_cf[r], 4);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const int leaves = s_cf[r][3];
+            for (int lf = lane; lf < leaves; lf += 64) s_leaf[r][lf] = pm_pw_leaf_sum(row + c0 + s_off[r][lf], s_off[r][lf + 1] - s_off[r][lf]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            piece = (lane == 0) ? pm_pw_combine(s_leaf[r], s_off[r], s_cf[r], 1, len) : 0.0;
+        }
+        acc = (c0 == 0) ? piece : acc + piece;           // (meaningful in lane 0)
+    }
+    if (lane == 0) out3[r] = acc / (double)n;
 }
 
-__global__ __launch_bounds__(STAT_THREADS) void mean_distance_final(const double *__restrict__ partial, int T, int n,
-                                                                    double *__restrict__ out1) {
-    __shared__ double scratch[STAT_THREADS / 64];
-    double s = 0.0;
-    const int total = T * T;
-    for (int t = threadIdx.x; t < total; t += STAT_THREADS) {
-        int bi = t / T, bj = t - bi * T;
-        if (bj >= bi) s += partial[t];
+// ---- mean pairwise distance, in the reference's own arithmetic (round 3) --------------------------------------------------
+// get_mean_distance (utils/utils.py:58-75) appends np.linalg.norm(p_i - p_j) for i < j in lexicographic order to a list and
+// takes np.average of it.  Restated exactly:
+//   element   np.linalg.norm of a 3-vector is sqrt(x.dot(x)), BLAS ddot, whose x86-64 kernels accumulate with fused
+//             multiply-adds: sqrt(fma(d2, d2, fma(d1, d1, d0 * d0)))   (verified against NumPy on the reference's fixtures);
+//   mean      np.add.reduce over the P = N(N-1)/2 elements in pieces of 8 192 (np.getbufsize()), every piece summed pairwise
+//             (csrc/pm_pairwise.h), the piece sums added first to last, divided by P.
+// The value equals the reference's bit for bit (tests: all twelve fixture clouds), so the ring radii — mean distance times the
+// logspace edges — are the reference's by construction.  A wave owns a piece: lanes <-> 64 consecutive elements (coalesced
+// loads of p_j, p_i mostly wave-uniform), a 128-element leaf is two such steps, NumPy's eight interleaved partial sums run
+// through the lanes l = 8 q + j as a chain over q (shuffles), the 64 leaf sums of a full piece meet in a balanced tree.  The
+// last, partial piece takes the general plan / leaf / combine route of pm_pairwise.h.  Piece sums go to `partial[]`; a second
+// launch adds them one after the other (staged through LDS) and divides.
+constexpr int MDX_WAVES = 4;
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+__device__ __forceinline__ long long md_row_start(long long i, long long n) { return i * (n - 1) - i * (i - 1) / 2; }
+
+__device__ __forceinline__ void md_locate(long long e, int n, int &i, int &j) {
+    const double t = 2.0 * n - 1.0;
+    long long ii = (long long)((t - __builtin_sqrt(__builtin_fmax(t * t - 8.0 * (double)e, 0.0))) * 0.5);
+    ii = ii < 0 ? 0 : (ii > n - 2 ? n - 2 : ii);
+    while (ii < n - 2 && md_row_start(ii + 1, n) <= e) ++ii;
+    while (ii > 0 && md_row_start(ii, n) > e) --ii;
+    i = (int)ii;
+    j = (int)(ii + 1 + (e - md_row_start(ii, n)));
+}
+
+__device__ __forceinline__ double md_dist(const double *__restrict__ P0, const double *__restrict__ P1, const double *__restrict__ P2,
+                                          int i, int j) {
+    const double d0 = P0[i] - P0[j], d1 = P1[i] - P1[j], d2 = P2[i] - P2[j];
+    return __builtin_sqrt(__builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0)));
+}
+
+__device__ __forceinline__ void md_advance(int &i, int &j, int by, int n) {
+    j += by;
+    while (j >= n && i < n - 2) { const int over = j - n; ++i; j = i + 1 + over; }
+}
+
+__global__ __launch_bounds__(MDX_WAVES * 64) void mean_distance_chunks(const double *__restrict__ xyz, int n, long long P, int nchunks,
+                                                                       int first, int stride, double *__restrict__ partial) {
+    __shared__ int s_off[MDX_WAVES][160];
+    __shared__ int s_cf[MDX_WAVES][4];
+    __shared__ double s_leaf[MDX_WAVES][160];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double *P0 = xyz, *P1 = xyz + (size_t)n, *P2 = xyz + 2 * (size_t)n;
+    const long long waves_total = (long long)gridDim.x * MDX_WAVES;
+    // (this rank's pieces first, first + stride, ...; the last piece of the list — the only one that can be partial — goes first)
+    const long long mine = (nchunks - 1 - first) / stride + 1;
+    for (long long k = (long long)blockIdx.x * MDX_WAVES + wave; k < mine; k += waves_total) {
+        const int c = first + (int)(mine - 1 - k) * stride;
+        const long long e0 = (long long)c * PM_PW_CHUNK;
+        const int len = (int)((P - e0 < PM_PW_CHUNK) ? P - e0 : PM_PW_CHUNK);
+        double chunk_sum;
+        if (len == PM_PW_CHUNK) {
+            // Lanes in element order within a 16-lane row pair up as (q, parity): lane_in_row = 2 q + p, so that accumulator
+            // r[acc] (acc = 2 * row + p ... see elem_of) runs through q = 0..7 by shifts of TWO lanes inside the row: DPP moves
+            // (VALU), and a lane whose source lies outside the row keeps its own value — with the addend zeroed for q = 0 every
+            // step is an unconditional add (v <- shifted(v) + term): finished lanes recompute the value they already hold.
+            // (Tried: __shfl_up(v, 8) chains — LDS permutes, 5.7 ms per 50 000-point cloud; eight leaves side by side with one
+            // accumulator per lane and no cross-lane traffic — uncoalesced loads, 6.9 ms.)
+            const int row = lane >> 4, lir = lane & 15, q = lir >> 1, par = lir & 1;
+            const int acc_id = 2 * row + par;                        // which of NumPy's eight partial sums this lane feeds
+            int i, j;
+            md_locate(e0 + 8 * q + acc_id, n, i, j);                 // element 8 q + acc of the 64-element half leaf
+            double keep = 0.0;
+            for (int leaf = 0; leaf < 64; ++leaf) {
+                const double a = md_dist(P0, P1, P2, i, j);
+                md_advance(i, j, 64, n);
+                const double b = md_dist(P0, P1, P2, i, j);
+                md_advance(i, j, 64, n);
+                const double a_eff = q == 0 ? 0.0 : a, b_eff = q == 0 ? 0.0 : b;
+                double v = a;
+#pragma unroll
+                for (int step = 1; step < 8; ++step) v = dpp_f64<0x112>(v) + a_eff;      // row_shr:2 — lane l reads lane l - 2
+                const double w = dpp_f64<0x10e>(v);                  // row_shl:14 — q = 0 reads q = 7 of its accumulator
+                v = q == 0 ? w + b : v;
+#pragma unroll
+                for (int step = 1; step < 8; ++step) v = dpp_f64<0x112>(v) + b_eff;
+                // r[acc] now sits in lanes (q = 7): lane_in_row 14 + p of row `row`: acc 0, 1 in row 0, ... 6, 7 in row 3
+                const double s01 = v + dpp_f64<0x101>(v);            // row_shl:1 — lane 14 reads lane 15: r[2 row] + r[2 row + 1]
+                const double ls = (readlane_f64(s01, 14) + readlane_f64(s01, 30)) + (readlane_f64(s01, 46) + readlane_f64(s01, 62));
+                if (lane == leaf) keep = ls;
+            }
+#pragma unroll
+            for (int st = 1; st < 64; st <<= 1) keep = keep + __shfl_down(keep, st, 64);   // balanced tree: left + right
+            chunk_sum = keep;                                        // valid in lane 0
+        } else {
+            // the partial last piece: plan its leaves (lane 0), leaf sums by all lanes, tree by lane 0
+            if (lane == 0) {
+                const int leaves = pm_pw_plan(len, s_off[wave], 160, s_cf[wave], 4);
+                s_cf[wave][3] = leaves;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const int leaves = s_cf[wave][3];
+            for (int lf = lane; lf < leaves; lf += 64) {
+                const int o = s_off[wave][lf], ll = s_off[wave][lf + 1] - o;
+                int i, j;
+                md_locate(e0 + o, n, i, j);
+                double res;
+                if (ll < 8) {
+                    res = 0.0;
+                    for (int t = 0; t < ll; ++t) { res += md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
+                } else {
+                    double r[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { r[u] = md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
+                    int t = 8;
+                    for (; t < ll - (ll % 8); t += 8) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { r[u] += md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
+                    }
+                    res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                    for (; t < ll; ++t) { res += md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
+                }
+                s_leaf[wave][lf] = res;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            chunk_sum = 0.0;
+            if (lane == 0) chunk_sum = pm_pw_combine(s_leaf[wave], s_off[wave], s_cf[wave], 1, len);
+        }
+        if (lane == 0) partial[c] = chunk_sum;
     }
-    double tot = block_sum(s, scratch);
-    if (threadIdx.x == 0) out1[0] = tot / (0.5 * (double)n * (double)(n - 1));
+}
+
+// the piece sums, one after the other (np.add.reduce across its buffer-sized pieces), divided by P
+__global__ __launch_bounds__(256) void mean_distance_final(const double *__restrict__ partial, int nchunks, long long P,
+                                                           double *__restrict__ out1) {
+    constexpr int CH = 2048;
+    __shared__ double buf[2][CH];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < CH; e += 256) buf[0][e] = (e < nchunks) ? partial[e] : 0.0;
+    __syncthreads();
+    double acc = 0.0;
+    int b = 0;
+    for (int c0 = 0; c0 < nchunks; c0 += CH, b ^= 1) {
+        if (tid >= 64) {
+            for (int e = tid - 64; e < CH; e += 192) buf[b ^ 1][e] = (c0 + CH + e < nchunks) ? partial[c0 + CH + e] : 0.0;
+        } else if (tid == 0) {
+            const int cnt = min(CH, nchunks - c0);
+            const double *t = buf[b];
+            int e = 0;
+            if (c0 == 0) { acc = t[0]; e = 1; }
+            // 32 LDS reads in flight while the previous 32 values are added (the additions stay one after the other)
+            if (e + 32 <= cnt) {
+                double u[32];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) u[k] = t[e + k];
+                e += 32;
+                for (; e + 32 <= cnt; e += 32) {
+                    double w[32];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) w[k] = t[e + k];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) acc += u[k];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) u[k] = w[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 32; ++k) acc += u[k];
+            }
+            for (; e < cnt; ++e) acc += t[e];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) out1[0] = acc / (double)P;
 }
 
 // ---- PCA axis: centred covariance in one block, 3x3 symmetric eigen-solve by cyclic Jacobi --------
@@ -150,44 +326,59 @@ size_t pm_centroid_workspace(int) { return 0; }
 
 int pm_centroid(const double *xyz, int n, double *out3, void *, size_t, void *stream) {
     if (!xyz || !out3 || n <= 0) return PM_ERR_INVALID_ARG;
-    pm::centroid_kernel<<<1, pm::STAT_THREADS, 0, (hipStream_t)stream>>>(xyz, n, out3);
+    pm::centroid_kernel<<<1, 192, 0, (hipStream_t)stream>>>(xyz, n, 0, out3);
     return pm::launch_status();
 }
 
+int pm_centroid_sequential(const double *xyz, int n, double *out3, void *stream) {
+    if (!xyz || !out3 || n <= 0) return PM_ERR_INVALID_ARG;
+    pm::centroid_kernel<<<1, 192, 0, (hipStream_t)stream>>>(xyz, n, 1, out3);
+    return pm::launch_status();
+}
+
+static long long md_pairs(int n) { return (long long)n * (n - 1) / 2; }
+static int md_chunks(int n) { return (int)((md_pairs(n) + PM_PW_CHUNK - 1) / PM_PW_CHUNK); }
+
 size_t pm_mean_distance_workspace(int n) {
-    if (n <= 0) return 0;
-    size_t T = ((size_t)n + pm::MD_TILE - 1) / pm::MD_TILE;
-    return T * T * sizeof(double);
+    if (n < 2) return 0;
+    return ((size_t)md_chunks(n) * sizeof(double) + 255) / 256 * 256;
+}
+
+static int md_launch(const double *xyz, int n, int first, int stride, double *partial, hipStream_t s) {
+    const int nchunks = md_chunks(n);
+    if (first >= nchunks) return PM_OK;
+    const long long mine = (nchunks - 1 - first) / stride + 1;
+    const long long want = (mine + pm::MDX_WAVES - 1) / pm::MDX_WAVES;
+    const int blocks = (int)(want < 8192 ? want : 8192);             // (waves stride over the pieces beyond that)
+    pm::mean_distance_chunks<<<blocks, pm::MDX_WAVES * 64, 0, s>>>(xyz, n, md_pairs(n), nchunks, first, stride, partial);
+    return pm::launch_status();
 }
 
 int pm_mean_distance(const double *xyz, int n, double *out1, void *ws, size_t ws_bytes, void *stream) {
     if (!xyz || !out1 || n < 2) return PM_ERR_INVALID_ARG;
+    if (n > 2000000) return PM_ERR_UNSUPPORTED;                      // (the piece count must fit an int: N(N-1)/2 / 8192)
     if (!ws || ws_bytes < pm_mean_distance_workspace(n)) return PM_ERR_WORKSPACE;
-    const int T = (n + pm::MD_TILE - 1) / pm::MD_TILE;
     hipStream_t s = (hipStream_t)stream;
-    pm::mean_distance_tiles<<<dim3(T, T), pm::MD_TILE, 0, s>>>(xyz, n, (double *)ws, 0, 1);
-    pm::mean_distance_final<<<1, pm::STAT_THREADS, 0, s>>>((const double *)ws, T, n, out1);
+    const int rc = md_launch(xyz, n, 0, 1, (double *)ws, s);
+    if (rc != PM_OK) return rc;
+    pm::mean_distance_final<<<1, 256, 0, s>>>((const double *)ws, md_chunks(n), md_pairs(n), out1);
     return pm::launch_status();
 }
 
 int pm_mean_distance_rows(const double *xyz, int n, int row_offset, int row_stride, double *partials, size_t partial_bytes,
                           void *stream) {
     if (!xyz || !partials || n < 2 || row_offset < 0 || row_stride < 1 || row_offset >= row_stride) return PM_ERR_INVALID_ARG;
+    if (n > 2000000) return PM_ERR_UNSUPPORTED;
     if (partial_bytes < pm_mean_distance_workspace(n)) return PM_ERR_WORKSPACE;
-    const int T = (n + pm::MD_TILE - 1) / pm::MD_TILE;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(partials, 0, pm_mean_distance_workspace(n), s) != hipSuccess) return pm::launch_status();
-    if (row_offset < T) {
-        const int rows = (T - row_offset + row_stride - 1) / row_stride;
-        pm::mean_distance_tiles<<<dim3(T, rows), pm::MD_TILE, 0, s>>>(xyz, n, partials, row_offset, row_stride);
-    }
-    return pm::launch_status();
+    return md_launch(xyz, n, row_offset, row_stride, partials, s);
 }
 
 int pm_mean_distance_finish(const double *partials, int n, double *out1, void *stream) {
     if (!partials || !out1 || n < 2) return PM_ERR_INVALID_ARG;
-    const int T = (n + pm::MD_TILE - 1) / pm::MD_TILE;
-    pm::mean_distance_final<<<1, pm::STAT_THREADS, 0, (hipStream_t)stream>>>(partials, T, n, out1);
+    if (n > 2000000) return PM_ERR_UNSUPPORTED;
+    pm::mean_distance_final<<<1, 256, 0, (hipStream_t)stream>>>(partials, md_chunks(n), md_pairs(n), out1);
     return pm::launch_status();
 }
 

@@ -21,9 +21,24 @@ def _cloud_3xn(detections, transposed):
     return t[:3, :].contiguous()
 
 
+def _mean_runs_sequentially(detections, transposed):
+    """How np.mean adds the points up depends on the memory layout: NumPy's reduction loops along the axis with the smaller
+    stride; if that is the point axis the sum is pairwise (pieces of 8 192, csrc/pm_pairwise.h), otherwise the points are added
+    one after the other.  NumPy input: its strides decide; torch tensors count as row-major."""
+    import numpy as np
+    if nat.is_torch(detections):
+        s0, s1 = detections.stride(0), detections.stride(1)
+    else:
+        a = np.asarray(detections)
+        s0, s1 = abs(a.strides[0]), abs(a.strides[1])
+    point_stride, coord_stride = (s0, s1) if transposed else (s1, s0)
+    return not (point_stride <= coord_stride)
+
+
 def get_centroid(detections, transposed=True):
-    """utils/utils.py:48-56 -> [1, 3] if transposed else [3, 1]."""
-    c = K.centroid(_cloud_3xn(detections, transposed))
+    """utils/utils.py:48-56 -> [1, 3] if transposed else [3, 1].  The reference's bits: np.mean's own summation order (pairwise
+    for the 3 x N layout the widget passes, point after point for N x 3)."""
+    c = K.centroid(_cloud_3xn(detections, transposed), sequential=_mean_runs_sequentially(detections, transposed))
     c = c.reshape(1, 3) if transposed else c.reshape(3, 1)
     return nat.like_input(c, detections)
 

@@ -42,7 +42,7 @@ def test_workspace_queries_and_argument_errors(lib_path):
     """Host-side behaviour that needs no device: sizes, and rejection before anything is enqueued."""
     from platymatch_amd import _native
     lib = _native.load()
-    assert lib.pm_mean_distance_workspace(1000) == 4 * 4 * 8
+    assert lib.pm_mean_distance_workspace(1000) == 512           # one float64 per 8 192-element piece of the 499 500 pairs (61), padded to 256 B
     assert lib.pm_icp_workspace(50000, 50000) > 50000 * 4
     assert lib.pm_icp_workspace(0, 10) == 0
     assert lib.pm_centroid(None, 10, None, None, 0, None) == -1

@@ -48,11 +48,11 @@ def test_statistics(gpu, oracle, name):
     for key in ("moving", "fixed"):
         x = gpu.d(d[key])
         c, md, x0 = gpu.K.centroid(x), gpu.K.mean_distance(x), gpu.K.pca_axis(x)
-        assert relerr(c.cpu().numpy(), oracle.get_centroid(d[key], transposed=False).ravel()) < 1e-14
-        assert abs(md.item() / oracle.get_mean_distance(d[key], transposed=False) - 1) < 1e-14   # (observed: <= 4e-16; the edge guard assumes 4e-14)
+        assert np.array_equal(c.cpu().numpy(), oracle.get_centroid(d[key], transposed=False).ravel())   # np.mean's bits (round 3)
+        assert md.item() == oracle.get_mean_distance(d[key], transposed=False)                    # the reference's bits (round 3: NumPy's order on the device)
         assert np.abs(x0.cpu().numpy() - oracle.pca_axis(d[key].T)).max() < 1e-12                # (observed: <= 9e-14; the edge guard assumes 1e-12)
-    assert abs(gpu.K.mean_distance(gpu.d(d["moving"])).item() / d["mean_dist_m"] - 1) < 1e-14   # vs the reference itself
-    assert abs(gpu.K.mean_distance(gpu.d(d["fixed"])).item() / d["mean_dist_f"] - 1) < 1e-14
+    assert gpu.K.mean_distance(gpu.d(d["moving"])).item() == float(d["mean_dist_m"])          # vs the reference itself: identical
+    assert gpu.K.mean_distance(gpu.d(d["fixed"])).item() == float(d["mean_dist_f"])
     assert np.abs(gpu.K.pca_axis(gpu.d(d["fixed"])).cpu().numpy() - d["x0_f"]).max() < 1e-12
     assert np.abs(gpu.K.pca_axis(gpu.d(d["moving"])).cpu().numpy() - d["x0_m"]).max() < 1e-12
 
@@ -77,11 +77,12 @@ def test_mean_distance_shared_out_over_ranks_is_bit_identical(gpu):
 
 
 def test_statistics_ragged_sizes(gpu, oracle):
-    for n in (2, 3, 63, 64, 65, 255, 256, 257, 1000, 4097):
+    for n in (2, 3, 63, 64, 65, 255, 256, 257, 1000, 4097, 8192, 8193, 20011):
         mv, _, _ = synth_pair(n, n)
         x = gpu.d(mv)
-        assert relerr(gpu.K.centroid(x).cpu().numpy(), mv.mean(1)) < 1e-14
-        assert abs(gpu.K.mean_distance(x).item() / oracle.get_mean_distance(mv, transposed=False) - 1) < 1e-14
+        assert np.array_equal(gpu.K.centroid(x).cpu().numpy(), mv.mean(1))
+        assert np.array_equal(gpu.K.centroid(x, sequential=True).cpu().numpy(), np.ascontiguousarray(mv.T).mean(0))   # the N x 3 layout's order
+        assert gpu.K.mean_distance(x).item() == oracle.get_mean_distance(mv, transposed=False)
 
 
 # ------------------------------------------------------------------------------------------------ shape context
@@ -391,9 +392,14 @@ def test_utils_mirror(gpu, oracle, micro):
     from platymatch_amd.utils.utils import get_centroid, get_error, get_mean_distance
     P, Q = micro["fit_moving"], micro["fit_fixed"]
     assert get_centroid(P, transposed=False).shape == (3, 1) and get_centroid(P.T, transposed=True).shape == (1, 3)
-    assert relerr(get_centroid(P, transposed=False), micro["centroid_F"]) < 1e-15
+    assert np.array_equal(get_centroid(P, transposed=False), micro["centroid_F"])                 # the reference's bits
+    assert np.array_equal(get_centroid(P.T, transposed=True), micro["centroid_T"])               # the fixture's call: a transposed VIEW (summed pairwise)
+    PT = np.ascontiguousarray(np.random.default_rng(0).normal(size=(9001, 3)) * 40 + 7)            # a C-ordered N x 3 array: point after point
+    assert np.array_equal(get_centroid(PT, transposed=True), np.mean(PT[:, :3], 0, keepdims=True))
+    assert np.array_equal(get_centroid(PT.T, transposed=False), np.mean(PT.T[:3, :], 1, keepdims=True))   # its view as 3 x N: the same order
+    assert np.array_equal(get_centroid(np.ascontiguousarray(PT.T), transposed=False), np.mean(np.ascontiguousarray(PT.T), 1, keepdims=True))
     np.testing.assert_array_almost_equal(get_centroid(micro["cube"], transposed=True), [[0.5, 0.5, 0.5]])   # reference test_utils.py
-    assert abs(get_mean_distance(P, transposed=False) / micro["mean_distance"] - 1) < 1e-14
+    assert get_mean_distance(P, transposed=False) == float(micro["mean_distance"])
     assert abs(get_error(P, Q) / micro["error_PQ"] - 1) < 1e-14
     assert get_error(None, None) is None
     four = np.vstack([P, np.arange(40.0)[None]])

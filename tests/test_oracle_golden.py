@@ -29,7 +29,7 @@ def test_micro_chi2_and_fits(oracle, micro):
     assert np.array_equal(oracle.get_centroid(P, transposed=False), micro["centroid_F"])
     assert np.array_equal(oracle.get_centroid(P.T, transposed=True), micro["centroid_T"])
     np.testing.assert_array_almost_equal(oracle.get_centroid(micro["cube"], transposed=True), [[0.5, 0.5, 0.5]])  # _tests/test_utils.py
-    assert abs(oracle.get_mean_distance(P, transposed=False) / micro["mean_distance"] - 1) < 1e-14
+    assert oracle.get_mean_distance(P, transposed=False) == micro["mean_distance"]          # NumPy's summation order, BLAS's fused norm: the bits
 
 
 def test_micro_degenerate_cloud(oracle, micro):
@@ -58,8 +58,8 @@ def test_scenario_statistics(oracle, scenario):
     name, d = scenario
     mv, fx = d["moving"], d["fixed"]
     assert np.array_equal(oracle.get_centroid(mv, transposed=False), d["centroid_m"])
-    assert abs(oracle.get_mean_distance(mv, transposed=False) / d["mean_dist_m"] - 1) < 1e-14
-    assert abs(oracle.get_mean_distance(fx, transposed=False) / d["mean_dist_f"] - 1) < 1e-14
+    assert oracle.get_mean_distance(mv, transposed=False) == d["mean_dist_m"]              # bit for bit (round 3)
+    assert oracle.get_mean_distance(fx, transposed=False) == d["mean_dist_f"]
     assert np.abs(oracle.pca_axis(mv.T) - d["x0_m"]).max() < 1e-12      # sklearn PCA axis incl. sign convention
     assert np.abs(oracle.pca_axis(fx.T) - d["x0_f"]).max() < 1e-12
 
