@@ -123,9 +123,9 @@ int pm_shape_context(const double *xyz, int n, int row0, int nrows, const double
  * which that permutation does not hold exactly (on a sector edge or pole of the frame) are recomputed by pm_shape_context's
  * kernel inside the same call.  Outputs are identical to pm_shape_context's in every case.
  *   edge_guard2  (device, may be NULL) two uint32 counters of (point, neighbour) pairs whose bin depends on the cloud statistics
- *                beyond the accuracy they are known to: [0] distance within 4e-14 (relative) of a ring radius — the mean
- *                pairwise distance agrees with the reference's to 1e-14 —, [1] azimuth within 1e-12 / sin(angle(axis, z)) of a
- *                sector edge — the PCA axis agrees to 1e-12.  Zero for generic data: "the reference's histograms" then holds by
+ *                beyond the accuracy they are known to: [1] azimuth within 1e-12 / sin(angle(axis, z)) of a sector edge — the
+ *                PCA axis agrees with sklearn's to 1e-12 —, [0] distance within 4e-14 (relative) of a ring radius (informative
+ *                since pm_mean_distance returns the reference's bits: a caller's own mean distance may not).  Zero for generic data: "the reference's histograms" then holds by
  *                construction for this call, not only by the fixtures.
  * workspace: pm_shape_context_workspace(nrows) bytes, 256-byte aligned (frames, thresholds, per-tile flags, counts). */
 size_t pm_shape_context_workspace(int nrows);
