@@ -185,8 +185,9 @@ _SIDE_STREAMS = {}
 _SIDE_LOCK = None
 
 
-def side_stream(device, key):
-    """A side stream of `device` that PERSISTS across calls, one per `key`.  torch's caching allocator keeps freed blocks per
+def side_stream(device, key, priority=0):
+    """A side stream of `device` that PERSISTS across calls, one per `key` (priority -1: its kernels are dispatched ahead of
+    normal-priority streams' remaining workgroups).  torch's caching allocator keeps freed blocks per
     stream: a stream created afresh for every registration (or every hypothesis) can reuse nothing, every large buffer is a new
     hipMalloc (22 ms per GB on this pool) until memory runs out and the whole cache is flushed — measured as a batch of 64
     registrations paying ~13 s of allocation, and every second 50 000 x 47 000 registration taking 6 s instead of 1.5 s."""
@@ -196,11 +197,11 @@ def side_stream(device, key):
     if _SIDE_LOCK is None:
         _SIDE_LOCK = threading.Lock()
     dev = torch.device(device)
-    k = (dev.index if dev.index is not None else torch.cuda.current_device(), key)
+    k = (dev.index if dev.index is not None else torch.cuda.current_device(), key, int(priority))
     with _SIDE_LOCK:
         s = _SIDE_STREAMS.get(k)
         if s is None:
-            s = _SIDE_STREAMS[k] = torch.cuda.Stream(device=dev)
+            s = _SIDE_STREAMS[k] = torch.cuda.Stream(device=dev, priority=int(priority))
         return s
 
 

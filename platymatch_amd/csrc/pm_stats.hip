@@ -213,23 +213,13 @@ __global__ __launch_bounds__(256) void mean_distance_final(const double *__restr
             const double *t = buf[b];
             int e = 0;
             if (c0 == 0) { acc = t[0]; e = 1; }
-            // 32 LDS reads in flight while the previous 32 values are added (two register sets in turn, no copies; the additions
-            // stay one after the other)
-            if (e + 32 <= cnt) {
-                double u[32], w[32];
+            // batches of 32 LDS reads, then their 32 additions one after the other: 12 cycles per addition, within a third of
+            // the dependent float64 add's latency (software-pipelined variants measured slower: 0.96 / 1.13 ms against 0.79 ms
+            // for the 152 588 piece sums of a 50 000-point cloud)
+            for (; e + 32 <= cnt; e += 32) {
+                double u[32];
 #pragma unroll
                 for (int k = 0; k < 32; ++k) u[k] = t[e + k];
-                e += 32;
-                for (; e + 64 <= cnt; e += 64) {
-#pragma unroll
-                    for (int k = 0; k < 32; ++k) w[k] = t[e + k];
-#pragma unroll
-                    for (int k = 0; k < 32; ++k) acc += u[k];
-#pragma unroll
-                    for (int k = 0; k < 32; ++k) u[k] = t[e + 32 + k];
-#pragma unroll
-                    for (int k = 0; k < 32; ++k) acc += w[k];
-                }
 #pragma unroll
                 for (int k = 0; k < 32; ++k) acc += u[k];
             }

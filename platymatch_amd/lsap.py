@@ -508,6 +508,9 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
     return out
 
 
+PIPELINED_PRIORITY = -1
+
+
 def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False, ready=None):
     """The widget's eight assignments (_dock_widget.py:604-611) for U8 [8, N, M] on the GPU: hypotheses 11, 12, 13, 14 are
     solved (four host threads drive their core solves and kernels concurrently), each together with its twin (22, 21, 24,
@@ -518,7 +521,10 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
     been written (_kernels.chi2_cost8_frame1_by_pairings): its solve starts then, while later pairings are still being built.
     (Measured at 50 000 nuclei, twice: no gain.  Before the auction warm start the three wrong-frame hypotheses needed the same
     ~2.8 s each, so the last one built decided (4.5 s against 4.0 s); with it the solves are short but made of dense passes
-    that queue behind the cost kernel (2.2 s against 1.8 s).  The driver does not use it.)"""
+    that queue behind the cost kernel (2.2 s against 1.8 s).  Round 3 gave the solver's streams priority over the cost
+    kernel's (PIPELINED_PRIORITY, tools/pipelined_assign_probe.py): no change, 2.14-2.32 s against 1.61-1.98 s back to back
+    (profiles/r03_pipelined_probe.txt) — the cost kernel's resident workgroups hold every CU for the length of a pairing.
+    The driver does not use it.)"""
     torch = nat.torch_mod()
     n, m = U8.shape[1], U8.shape[2]
     out = [None] * 8
@@ -538,7 +544,8 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
 
     def pair(h):
         twin = [t for t, s in TWINS.items() if s == h][0]
-        stream = nat.side_stream(U8.device, ("pair", caller, h))      # persistent: the allocator's cache is per stream
+        # persistent: the allocator's cache is per stream; pipelined behind the cost build the dense passes must get in front of it
+        stream = nat.side_stream(U8.device, ("pair", caller, h), priority=PIPELINED_PRIORITY if ready is not None else 0)
         with torch.cuda.device(U8.device), torch.cuda.stream(stream):
             if ready is not None:
                 stream.wait_event(ready[h])
