@@ -396,11 +396,6 @@ struct GridSearch {
         }
     }
 
-    // The same answer when a candidate at squared distance bS is already known (ICP: the previous iteration's match): every
-    // point that could beat or tie it lies within sqrt(bS) of the query, hence in the cells the box query +- rad covers
-    // (the point -> cell map is monotone per axis, so no slack beyond rad >= the true distance is needed).  The box is
-    // ny * nz runs of x-adjacent cells; lanes share the runs (several lanes per run while there are fewer runs than lanes).
-    // Returns false (nothing scanned) if the box has more than GR_BALL_RUNS runs: rings() is the better plan then.
     // candidates of up to three index ranges [a_b, e_b) (stride `step` each) as ONE sequence, GR_FLAT records in flight at a time: a
     // lane that owns several runs of cells pays one round trip per GR_FLAT candidates instead of one (or more) per run
     __device__ __forceinline__ void scan3(int a0, int e0, int a1, int e1, int a2, int e2, int lg) {     // stride 1 << lg
@@ -594,8 +589,8 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
     // workgroup barrier; the workgroup whose add came last reads with L1-bypassing loads — no fence, no waiting):
     const int leaf0 = blockIdx.x * LPB;
     const int mine = min(LPB, a.leaves - leaf0);        // leaves of this workgroup that exist
-    if (tid < LPB * IT_SLOTS) {
-        const int lf = tid / IT_SLOTS, k = tid - lf * IT_SLOTS;
+    for (int e = tid; e < LPB * IT_SLOTS; e += 256) {
+        const int lf = e / IT_SLOTS, k = e - lf * IT_SLOTS;
         if (lf < mine) {
             double acc = 0.0;
 #pragma unroll
@@ -1020,7 +1015,11 @@ int icp_iteration(bool first, double *mov, int n, const double *fix, int m, cons
     // first iteration: nothing bounds the search, 32 lanes per point walk the rings; afterwards the previous match does
     // and 8 or 4 lanes per point (4 or 8 leaves per workgroup) are plenty for the few cells left
     if (first) icp_iter_kernel<GR_LANES, true><<<(n + 256 / GR_LANES - 1) / (256 / GR_LANES), 256, 0, s>>>(a);
+#ifdef PM_GR_TRY_LANES      // (tuning builds: tools/scripts)
+    else if (n >= GR_ITER_FEW_LANES_FROM) icp_iter_kernel<PM_GR_TRY_LANES, false><<<(n + 256 / PM_GR_TRY_LANES - 1) / (256 / PM_GR_TRY_LANES), 256, 0, s>>>(a);
+#else
     else if (n >= GR_ITER_FEW_LANES_FROM) icp_iter_kernel<4, false><<<(n + 63) / 64, 256, 0, s>>>(a);
+#endif
     else icp_iter_kernel<8, false><<<(n + 31) / 32, 256, 0, s>>>(a);
     return launch_status();
 }

@@ -7,7 +7,6 @@
 namespace pm {
 
 constexpr int STAT_THREADS = 1024;
-constexpr int MD_TILE = 256;
 
 // ---- centroid in NumPy's own summation order (round 3) ------------------------------------------------------------------
 // get_centroid (utils/utils.py:48-56) is np.mean(detections[:3, :], 1) for the 3 x N layout the widget passes: each row goes
@@ -66,11 +65,11 @@ __global__ __launch_bounds__(192) void centroid_kernel(const double *__restrict_
 //   mean      np.add.reduce over the P = N(N-1)/2 elements in pieces of 8 192 (np.getbufsize()), every piece summed pairwise
 //             (csrc/pm_pairwise.h), the piece sums added first to last, divided by P.
 // The value equals the reference's bit for bit (tests: all twelve fixture clouds), so the ring radii — mean distance times the
-// logspace edges — are the reference's by construction.  A wave owns a piece: lanes <-> 64 consecutive elements (coalesced
-// loads of p_j, p_i mostly wave-uniform), a 128-element leaf is two such steps, NumPy's eight interleaved partial sums run
-// through the lanes l = 8 q + j as a chain over q (shuffles), the 64 leaf sums of a full piece meet in a balanced tree.  The
-// last, partial piece takes the general plan / leaf / combine route of pm_pairwise.h.  Piece sums go to `partial[]`; a second
-// launch adds them one after the other (staged through LDS) and divides.
+// logspace edges — are the reference's by construction.  A wave owns a piece: its lanes hold 64 consecutive elements (loads of
+// p_j contiguous within a row of the pair list, p_i mostly wave-uniform), a 128-element leaf is two such steps, NumPy's eight
+// interleaved partial sums run as chains through the lanes of a 16-lane row (DPP moves; layout at the loop below), the 64 leaf
+// sums of a full piece meet in a balanced tree.  The last, partial piece takes the general plan / leaf / combine route of
+// pm_pairwise.h.  Piece sums go to `partial[]`; a second launch adds them one after the other (staged through LDS) and divides.
 constexpr int MDX_WAVES = 4;
 
 template <int CTRL>

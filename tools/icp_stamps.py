@@ -65,6 +65,9 @@ for d in extra:
     if d.startswith("-DPM_GR_FEW_FROM="):
         few_from = int(d.split("=")[1])
 lanes = 4 if n >= few_from else 8
+for d in extra:
+    if d.startswith("-DPM_GR_TRY_LANES=") and n >= few_from:
+        lanes = int(d.split("=")[1])
 blocks = (n + 256 // lanes - 1) // (256 // lanes)
 t = stamps.cpu().numpy()[:blocks].astype(np.float64)
 t0 = t[:, 0].min()
