@@ -1,5 +1,9 @@
-import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+"""How close the device's cloud statistics come to the reference fixtures and to the oracle (a probe, not a test; it lives under
+tests/ because it calls the oracle).  Usage: python tests/probes/axis_probe.py"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import bench, oracle
 from conftest import SCENARIOS, load_golden
