@@ -38,6 +38,59 @@ def test_python_binding_covers_the_header(lib_path):
     assert b"workspace" in lib.pm_error_string(-2)
 
 
+def header_prototypes():
+    """name -> (return type, [parameter types]) from the header text (comments stripped, one declaration per ';')."""
+    text = open(os.path.join(ROOT, "include", "platymatch_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(pm_[a-z0-9_]+)\s*\(([^;{}]*)\)\s*;", text):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+        plist = [] if params in ("", "void") else [re.sub(r"\s+", " ", q.strip()) for q in params.split(",")]
+        protos[name] = (ret, plist)
+    return protos
+
+
+def c_kind(decl):
+    """A C parameter / return declaration -> the ctypes kind the binding must use."""
+    d = decl.replace("const ", "").strip()
+    if "*" in d:
+        return "char_p" if d.startswith("char") else "pointer"
+    base = d.split(" ")[0] if " " in d and not d.startswith(("unsigned", "long")) else d
+    base = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*$", "", d).strip() or d          # drop the parameter name
+    table = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "unsigned int": "u32", "size_t": "size", "double": "f64",
+             "long": "i64", "long long": "i64", "int64_t": "i64", "uint64_t": "u64", "unsigned long long": "u64", "void": "void"}
+    assert base in table, decl
+    return table[base]
+
+
+def ctypes_kind(t):
+    if t is None:
+        return "void"
+    return {ctypes.c_void_p: "pointer", ctypes.c_char_p: "char_p", ctypes.c_int: "i32", ctypes.c_int32: "i32", ctypes.c_uint32: "u32",
+            ctypes.c_uint: "u32", ctypes.c_size_t: "size", ctypes.c_double: "f64", ctypes.c_long: "i64", ctypes.c_longlong: "i64",
+            ctypes.c_int64: "i64", ctypes.c_uint64: "u64", ctypes.c_ulonglong: "u64", ctypes.c_ulong: "u64"}[t]
+
+
+def test_python_signatures_match_the_header_prototypes():
+    """Every entry point's ctypes signature (platymatch_amd/_native.py) against its prototype in include/platymatch_hip.h:
+    same number of parameters, each of the same kind and width (pointer, int32, uint32, int64, uint64, size_t, double) — an
+    argument added to one side only would otherwise shift every later argument silently."""
+    from platymatch_amd import _native
+    protos = header_prototypes()
+    assert sorted(protos) == sorted(_native.SIGNATURES)
+    same = {"size": "u64", "u64": "u64", "i64": "i64"}            # (size_t and uint64_t travel alike on this ABI)
+    for name, (ret, params) in protos.items():
+        res, args = _native.SIGNATURES[name]
+        assert len(args) == len(params), (name, len(args), params)
+        want = [c_kind(q) for q in params]
+        have = [ctypes_kind(a) for a in args]
+        for k, (w, h) in enumerate(zip(want, have)):
+            assert same.get(w, w) == same.get(h, h), (name, k, params[k], h)
+        wr, hr = c_kind(ret + " x") if "*" not in ret else c_kind(ret), ctypes_kind(res)
+        assert same.get(wr, wr) == same.get(hr, hr) or (wr == "pointer" and hr == "pointer"), (name, ret, hr)
+
+
 def test_workspace_queries_and_argument_errors(lib_path):
     """Host-side behaviour that needs no device: sizes, and rejection before anything is enqueued."""
     from platymatch_amd import _native
