@@ -94,7 +94,7 @@ def test_unchanged_widget_body_on_the_drop_in_matches_the_reference():
     A_final = out["A_icp"] @ out["A_sc"]                                                                       # :428
     assert relerr(A_final, d["A_final"]) < 1e-9
     np.testing.assert_array_almost_equal(d["A_gt"], A_final)          # the reference test's own assertion (decimal 6)
-    assert wall < 30.0 and out["loop_seconds"] < 10.0                 # the reference needs ~90 s for these loops alone
+    assert wall < 60.0 and out["loop_seconds"] < 30.0                 # the reference needs ~90 s for these loops alone (typically 3 s here; generous: shared host cores)
 
 
 def test_get_unary_distance_lookup_equals_per_pair_launch_and_survives_foreign_inputs():
