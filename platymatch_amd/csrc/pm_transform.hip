@@ -22,8 +22,18 @@ __global__ __launch_bounds__(TF_THREADS) void apply_affine_kernel(const double *
     const int i = blockIdx.x * TF_THREADS + threadIdx.x;
     if (i >= n) return;
     const double x = in[i], y = in[(size_t)n + i], z = in[2 * (size_t)n + i];
+    // apply_transform.py:14-17 is np.matmul(A, [moving; 1]): BLAS dgemm, whose x86-64 kernels run the k = 0..3 products of an output
+    // element as one chain of fused multiply-adds (the form pm_similar_apply restates and tests against NumPy).  Same chain here,
+    // so that the cloud ICP starts from — the RANSAC winner applied to the moving cloud — carries the reference's bits: on
+    // lattice-like data (voxel coordinates) a moved point can sit exactly midway between two fixed points, and the last bit
+    // decides its first correspondence (tests/probes/soak_parity.py found such cases).
 #pragma unroll
-    for (int r = 0; r < 3; ++r) out[(size_t)r * n + i] = ((A[4 * r] * x + A[4 * r + 1] * y) + A[4 * r + 2] * z) + A[4 * r + 3];
+    for (int r = 0; r < 3; ++r) {
+        double acc = A[4 * r] * x;
+        acc = __builtin_fma(A[4 * r + 1], y, acc);
+        acc = __builtin_fma(A[4 * r + 2], z, acc);
+        out[(size_t)r * n + i] = __builtin_fma(A[4 * r + 3], 1.0, acc);
+    }
 }
 
 // Ordered sum over the blocks of one slot of the per-block partials: the same additions in the same order wherever

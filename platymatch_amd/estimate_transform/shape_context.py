@@ -234,8 +234,19 @@ def fresh_device_seed(rng=None):
     return (hi << 32) | lo
 
 
+def refit_affine_winner(deferred):
+    """The model of a RANSAC winner by the reference's own expression, [fixed; 1] . pinv([moving; 1]) of its sample
+    (find_transform.py:11-17), on the host.  deferred: what do_ransac(defer=...) left behind (the sample's 2 k points, on the
+    device) -> 4 x 4 GPU tensor."""
+    from .find_transform import affine_pinv_host
+    torch = nat.torch_mod()
+    pts, k = deferred["pts"], deferred["k"]
+    h = pts.cpu().numpy()
+    return torch.as_tensor(affine_pinv_host(h[:, :k], h[:, k:]), device=pts.device)
+
+
 def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transform='Affine', rows=None, cols=None,
-              samples=None, device_seed=None, run=0):
+              samples=None, device_seed=None, run=0, defer=None):
     """shape_context.py:103-139 -> (A_best 4 x 4, inliers_best).
 
     The host draws the index sets (same RNG calls as the reference); one kernel launch fits and
@@ -246,7 +257,10 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
     `rows`/`cols` (optional) select matched pairs without gathering on the host:
     pairs are (moving_all[:, rows[k]], fixed_all[:, cols[k]]).  `samples` (optional, [trials, min_samples] int32):
     index sets already drawn with draw_ransac_samples (pipeline.estimate_transform draws them ahead of time).
-    `device_seed` (optional, 64-bit int): draw the sets on the device instead (Philox stream `run` of that seed; see SAMPLER)."""
+    `device_seed` (optional, 64-bit int): draw the sets on the device instead (Philox stream `run` of that seed; see SAMPLER).
+    `defer` (optional dict, 'Affine' only): the winner's host refit (below) is left to the caller — the dict receives what
+    refit_affine_winner needs and the device's own fit of the winner is returned (pipeline.estimate_transform refits only the
+    hypothesis it goes on with: one read-back instead of eight)."""
     torch = nat.torch_mod()
     m, f = nat.to_dev(moving_all), nat.to_dev(fixed_all)
     if m.dim() != 2 or f.dim() != 2:
@@ -318,13 +332,21 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
         best = int(np.argmax(inl_h))          # first maximum == first strictly-better trial
         if inl_h[best] <= 0:
             return (torch.as_tensor(ones, device=m.device) if nat.is_torch(moving_all) else ones), 0
-        if redo.size and best in set(redo.tolist()):
-            # the winner came from the host: refit it by the literal per-sample expression (the batched call may differ in
-            # the last bits)
-            mh, fh = host_pairs()
-            A_best = torch.as_tensor(affine_pinv_host(mh[:, samples[best]], fh[:, samples[best]]), device=m.device)
+        # The winning trial's model by the reference's own expression, [fixed; 1] . pinv([moving; 1]) of ITS sample
+        # (find_transform.py:11-17), on the host: the device's fit equals it to ~1e-12, but ICP starts from this matrix applied to
+        # the moving cloud, and on lattice-like data the last bit of a moved point can decide its first correspondence
+        # (tests/probes/soak_parity.py).  Only the sample's 2 k points travel.
+        if isinstance(samples, _DeviceSamples):
+            sel = samples.dev[best].long()
         else:
+            sel = torch.as_tensor(np.asarray(samples[best], dtype=np.int64), device=m.device)
+        mi, fi = (rows[sel].long(), cols[sel].long()) if rows is not None else (sel, sel)
+        pts = torch.cat((m[:, mi], f[:, fi]), dim=1)
+        if defer is not None:
+            defer.update(pts=pts, k=k)
             A_best = A[best]
+        else:
+            A_best = refit_affine_winner({"pts": pts, "k": k})
         return (A_best if nat.is_torch(moving_all) else A_best.cpu().numpy()), int(inl_h[best])
     elif transform == 'Similar':
         mh, fh = m.cpu().numpy(), f.cpu().numpy()

@@ -136,10 +136,15 @@ class GpuBackend:
         from .estimate_transform.shape_context import draw_ransac_samples
         return draw_ransac_samples(n, min_samples, trials, rng=rng)
 
-    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples, samples=None, device_seed=None, run=0):
+    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples, samples=None, device_seed=None, run=0, defer=None):
         from .estimate_transform.shape_context import do_ransac
         return do_ransac(mov, fix, min_samples=min_samples, trials=trials, error=error, transform=transform,
-                         rows=rows, cols=cols, samples=samples, device_seed=device_seed, run=run)
+                         rows=rows, cols=cols, samples=samples, device_seed=device_seed, run=run, defer=defer)
+
+    def refit_winner(self, deferred):
+        """The chosen hypothesis's RANSAC model by the reference's own host expression (shape_context.refit_affine_winner)."""
+        from .estimate_transform.shape_context import refit_affine_winner
+        return refit_affine_winner(deferred)
 
     def fit(self, kp_m, kp_f, transform):
         from .estimate_transform.find_transform import get_affine_transform, get_similar_transform
@@ -747,16 +752,25 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         A_h = []
         if on_device:
             dseed = (int(seed) & ((1 << 64) - 1)) if seed is not None else _shared_device_seed(group, mov.device)
+        # 'Affine': a run's winner is the device's fit of its sample; the hypothesis the registration goes on with gets the
+        # reference's own expression on the host afterwards (one read-back instead of eight; the other seven only appear in
+        # details["ransac_A"], equal to the reference's to ~1e-12)
+        can_defer = transform == 'Affine' and hasattr(be, "refit_winner")
+        deferred = [dict() for _ in range(8)]
         for h, (r, c) in enumerate(lsa):
+            extra = {"defer": deferred[h]} if can_defer else {}
             if on_device:                            # stream h of the registration's seed: the eight runs draw independent sets
                 A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
-                                    ransac_samples, device_seed=dseed, run=h)
+                                    ransac_samples, device_seed=dseed, run=h, **extra)
             else:
                 A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
-                                    ransac_samples, samples=sets[h])
+                                    ransac_samples, samples=sets[h], **extra)
             A_h.append(nat.to_dev(A, dev=mov.device))
             inliers[h] = k
-        A_sc = A_h[int(np.argmax(inliers))]          # first maximum (_dock_widget.py:683-703)
+        h_best = int(np.argmax(inliers))             # first maximum (_dock_widget.py:683-703)
+        if can_defer and deferred[h_best]:
+            A_h[h_best] = be.refit_winner(deferred[h_best])
+        A_sc = A_h[h_best]
         t0 = mark("gpu_ransac", t0)
         if details is not None:
             details.update(lsa=lsa, ransac_A=torch.stack(A_h).cpu().numpy())

@@ -1,0 +1,69 @@
+"""Random registrations, HIP path against the CPU oracle end to end (a fixed slice of tests/probes/soak_parity.py's stream), and
+the cases that stream once caught: lattice clouds whose moved points sit exactly midway between two fixed points, where the
+last bit of the RANSAC winner applied to the moving cloud decides the first ICP correspondences (round 3: the winner is
+refitted by the reference's own expression on the host and applied in np.matmul's multiply-add chain)."""
+import numpy as np
+import pytest
+
+from soak_cases import make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def run_pair(oracle, seed, max_points=500):
+    import platymatch_amd
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    mv, fx, lattice, transform, rs = make_case(seed, max_points)
+    err = 25.0 * (np.abs(mv).max() / 300.0 + 1e-9)
+    det, odet = {}, {}
+    ref = oracle.estimate_transform(mv, fx, transform=transform, ransac_trials=80, ransac_error=err, icp_iterations=4, seed=rs, details=odet)
+    got = platymatch_amd.register(mv, fx, transform=transform, ransac_trials=80, ransac_error=err, icp_iterations=4, seed=rs, details=det)
+    return (mv, fx, lattice, transform), ref, got, odet, det
+
+
+def check(case, ref, got, odet, det):
+    for h in range(8):
+        assert np.array_equal(det["lsa"][h][0], odet["lsa"][h][0]) and np.array_equal(det["lsa"][h][1], odet["lsa"][h][1]), h
+    assert np.array_equal(got[2], ref[2])
+    well = np.isfinite(ref[0]).all() and np.isfinite(ref[1]).all() and np.linalg.cond(ref[0]) < 1e8
+    if well:
+        assert np.array_equal(det["nn"], odet["nn"])                       # every correspondence of every ICP iteration
+        assert relerr(got[0], ref[0]) < 1e-6 and relerr(got[1] @ got[0], ref[1] @ ref[0]) < 1e-6      # north_star: 1e-5
+    return well
+
+
+@pytest.fixture(scope="module")
+def ready():
+    import torch
+    from platymatch_amd import _native
+    from platymatch_amd.build import build_native
+    build_native()
+    _native.load()
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("seed", [49, 54, 114, 129, 234, 349])
+def test_lattice_cases_the_soak_caught(ready, oracle, seed):
+    """Before the fix: 7-9 first-iteration correspondences differed (two fixed points 4e-14 apart in distance from the moved
+    point) and the final transform was off by up to 26 %."""
+    import platymatch_amd
+    case, ref, got, odet, det = run_pair(oracle, seed)
+    assert case[2] and case[3] == "Affine"
+    assert check(case, ref, got, odet, det)
+    if np.linalg.cond(ref[0]) < 1e3:
+        # the RANSAC winner is the reference's matrix to the bit (the same NumPy expression on the same four pairs)
+        assert np.array_equal(np.asarray(got[0])[:3], np.asarray(ref[0])[:3])
+
+
+def test_a_slice_of_the_random_stream(ready, oracle):
+    well = 0
+    for seed in range(40):
+        case, ref, got, odet, det = run_pair(oracle, seed, max_points=300)
+        well += check(case, ref, got, odet, det)
+    assert well >= 20
