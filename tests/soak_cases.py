@@ -25,3 +25,47 @@ def make_case(seed, max_points=500):
     scale = float(rng.choice([1.0, 1.0, 1e-3, 1e3]))
     return (np.ascontiguousarray(mv[:, :n] * scale), np.ascontiguousarray(fx[:, :m] * scale), lattice,
             "Similar" if seed % 3 == 2 else "Affine", int(rng.integers(0, 2 ** 31)))
+
+
+def make_case_b(seed, max_points=400):
+    """A second family, the awkward corners -> dict(mv, fx, kind, kwargs for estimate_transform):
+    0 integer voxel coordinates; 1 the same cloud twice (permuted: zero-cost matches, exact ties); 2 tiny clouds (4..12 points);
+    3 planar clouds; 4 RANSAC samples of 3 / 5 / 8 pairs; 5 supervised mode (keypoints)."""
+    rng = np.random.default_rng(7000003 * seed + 5)
+    kind = seed % 6
+    n = int(rng.integers(20, max_points + 1))
+    m = int(rng.integers(20, max_points + 1)) if rng.random() < 0.6 else n
+    if kind == 2:
+        n, m = int(rng.integers(4, 13)), int(rng.integers(4, 13))
+    big = max(n, m)
+    axes = rng.uniform(10.0, 80.0, size=(3, 1))
+    base = rng.normal(size=(3, big)) * axes + rng.uniform(50.0, 300.0, size=(3, 1))
+    th = rng.uniform(-0.4, 0.4)
+    A = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]]) * rng.uniform(0.8, 1.25) + rng.normal(scale=0.02, size=(3, 3))
+    t = rng.uniform(-30.0, 30.0, size=(3, 1))
+    kwargs = dict(transform="Similar" if seed % 4 == 3 else "Affine", ransac_trials=80, ransac_error=20.0, icp_iterations=4,
+                  seed=int(rng.integers(0, 2 ** 31)))
+    if kind == 3:
+        base[2] = base[2, 0]                                             # a planar cloud
+    mv = base.copy()
+    fx = A @ base + t + rng.normal(scale=0.5, size=(3, big))
+    if kind == 3:
+        fx[2] = fx[2, 0]
+    if kind == 0:
+        mv, fx = np.round(mv), np.round(fx)
+    perm = rng.permutation(big)
+    if kind == 1:
+        fx = mv.copy()
+        m = n
+    fx = fx[:, perm]
+    mv, fx = np.ascontiguousarray(mv[:, :n]), np.ascontiguousarray(fx[:, :m])
+    if kind == 1:
+        fx = np.ascontiguousarray(mv[:, rng.permutation(n)])
+    if kind == 4:
+        kwargs["ransac_samples"] = int(rng.choice([3, 5, 8]))
+    if kind == 5:
+        inv = np.argsort(perm)                                           # fx[:, inv[i]] is the partner of mv[:, i]
+        idx = [i for i in range(min(n, big)) if inv[i] < m][:12]
+        if len(idx) >= 4:
+            kwargs.update(mode="supervised", keypoints=(np.ascontiguousarray(mv[:, idx]), np.ascontiguousarray(fx[:, inv[idx]])))
+    return dict(mv=mv, fx=fx, kind=kind, kwargs=kwargs)
