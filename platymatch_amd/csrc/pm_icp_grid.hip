@@ -545,9 +545,9 @@ __global__ __launch_bounds__(256) void icp_iter_kernel(const IterArgs a) {
     int iI = 0x7fffffff;
     if (!FIRST) {
         const double x = p0, y = p1, z = p2;
-        p0 = ((a.A_prev[0] * x + a.A_prev[1] * y) + a.A_prev[2] * z) + a.A_prev[3];
-        p1 = ((a.A_prev[4] * x + a.A_prev[5] * y) + a.A_prev[6] * z) + a.A_prev[7];
-        p2 = ((a.A_prev[8] * x + a.A_prev[9] * y) + a.A_prev[10] * z) + a.A_prev[11];
+        p0 = affine_row(a.A_prev, x, y, z);
+        p1 = affine_row(a.A_prev + 4, x, y, z);
+        p2 = affine_row(a.A_prev + 8, x, y, z);
         const int j_prev = a.nn_prev[ic];
         const double f0 = a.fix[j_prev], f1 = a.fix[(size_t)m + j_prev], f2 = a.fix[2 * (size_t)m + j_prev];
         const double d0 = p0 - f0, d1 = p1 - f1, d2 = p2 - f2;
@@ -829,9 +829,9 @@ __global__ __launch_bounds__(256, 4) void icp_loop_kernel(const LoopArgs la) {  
         // apply the transform fitted by the previous iteration (:23) and take the residual against the previous match (:24)
         {
             const double x = p0, y = p1, z = p2;
-            p0 = ((A_s[0] * x + A_s[1] * y) + A_s[2] * z) + A_s[3];
-            p1 = ((A_s[4] * x + A_s[5] * y) + A_s[6] * z) + A_s[7];
-            p2 = ((A_s[8] * x + A_s[9] * y) + A_s[10] * z) + A_s[11];
+            p0 = affine_row(A_s, x, y, z);
+            p1 = affine_row(A_s + 4, x, y, z);
+            p2 = affine_row(A_s + 8, x, y, z);
         }
         const double e0 = p0 - m0, e1 = p1 - m1, e2 = p2 - m2;
         const double S0 = (e0 * e0 + e1 * e1) + e2 * e2;

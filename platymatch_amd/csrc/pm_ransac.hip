@@ -182,9 +182,9 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kernel(const double *__rest
 #pragma unroll 4
         for (int e = e0; e < e0 + RS_SUB; ++e) {
             const double x = Pm[0][e], y = Pm[1][e], z = Pm[2][e];
-            const double d0 = Pf[0][e] - (((A[0] * x + A[1] * y) + A[2] * z) + A[3]);
-            const double d1 = Pf[1][e] - (((A[4] * x + A[5] * y) + A[6] * z) + A[7]);
-            const double d2 = Pf[2][e] - (((A[8] * x + A[9] * y) + A[10] * z) + A[11]);
+            const double d0 = Pf[0][e] - affine_row(A, x, y, z);
+            const double d1 = Pf[1][e] - affine_row(A + 4, x, y, z);
+            const double d2 = Pf[2][e] - affine_row(A + 8, x, y, z);
             const double d = __builtin_sqrt((d0 * d0 + d1 * d1) + d2 * d2);   // np.linalg.norm (:133)
             cnt += (d <= error) ? 1 : 0;                                        // :134
         }

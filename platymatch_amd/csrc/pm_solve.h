@@ -107,6 +107,17 @@ __device__ __forceinline__ void moment_terms(double a0, double a1, double a2, do
     s[21] = (f0 * f0 + f1 * f1) + f2 * f2;
 }
 
+// One row of apply_affine_transform (apply_transform.py:14-17: np.matmul(A, [p; 1])) in np.matmul's own arithmetic: BLAS dgemm's
+// x86-64 kernels run the k = 0..3 products of an output element as one chain of fused multiply-adds, starting from the rounded
+// first product.  Every kernel that moves a point uses this form, so that a cloud carries the reference's bits wherever the
+// 4 x 4 does (the RANSAC winner; pinv fits of a degenerate ICP step, whose next fit amplifies the cloud's last bits by 1e11).
+__device__ __forceinline__ double affine_row(const double *A4, double x, double y, double z) {
+    double acc = A4[0] * x;
+    acc = __builtin_fma(A4[1], y, acc);
+    acc = __builtin_fma(A4[2], z, acc);
+    return __builtin_fma(A4[3], 1.0, acc);
+}
+
 // A_icp <- A_est . A_icp (perform_icp.py:25, np.matmul), all four rows.
 __device__ __forceinline__ void compose_affine(const double A[16], double *A_icp16) {
     double C[16];

@@ -22,18 +22,11 @@ __global__ __launch_bounds__(TF_THREADS) void apply_affine_kernel(const double *
     const int i = blockIdx.x * TF_THREADS + threadIdx.x;
     if (i >= n) return;
     const double x = in[i], y = in[(size_t)n + i], z = in[2 * (size_t)n + i];
-    // apply_transform.py:14-17 is np.matmul(A, [moving; 1]): BLAS dgemm, whose x86-64 kernels run the k = 0..3 products of an output
-    // element as one chain of fused multiply-adds (the form pm_similar_apply restates and tests against NumPy).  Same chain here,
-    // so that the cloud ICP starts from — the RANSAC winner applied to the moving cloud — carries the reference's bits: on
-    // lattice-like data (voxel coordinates) a moved point can sit exactly midway between two fixed points, and the last bit
-    // decides its first correspondence (tests/probes/soak_parity.py found such cases).
+    // np.matmul's arithmetic (pm_solve.h: affine_row) — found necessary by tests/probes/soak_parity.py: on lattice-like data
+    // (voxel coordinates) a moved point can sit exactly midway between two fixed points, and the last bit of the cloud ICP
+    // starts from decides its first correspondence
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        double acc = A[4 * r] * x;
-        acc = __builtin_fma(A[4 * r + 1], y, acc);
-        acc = __builtin_fma(A[4 * r + 2], z, acc);
-        out[(size_t)r * n + i] = __builtin_fma(A[4 * r + 3], 1.0, acc);
-    }
+    for (int r = 0; r < 3; ++r) out[(size_t)r * n + i] = affine_row(A + 4 * r, x, y, z);
 }
 
 // Ordered sum over the blocks of one slot of the per-block partials: the same additions in the same order wherever
@@ -169,9 +162,7 @@ __global__ __launch_bounds__(TF_RED_THREADS) void update_kernel(const double *__
     const int i = blockIdx.x * TF_BLOCK_PTS + threadIdx.x;
     if (i < n) {
         const double x = mov[i], y = mov[(size_t)n + i], z = mov[2 * (size_t)n + i];
-        const double q0 = ((As[0] * x + As[1] * y) + As[2] * z) + As[3];
-        const double q1 = ((As[4] * x + As[5] * y) + As[6] * z) + As[7];
-        const double q2 = ((As[8] * x + As[9] * y) + As[10] * z) + As[11];
+        const double q0 = affine_row(As, x, y, z), q1 = affine_row(As + 4, x, y, z), q2 = affine_row(As + 8, x, y, z);
         mov[i] = q0; mov[(size_t)n + i] = q1; mov[2 * (size_t)n + i] = q2;
         const int j = nn ? nn[i] : i;
         const double d0 = q0 - fix[j], d1 = q1 - fix[(size_t)m + j], d2 = q2 - fix[2 * (size_t)m + j];
