@@ -1,0 +1,60 @@
+"""The sharded path with the REAL GPU backend on several ranks: the ranks share this box's one GPU and gloo carries the
+collectives (two ranks cannot share a device under RCCL; RCCL itself runs at world size 1 in tests/test_gpu_rccl.py, and the
+N-GPU run is the driver's).  What is checked is the code every rank executes — row-sharded statistics, descriptors, cost blocks,
+the sharded assignment's query protocol over DeviceMatrix blocks, replicated and sharded ICP, the streamed mode — against the
+one-process run of the same call: identical assignment vectors, inlier counts and A_sc, final 4x4 to 1e-9
+(tools/two_rank_registration.py); and bench.py's own multi-rank step."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra)
+    return env
+
+
+def _ranks(world, args, **extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "two_rank_registration.py")] + [str(a) for a in args]
+    return subprocess.run(cmd, env=_env(**extra), capture_output=True, text=True, timeout=900, cwd=ROOT)
+
+
+@pytest.mark.parametrize("world,n,m,streamed", [(2, 1500, 1600, False), (2, 1600, 1500, False), (3, 1300, 1400, True), (3, 1400, 1300, True)])
+def test_ranks_sharing_the_gpu_reproduce_the_one_process_registration(world, n, m, streamed):
+    """N <= M: the sharded device solve (nothing gathered); N > M: gathered to the hypothesis's owner, or — streamed — the
+    transposed roles of round 3.  Both ICP variants (replicated, sharded) inside the script."""
+    p = _ranks(world, [n, m], **({"PM_STREAM_HYPOTHESES": "1"} if streamed else {}))
+    assert p.returncode == 0, (p.stdout[-2500:], p.stderr[-2500:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("ICP ")]
+    assert len(lines) == 2 and all(l.endswith("OK") for l in lines), p.stdout[-2500:]
+
+
+def test_bench_step_on_two_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 2` through its own launcher, the ranks put on cuda:0 and gloo in RCCL's place (rehearsal
+    switches of bench.py): the sharded step end to end, one JSON line from rank 0."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--points", "6000",
+                        "--icp-iters", "5", "--no-cpu-baseline"], env=_env(PM_BENCH_ONE_DEVICE="1", PM_BENCH_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["config"]["sharding"] == "rows/2" and d["value"] > 0 and d["scaling"] == "strong"
+    assert set(d["stage_ms"]) == {"statistics", "shape_context", "chi2_cost8", "icp"}
