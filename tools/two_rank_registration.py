@@ -5,7 +5,7 @@ run of the same call — assignment vectors and inlier counts identical, 4x4 mat
 sharded ICP.  (The N-GPU run over RCCL is the driver's; this checks the code path, not the speed.)
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
-        tools/two_rank_registration.py [N [M]]"""
+        tools/two_rank_registration.py [N [M [SEED]]]"""
 import os
 import sys
 
@@ -26,7 +26,8 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 m = int(sys.argv[2]) if len(sys.argv) > 2 else n - 37       # N > M by default (assignment by gather); pass M >= N for the sharded solve
-mv, fx, _ = synth_pair(max(n, m), 77, m=m)
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 77
+mv, fx, _ = synth_pair(max(n, m), seed, m=m)
 mv = np.ascontiguousarray(mv[:, :n])
 kw = dict(ransac_trials=500, ransac_error=8.0, icp_iterations=12, seed=4)
 streamed = os.environ.get("PM_STREAM_HYPOTHESES") == "1"       # two cost matrices resident at a time on every rank (config 4's mode)
