@@ -279,10 +279,13 @@ int pmo_ransac_score(const double *mov, const double *fix, int n, const double *
         int cnt = 0;
         for (int i = 0; i < n; ++i) {
             double m0 = mov[i], m1 = mov[n + i], m2 = mov[2 * (size_t)n + i];
-            double p0 = ((a[0] * m0 + a[1] * m1) + a[2] * m2) + a[3];
-            double p1 = ((a[4] * m0 + a[5] * m1) + a[6] * m2) + a[7];
-            double p2 = ((a[8] * m0 + a[9] * m1) + a[10] * m2) + a[11];
-            double d = norm3(fix[i] - p0, fix[n + i] - p1, fix[2 * (size_t)n + i] - p2);
+            /* :128 apply_affine_transform = np.matmul: BLAS dgemm, a chain of fused multiply-adds over k = 0..3;
+             * :133 np.linalg.norm of a 3-vector = sqrt(x.dot(x)): BLAS ddot, the same kind of chain (as in pmo_mean_distance) */
+            double p0 = fma(a[3], 1.0, fma(a[2], m2, fma(a[1], m1, a[0] * m0)));
+            double p1 = fma(a[7], 1.0, fma(a[6], m2, fma(a[5], m1, a[4] * m0)));
+            double p2 = fma(a[11], 1.0, fma(a[10], m2, fma(a[9], m1, a[8] * m0)));
+            double e0 = fix[i] - p0, e1 = fix[n + i] - p1, e2 = fix[2 * (size_t)n + i] - p2;
+            double d = sqrt(fma(e2, e2, fma(e1, e1, e0 * e0)));
             if (d <= error) ++cnt;
         }
         inliers[t] = cnt;

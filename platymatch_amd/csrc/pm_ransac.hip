@@ -185,7 +185,7 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kernel(const double *__rest
             const double d0 = Pf[0][e] - affine_row(A, x, y, z);
             const double d1 = Pf[1][e] - affine_row(A + 4, x, y, z);
             const double d2 = Pf[2][e] - affine_row(A + 8, x, y, z);
-            const double d = __builtin_sqrt((d0 * d0 + d1 * d1) + d2 * d2);   // np.linalg.norm (:133)
+            const double d = __builtin_sqrt(__builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0)));   // np.linalg.norm of a 3-vector (:133) = sqrt(x.dot(x)): BLAS ddot's multiply-add chain
             cnt += (d <= error) ? 1 : 0;                                        // :134
         }
     }
