@@ -122,11 +122,14 @@ int pm_shape_context(const double *xyz, int n, int row0, int nrows, const double
  * histogram per row is kept (frame 1) and frames 2..4 are written as its phi permutations.  Tiles holding a neighbour for
  * which that permutation does not hold exactly (on a sector edge or pole of the frame) are recomputed by pm_shape_context's
  * kernel inside the same call.  Outputs are identical to pm_shape_context's in every case.
- *   edge_guard2  (device, may be NULL) two uint32 counters of (point, neighbour) pairs whose bin depends on the cloud statistics
- *                beyond the accuracy they are known to: [1] azimuth within 1e-12 / sin(angle(axis, z)) of a sector edge — the
- *                PCA axis agrees with sklearn's to 1e-12 —, [0] distance within 4e-14 (relative) of a ring radius (informative
- *                since pm_mean_distance returns the reference's bits: a caller's own mean distance may not).  Zero for generic data: "the reference's histograms" then holds by
- *                construction for this call, not only by the fixtures.
+ *   edge_guard2  (device, may be NULL) two uint32 counters of (point, neighbour) pairs whose bin the reference itself would not
+ *                decide reproducibly: [1] azimuth within 1e-12 / sin(angle(axis, z)) of a sector edge — the PCA axis agrees
+ *                with sklearn's to 1e-12 —, [0] distance within 4e-14 (relative) of a ring radius (informative since
+ *                pm_mean_distance returns the reference's bits: a caller's own mean distance may not); and, both counters,
+ *                any neighbour within 1.6e-13 x (|x| + |y| + |z| of the queried point) of a ring radius [0], a sector plane
+ *                or a polar cone [1] — four times the error np.linalg.inv leaves on the reference's local coordinates
+ *                (shape_context.py:81; lattice-like input puts neighbours exactly there).  Zero for generic data: "the
+ *                reference's histograms" then holds by construction for this call, not only by the fixtures.
  * workspace: pm_shape_context_workspace(nrows) bytes, 256-byte aligned (frames, thresholds, per-tile flags, counts). */
 size_t pm_shape_context_workspace(int nrows);
 int pm_shape_context_tiled(const double *xyz, int n, int row0, int nrows, const double *centroid3,

@@ -20,6 +20,15 @@
  *   numpy 2.2.6   floor_divide on float64 (npy_divmod), np.linalg.norm, np.cross
  *   scipy 1.15.3  spatial.distance_matrix (minkowski p=2), optimize.linear_sum_assignment
  * Their published algorithms are restated where used.
+ *
+ * Two places where the reference's own bits depend on its C / linear-algebra libraries, and what this file does there
+ * (measured by tests/golden/soak_oracle_vs_reference.py):
+ *   x ** 2 on NumPy float64 scalars (get_unary_distance, shape_context.py:95) is libm pow(x, 2.0); glibc >= 2.28 does not
+ *     round it correctly (one operand in ~2 000 differs from x * x by an ulp).  Squared here by multiplication: 10 of
+ *     1 035 624 cost entries differ from this container's reference by one ulp.
+ *   transform() (shape_context.py:61-84) builds local coordinates through np.linalg.inv of a 4 x 4: LAPACK's rounding leaves
+ *     up to 4e-14 x |d|_1 on each.  Projected directly here; histograms are the reference's unless a neighbour lies within
+ *     that noise of a bin boundary or duplicates the queried point (generic clouds: never in 577 random pairs).
  */
 #include <math.h>
 #include <omp.h>

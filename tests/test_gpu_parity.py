@@ -955,9 +955,15 @@ def test_edge_guard_is_zero_on_every_fixture_and_counts_constructed_cases(gpu, o
     u /= np.linalg.norm(u)
     cloud[:, 1] = p0 + u * (md * 0.25000000000000006)                 # np.logspace's second edge times md
     cloud[:, 2] = p0 + 7.0 * x + 3.0 * z                               # azimuth 0 in point 0's frame: on a sector edge
+    base = gpu.K.shape_context(gpu.d(np.ascontiguousarray(cloud)), gpu.d(c), gpu.d(x0), gpu.d(np.array([md])), 4)["guard"].cpu().tolist()
+    assert base[0] >= 1 and base[1] >= 1
+    # ... and point 3 in the plane z = 0 of point 0's frame at azimuth 40 degrees: on the polar cone theta = 90 degrees, where the
+    # reference's inv()-based coordinates (noise ~1e-11 here) decide the bin as its LAPACK happens to round
+    y = np.cross(z, x)
+    cloud[:, 3] = p0 + 6.0 * (np.cos(np.deg2rad(40.0)) * x + np.sin(np.deg2rad(40.0)) * y)
     r = gpu.K.shape_context(gpu.d(np.ascontiguousarray(cloud)), gpu.d(c), gpu.d(x0), gpu.d(np.array([md])), 4)
     ring, sector = r["guard"].cpu().tolist()
-    assert ring >= 1 and sector >= 1
+    assert ring >= base[0] and sector >= base[1] + 1
     # ... and the driver reports it
     from platymatch_amd import pipeline as P
     d = load_golden("synth128")
