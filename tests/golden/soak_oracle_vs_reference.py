@@ -88,6 +88,14 @@ while time.perf_counter() < t_end:
                 fails.append(tag + ": get_centroid bits")
             if ut.get_mean_distance(cloud, transposed=False) != oracle.get_mean_distance(cloud, False):
                 fails.append(tag + ": get_mean_distance bits")
+            ct = np.ascontiguousarray(cloud.T)                                   # the N x 3 layout (transposed=True)
+            if not np.array_equal(np.asarray(ut.get_centroid(ct, transposed=True)), np.asarray(oracle.get_centroid(ct, True))):
+                fails.append(tag + ": get_centroid(transposed=True) bits")
+            if ut.get_mean_distance(ct, transposed=True) != oracle.get_mean_distance(ct, True):
+                fails.append(tag + ": get_mean_distance(transposed=True) bits")
+        pq = min(n, m)
+        if ut.get_error(mv[:, :pq], fx[:, :pq]) != oracle.get_error(mv[:, :pq], fx[:, :pq]):
+            fails.append(tag + ": get_error bits")
         # descriptors: the reference's normalised histograms back to counts (x (N-1), exact for these sizes)
         desc_r, desc_o = {}, {}
         for cloud, typ, nf in ((mv, "moving", 2), (fx, "fixed", 4)):
