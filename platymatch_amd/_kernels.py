@@ -184,8 +184,9 @@ def label_moments(labels, n_labels=None):
 
 def shape_context(xyz, centroid3, x0_3, mean_dist1, n_frames, row0=0, nrows=None, want_counts=False, want_hist=True, path="tiled"):
     """-> dict(hist=[F, nrows, 360] float64, counts=[F, nrows, 360] int32, totals=[F, nrows] int32, guard=int32 GPU [2] or None).
-    guard (tiled path): how many (point, neighbour) pairs sit so close to a ring radius / a sector edge that the tested agreement of
-    the mean distance (1e-14) / the PCA axis (1e-12) with the reference's does not settle their bin (include/platymatch_hip.h).
+    guard (tiled path): how many (point, neighbour) pairs sit so close to a ring radius [0] / a sector plane or polar cone [1] — or
+    coincide — that neither the tested agreement of the PCA axis with the reference's (1e-12) nor the reference's own rounding noise
+    (np.linalg.inv behind its local coordinates) settles their bin (include/platymatch_hip.h).
     path: "tiled" (default: pm_shape_context_tiled) or "general" (pm_shape_context, one workgroup per point: the kernel the
     tiled call itself falls back to for tiles with neighbours on a sector edge) — identical outputs."""
     torch = _t()

@@ -686,7 +686,9 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                     Affine ICP loop in one launch of persistent workgroups (only for a device that does nothing else meanwhile;
                     estimate_transform_batch always passes False: its workers keep several streams busy) — identical results
     details         optional dict filled with intermediate results (lsa, ransac_A, residuals, edge_guard: how many neighbours lie so
-                    close to a ring radius or sector edge that the tested accuracy of the cloud statistics does not settle their bin)
+                    close to a ring radius ("ring") or to a sector plane / polar cone ("sector") — or coincide with the queried
+                    point — that the reference itself would bin them by the rounding noise of its linear algebra; all zero =
+                    the integer histograms are the reference's by construction for this call)
     """
     import time
     import torch
