@@ -10,9 +10,13 @@ namespace pm {
 // Conditioning thresholds below which a fit is reported as degenerate (callers then refit with the reference's own
 // pinv on the host, which returns the minimum-norm answer for rank-deficient input: find_transform.py:17).
 //   PM_DEGENERATE_MOMENTS: det(Cmm) / (trace(Cmm)/3)^3 of the centred 3x3 moment matrix (1 for an isotropic cloud, 0 for a
-//                          planar one); the normal-equation solve loses about eps / ratio relative accuracy.
+//                          planar one); the normal-equation solve loses about eps / ratio relative accuracy.  1e-5 (round 3; 1e-8
+//                          before): a fit worse than ~1e-11 is not worth its speed — an ICP run whose cloud flattens (far more
+//                          moving than fixed points) amplified a 1e-9 difference to 1e-3 within a few iterations, where the
+//                          reference's pinv chain (what the caller reruns with) stays on track.  Clouds flatter than ~500:500:1
+//                          take that slower path.
 //   PM_DEGENERATE_SIMPLEX: |det D| / (|d1| |d2| |d3|) of the edge matrix of a 4-point sample (Hadamard ratio).
-#define PM_DEGENERATE_MOMENTS 1e-8
+#define PM_DEGENERATE_MOMENTS 1e-5
 #define PM_DEGENERATE_MOMENTS_SAMPLE 1e-6
 #define PM_DEGENERATE_SIMPLEX 1e-6
 
@@ -118,13 +122,15 @@ __device__ __forceinline__ double affine_row(const double *A4, double x, double 
     return __builtin_fma(A4[3], 1.0, acc);
 }
 
-// A_icp <- A_est . A_icp (perform_icp.py:25, np.matmul), all four rows.
+// A_icp <- A_est . A_icp (perform_icp.py:25, np.matmul), all four rows, in np.matmul's arithmetic (dgemm's multiply-add chain, as
+// affine_row).  It matters when a degenerate run's pinv fits carry entries of 1e10 that cancel in this product: the plain
+// multiply-and-add form left the composed 4x4 1e-3 from the reference's although every cloud along the way had its bits.
 __device__ __forceinline__ void compose_affine(const double A[16], double *A_icp16) {
     double C[16];
     for (int r = 0; r < 4; ++r)
         for (int c = 0; c < 4; ++c) {
-            double t = 0.0;
-            for (int k = 0; k < 4; ++k) t += A[4 * r + k] * A_icp16[4 * k + c];
+            double t = A[4 * r] * A_icp16[c];
+            for (int k = 1; k < 4; ++k) t = __builtin_fma(A[4 * r + k], A_icp16[4 * k + c], t);
             C[4 * r + c] = t;
         }
     for (int k = 0; k < 16; ++k) A_icp16[k] = C[k];
