@@ -351,14 +351,20 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
             UT_t = be.chi2_cost_single(f_loc[bt], sc_m_full[at])
             ih = {}
             c_h, c_t = solve_pair_sharded(lm(UT_h), lm(UT_t), bm, n, group, h % world, ih, accept_near_ties=accept_near_ties)
-            del UT_h, UT_t
-            for idx, c4r in ((h, c_h), (twin, c_t)):
-                if c4r is None:
+            for idx, c4r, UT in ((h, c_h, UT_h), (twin, c_t, UT_t)):
+                if c4r is None and n * m <= lsap.DENSE_FALLBACK_MAX_ENTRIES and getattr(UT, "is_cuda", False):
+                    # ties / near-ties the sharded scheme cannot settle, and a matrix the dense solver can take: the blocks of
+                    # U^T go to the hypothesis's owner; SciPy solves an N > M problem through its transpose as well
+                    _, c4r = _gather_and_solve(UT, bm, idx % world, group)
+                    routes[idx] = "gathered (transposed)"
+                elif c4r is None:
                     raise RuntimeError("hypothesis %s: the assignment could not be certified unique (an alternative within ~1e-11 of the "
                                        "optimum, exact ties or non-finite costs) and the matrix is too large for the dense solver; "
                                        "accept_near_ties=True takes the certified optimum as it is" % HYPOTHESES[idx])
+                else:
+                    routes[idx] = "sharded device (transposed: fixed rows sharded)"
                 out[idx] = lsap._answer(np.asarray(c4r), n, m)                       # fixed j -> moving i, as SciPy reports an N > M problem
-                routes[idx] = "sharded device (transposed: fixed rows sharded)"
+            del UT_h, UT_t
         if info is not None:
             info["routes"] = routes
             info["mode"] = "streamed: two matrices resident at a time"
@@ -379,6 +385,10 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
                    None if c_t is None else (rows, np.asarray(c_t, dtype=np.int64))]
             routes[h] = "sharded device" if c_h is not None else "uncertified"          # (details of the route: on the root only)
             routes[twin] = "sharded device" if c_t is not None else "uncertified"
+            for k2, idx in enumerate((h, twin)):
+                if got[k2] is None and n * m <= lsap.DENSE_FALLBACK_MAX_ENTRIES and getattr(U2, "is_cuda", False):
+                    got[k2] = _gather_and_solve(U2[k2], bounds, idx % world, group)   # ties at a size the dense solver can take
+                    routes[idx] = "gathered"
         for idx, g in zip((h, twin), got):
             if g is None:
                 raise RuntimeError("hypothesis %s: the assignment could not be certified unique (an alternative within ~1e-11 of the "
@@ -389,6 +399,38 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
         info["routes"] = routes
         info["mode"] = "streamed: two matrices resident at a time"
     return out
+
+
+def _gather_and_solve(block, bounds, owner, group):
+    """One hypothesis whose sharded solve could not certify its answer (ties, non-finite costs): its row blocks [rows_g, C] are
+    assembled on `owner` and solved there (lsap.solve_on_device: the device scheme once more on the whole matrix, else SciPy's
+    algorithm itself), the answer goes to every rank.  Only for matrices the dense solver can take (the caller checks).
+    -> (row_ind, col_ind) of the R x C problem the blocks belong to (R = bounds[-1]); a solver refusal is raised on every rank."""
+    import torch
+    from .lsap import linear_sum_assignment, solve_on_device
+    dist = _dist()
+    rank, world = _world(group)
+    biggest = max(bounds[g + 1] - bounds[g] for g in range(world))
+    cols = block.shape[1]
+    padded = torch.zeros((biggest, cols), dtype=block.dtype, device=block.device)
+    padded[:block.shape[0]].copy_(block)
+    whole = torch.empty((world, biggest, cols), dtype=block.dtype, device=block.device) if owner == rank else None
+    dist.gather(padded, [whole[g] for g in range(world)] if owner == rank else None, dst=_global_rank(group, owner), group=group)
+    status = torch.zeros(1, dtype=torch.int32, device=block.device)
+    k = min(bounds[-1], cols)
+    buf = torch.zeros((2, k), dtype=torch.int64, device=block.device)
+    if owner == rank:
+        U = torch.cat([whole[g][:bounds[g + 1] - bounds[g]] for g in range(world)], dim=0)
+        try:
+            r, c = solve_on_device(U) if U.is_cuda else linear_sum_assignment(U.numpy())
+            buf[0], buf[1] = torch.as_tensor(r, device=block.device), torch.as_tensor(c, device=block.device)
+        except ValueError as e:
+            status[0] = 2 if "infeasible" in str(e) else 1
+    dist.all_reduce(status, op=dist.ReduceOp.MAX, group=group)
+    if int(status.item()):
+        raise ValueError("cost matrix is infeasible" if int(status.item()) == 2 else "matrix contains invalid numeric entries")
+    dist.broadcast(buf, src=_global_rank(group, owner), group=group)
+    return buf[0].cpu().numpy(), buf[1].cpu().numpy()
 
 
 def iter_cost_blocks(be, mov, fix, rows_per_block, group=None):
@@ -532,6 +574,11 @@ def assign(U_loc, bounds, group=None, info=None, local_matrix=None, accept_near_
 ICP_SHARD_MIN_POINTS = 400_000
 
 
+class PlanarCloud(ValueError):
+    """icp_sharded: the moving cloud is (nearly) planar — the fit needs the reference's pinv on the host, which the sharded loop
+    does not have.  Raised on every rank together; estimate_transform answers it with the replicated loop."""
+
+
 def icp_sharded(be, moved, fix, iters, group=None):
     """Affine ICP with the moving rows sharded (perform_icp.py:7-26).  -> (A_icp [4,4], residuals [iters])."""
     import torch
@@ -567,9 +614,9 @@ def icp_sharded(be, moved, fix, iters, group=None):
             be.icp_update(sums, origin, loc, fix, nn, A_icp, parts_out=rp_view, status=status)
             if world == 1:
                 res_buf[it].copy_(rp_view)
-    if status is not None and int(status.item()) != 0:       # identical sums on every rank: all ranks raise together
-        raise ValueError("sharded ICP met a (nearly) planar moving cloud: the reference's pinv fit is needed there; run the "
-                         "refinement unsharded (icp_shard_min_points above the cloud size)")
+    if status is not None and int(status.item()) != 0:       # identical sums on every rank: all ranks leave together
+        raise PlanarCloud("sharded ICP met a (nearly) planar moving cloud: the reference's pinv fit is needed there; run the "
+                          "refinement unsharded (icp_shard_min_points above the cloud size)")
     residuals = list((res_buf[:iters, 0] / res_buf[:iters, 1]).unbind(0)) if iters else []
     res = torch.stack(residuals) if residuals else torch.empty(0, dtype=torch.float64, device=moved.device)
     return A_icp.reshape(4, 4), res
@@ -794,11 +841,16 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         moved = apply_affine_host(np.ascontiguousarray(mov_h[:3]), A_sc.cpu().numpy() if nat.is_torch(A_sc) else np.asarray(A_sc))
     else:
         moved = be.apply_affine(A_sc, mov)                                          # :714
+    sharded_icp_done = False
     if world > 1 and transform == 'Affine' and mov.shape[1] >= icp_shard_min_points:
-        A_icp, res = icp_sharded(be, moved, fix, int(icp_iterations), group)
-        if details is not None:
-            details['residuals'] = res.cpu().numpy()
-    else:
+        try:
+            A_icp, res = icp_sharded(be, moved, fix, int(icp_iterations), group)
+            sharded_icp_done = True
+            if details is not None:
+                details['residuals'] = res.cpu().numpy()
+        except PlanarCloud:
+            pass                     # (every rank arrives here together) -> the replicated loop below, which has the host's pinv fits
+    if not sharded_icp_done:
         log = {} if details is not None else None
         if icp_one_launch is None:
             A_icp = be.icp(moved, fix, int(icp_iterations), transform, log)         # :715-717

@@ -46,6 +46,27 @@ def test_ranks_sharing_the_gpu_reproduce_the_one_process_registration(world, n, 
     assert len(lines) == 2 and all(l.endswith("OK") for l in lines), p.stdout[-2500:]
 
 
+def test_sharded_run_on_a_lattice_cloud_gathers_what_ties_leave_uncertified():
+    """tests/soak_cases.py case 29: a coarse lattice with duplicates — exact ties in every cost matrix.  Streamed over three
+    ranks the sharded solve cannot certify a unique optimum; the pairing's blocks then go to the hypothesis's owner and SciPy's
+    algorithm answers (round 3; before: a refusal).  Same assignments, inlier counts and A_sc as the one-process run."""
+    p = _ranks(3, [2600, 2600, 29], PM_SOAK_CASE="1", PM_STREAM_HYPOTHESES="1")
+    assert p.returncode == 0, (p.stdout[-2500:], p.stderr[-2500:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("ICP ")]
+    assert len(lines) == 2 and all(l.endswith("OK") for l in lines), p.stdout[-2500:]
+    assert "'gathered'" in p.stdout
+
+
+def test_sharded_icp_on_a_nearly_planar_cloud_falls_back_to_the_replicated_loop():
+    """tests/soak_cases.py case 3: one axis 0.2 of the others and a transform that flattens it further — the sharded ICP's normal
+    equations are too ill-conditioned (pm_solve.h: PM_DEGENERATE_MOMENTS); every rank leaves it together and runs the replicated
+    loop with the reference's pinv fits (round 3; before: a refusal).  Equal to the one-process run."""
+    p = _ranks(2, [2600, 2600, 3], PM_SOAK_CASE="1")
+    assert p.returncode == 0, (p.stdout[-2500:], p.stderr[-2500:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("ICP ")]
+    assert len(lines) == 2 and all(l.endswith("OK") for l in lines), p.stdout[-2500:]
+
+
 def test_bench_step_on_two_ranks_sharing_the_gpu():
     """`python bench.py --gpus 2` through its own launcher, the ranks put on cuda:0 and gloo in RCCL's place (rehearsal
     switches of bench.py): the sharded step end to end, one JSON line from rank 0."""

@@ -27,8 +27,13 @@ torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 m = int(sys.argv[2]) if len(sys.argv) > 2 else n - 37       # N > M by default (assignment by gather); pass M >= N for the sharded solve
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 77
-mv, fx, _ = synth_pair(max(n, m), seed, m=m)
-mv = np.ascontiguousarray(mv[:, :n])
+if os.environ.get("PM_SOAK_CASE") == "1":            # a case of tests/soak_cases.py (lattice clouds, duplicates, odd scales) instead of the blob
+    from soak_cases import make_case
+    mv, fx, _, _, _ = make_case(seed, max(n, m))
+    n, m = mv.shape[1], fx.shape[1]
+else:
+    mv, fx, _ = synth_pair(max(n, m), seed, m=m)
+    mv = np.ascontiguousarray(mv[:, :n])
 kw = dict(ransac_trials=500, ransac_error=8.0, icp_iterations=12, seed=4)
 streamed = os.environ.get("PM_STREAM_HYPOTHESES") == "1"       # two cost matrices resident at a time on every rank (config 4's mode)
 ok = True
