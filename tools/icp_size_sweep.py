@@ -50,6 +50,12 @@ for n, m in sizes:
         _, parts = K.icp_update(sums, origin, loc, fix, nn, A2, nn_trusted=True)
         ok &= bits(parts[0] / parts[1], res[it])
     ok &= bits(A.reshape(16), A2) and bits(work, loc)
+    if 2 <= n <= 70000:                       # the one-launch persistent loop (an option): the same bits, or an honest status 2
+        w1 = start.clone()
+        st = torch.zeros(1, dtype=torch.int32, device=dev)
+        A1, res1, nn1 = K.icp(w1, fix, iters, want_nn=True, one_launch=True, status=st)
+        if int(st.item()) != 2:
+            ok &= bits(A1.reshape(16), A.reshape(16)) and bits(w1, work) and bits(res1, res) and bool(torch.equal(nn1, nn_all))
     torch.cuda.synchronize()
     bad += not ok
     print("N=%8d M=%8d: %s  (%s reference search, %.1f s)" % (n, m, "identical" if ok else "MISMATCH", "brute-force" if brute else "grid (rings)",
