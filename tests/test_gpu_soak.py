@@ -93,3 +93,49 @@ def test_a_slice_of_the_awkward_family(ready, oracle):
         if np.isfinite(ref[0]).all() and np.isfinite(ref[1]).all() and np.linalg.cond(ref[0]) < 1e8:
             assert relerr(got[1] @ got[0], ref[1] @ ref[0]) < 1e-6, (seed, c["kind"])
     assert seen == {0, 1, 2, 3, 4, 5}
+
+
+def test_product_on_the_reference_outputs_for_36_random_small_clouds(ready):
+    """tests/golden/random_small.npz holds what the unmodified reference computes for 36 generic pairs of 8-40 points.  The HIP
+    path against it directly (no oracle in between): centroid and mean distance bit for bit, every histogram, the two stored cost
+    matrices (one ulp off in the same 12 of 39 992 entries as any correctly rounded squaring: libm's pow), seeded
+    do_ransac's inlier count and model (the reference's own bits: the winner is refitted by its expression), perform_icp within 1e-9."""
+    import os
+    import torch
+    from platymatch_amd import _kernels as K, _native as nat
+    from platymatch_amd.estimate_transform import perform_icp as pi, shape_context as sc
+    pi.VERBOSE = False
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "random_small.npz"))
+    dev = torch.device("cuda:0")
+    off = entries = 0
+    for k in range(int(d["cases"][0])):
+        p = "c%02d_" % k
+        mv, fx = d[p + "moving"], d[p + "fixed"]
+        desc = {}
+        for cloud, key, nf, ckey in ((mv, "m", 2, "counts_m"), (fx, "f", 4, "counts_f")):
+            x = nat.to_dev(cloud, dev=dev)
+            c, md, x0 = K.centroid(x), K.mean_distance(x), K.pca_axis(x)
+            assert np.array_equal(c.cpu().numpy(), np.ravel(d[p + "centroid_" + key]))
+            assert md.item() == d[p + "mean_dist"][0 if key == "m" else 1]
+            r = K.shape_context(x, c, x0, md, nf, want_counts=True, want_hist=True)
+            assert np.array_equal(r["counts"].cpu().numpy(), d[p + ckey]), (k, key)
+            assert r["guard"].cpu().tolist() == [0, 0]
+            desc[key] = r["hist"]
+        U8 = K.chi2_cost8(desc["m"], desc["f"]).cpu().numpy()
+        for name, h in (("U11", 0), ("U24", 7)):
+            got, want = U8[h], d[p + name]
+            diff = got != want
+            entries += want.size
+            off += int(diff.sum())
+            assert np.all(np.abs(got[diff].view(np.int64) - want[diff].view(np.int64)) <= 1), (k, name)
+        pq = min(mv.shape[1], fx.shape[1])
+        for tr in ("Affine", "Similar"):
+            np.random.seed(int(d[p + "seed"][0]))
+            A, inl = sc.do_ransac(mv[:, :pq], fx[:, :pq], 4, 30, 10.0, tr)
+            assert int(inl) == int(d[p + "ransac_inl_" + tr][0]), (k, tr)
+            assert np.array_equal(np.asarray(A), d[p + "ransac_A_" + tr]), (k, tr)
+            got = np.asarray(pi.perform_icp(mv, fx, 5, tr))
+            want = d[p + "icp_" + tr]
+            if np.isfinite(want).all():
+                assert relerr(got, want) < 1e-9, (k, tr, relerr(got, want))
+    assert entries == 39992 and off == 12, (off, entries)

@@ -148,3 +148,42 @@ def test_oracle_reproduces_ransac_k_fixture(oracle):
     np.random.seed(13)
     A, inl = oracle.do_ransac(d["halfplane_moving"], d["halfplane_fixed"], 4, 300, 3.0)
     assert inl == int(d["halfplane_ransac_inliers"]) and np.array_equal(A, d["halfplane_ransac_A"])
+
+
+# ------------------------------------------------------------------------------------------------ random small clouds (round 3)
+def _random_small():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "random_small.npz"))
+
+
+def test_oracle_reproduces_the_reference_on_36_random_small_clouds(oracle):
+    """tests/golden/random_small.npz (gen_random_small.py: the unmodified reference on 36 generic pairs of 8-40 points): centroid,
+    mean distance, every histogram, seeded do_ransac and perform_icp in both modes — bit for bit; the two stored chi-square
+    matrices bit for bit except where libm's pow(x, 2.0) behind the reference's `** 2` is not x * x: at most one
+    ulp, in 12 of the 39 992 entries."""
+    d = _random_small()
+    off = entries = 0
+    for k in range(int(d["cases"][0])):
+        p = "c%02d_" % k
+        mv, fx = d[p + "moving"], d[p + "fixed"]
+        n, m = mv.shape[1], fx.shape[1]
+        assert np.array_equal(np.asarray(oracle.get_centroid(mv, False)), d[p + "centroid_m"])
+        assert np.array_equal(np.asarray(oracle.get_centroid(fx, False)), d[p + "centroid_f"])
+        assert oracle.get_mean_distance(mv, False) == d[p + "mean_dist"][0] and oracle.get_mean_distance(fx, False) == d[p + "mean_dist"][1]
+        cm, tm = oracle.shape_context_counts(oracle.get_centroid(mv, False), oracle.get_mean_distance(mv, False), mv, "moving")
+        cf, tf = oracle.shape_context_counts(oracle.get_centroid(fx, False), oracle.get_mean_distance(fx, False), fx, "fixed")
+        assert np.array_equal(cm, d[p + "counts_m"]) and np.array_equal(cf, d[p + "counts_f"]), k
+        um, uf = oracle.normalise_counts(cm, tm), oracle.normalise_counts(cf, tf)
+        for name, a, b in (("U11", um[0], uf[0]), ("U24", um[1], uf[3])):
+            got, want = np.asarray(oracle.unary_distance_matrix(a, b)), d[p + name]
+            diff = got != want
+            entries += want.size
+            off += int(diff.sum())
+            assert np.all(np.abs(got[diff].view(np.int64) - want[diff].view(np.int64)) <= 1), (k, name)     # one ulp at most
+        pq = min(n, m)
+        for tr in ("Affine", "Similar"):
+            np.random.seed(int(d[p + "seed"][0]))
+            A, inl = oracle.do_ransac(mv[:, :pq], fx[:, :pq], 4, 30, 10.0, tr)
+            assert int(inl) == int(d[p + "ransac_inl_" + tr][0]) and np.array_equal(np.asarray(A), d[p + "ransac_A_" + tr]), (k, tr)
+            assert np.array_equal(np.asarray(oracle.perform_icp(mv, fx, 5, tr)), d[p + "icp_" + tr], equal_nan=True), (k, tr)
+    assert entries == 39992 and off == 12, (off, entries)          # deterministic data: exactly these twelve, one ulp each
