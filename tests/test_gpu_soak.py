@@ -139,3 +139,34 @@ def test_product_on_the_reference_outputs_for_36_random_small_clouds(ready):
             if np.isfinite(want).all():
                 assert relerr(got, want) < 1e-9, (k, tr, relerr(got, want))
     assert entries == 39992 and off == 12, (off, entries)
+
+
+def test_edge_guard_of_zero_means_the_references_histograms_on_voxel_and_lattice_clouds(ready):
+    """tests/golden/random_lattice.npz: the unmodified reference's four descriptor sets for 90 small clouds on integer voxel
+    coordinates, on a coarse lattice, and with integer x, y and a float z (the layout of the reference's own assets).  There
+    neighbours sit exactly on bin boundaries and the reference bins them by the rounding noise of its np.linalg.inv (DESIGN.md
+    §2).  The statement under test: whenever the call's edge guard is [0, 0], the HIP path's histograms ARE the reference's;
+    and a cloud whose histograms differ always has a non-zero guard."""
+    import os
+    import torch
+    from platymatch_amd import _kernels as K, _native as nat
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "random_lattice.npz"))
+    dev = torch.device("cuda:0")
+    unguarded = guarded = guarded_equal = 0
+    for k in range(int(d["cases"][0])):
+        p = "c%02d_" % k
+        cloud, cnt, tot = d[p + "cloud"], d[p + "counts"].astype(np.float64), d[p + "totals"].astype(np.float64)
+        with np.errstate(all="ignore"):
+            want = np.where(tot[:, :, None] < 0, np.nan, cnt / np.where(tot > 0, tot, np.nan)[:, :, None])
+        x = nat.to_dev(cloud, dev=dev)
+        r = K.shape_context(x, K.centroid(x), K.pca_axis(x), K.mean_distance(x), 4)
+        got = r["hist"].cpu().numpy()
+        same = np.array_equal(got, want, equal_nan=True)
+        if r["guard"].cpu().tolist() == [0, 0]:
+            unguarded += 1
+            assert same, k                              # guard 0 => the reference's histograms, lattice or not
+        else:
+            guarded += 1
+            guarded_equal += same
+    assert unguarded >= 60 and guarded >= 3 and guarded_equal < guarded, (unguarded, guarded, guarded_equal)     # (83, 7, 2) when written
+    print("clouds with guard 0 (all equal to the reference): %d; with a non-zero guard: %d, of which equal all the same: %d" % (unguarded, guarded, guarded_equal))
