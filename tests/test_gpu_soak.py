@@ -170,3 +170,32 @@ def test_edge_guard_of_zero_means_the_references_histograms_on_voxel_and_lattice
             guarded_equal += same
     assert unguarded >= 60 and guarded >= 3 and guarded_equal < guarded, (unguarded, guarded, guarded_equal)     # (83, 7, 2) when written
     print("clouds with guard 0 (all equal to the reference): %d; with a non-zero guard: %d, of which equal all the same: %d" % (unguarded, guarded, guarded_equal))
+
+
+def test_product_end_to_end_on_the_references_24_random_small_pairs(ready):
+    """tests/golden/random_e2e.npz: the unmodified reference end to end on generic, voxel, lattice and asset-like pairs.  The HIP
+    path against it directly: whenever the call's edge guard is zero — the eight assignment vectors, the inlier counts, A_sc
+    (bit for bit: the winner's model is the reference's own expression), every ICP correspondence; A_final to 1e-9."""
+    import os
+    import platymatch_amd
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "random_e2e.npz"))
+    checked = guarded = guarded_equal = 0
+    for k in range(int(d["cases"][0])):
+        p = "c%02d_" % k
+        det = {}
+        got = platymatch_amd.register(d[p + "moving"], d[p + "fixed"], ransac_trials=60, ransac_error=12.0, icp_iterations=4, seed=0, details=det)
+        same = (all(np.array_equal(det["lsa"][h][0], d[p + "lsa_rows"][h]) and np.array_equal(det["lsa"][h][1], d[p + "lsa_cols"][h]) for h in range(8))
+                and np.array_equal(got[2], d[p + "ransac_inliers"]) and np.array_equal(np.asarray(got[0]), d[p + "A_sc"])
+                and np.array_equal(np.asarray(det["nn"]), d[p + "icp_nn"]))
+        g = det["edge_guard"]
+        if sum(v for side in g.values() for v in side.values()) == 0:
+            checked += 1
+            assert same, (k, int(d[p + "kind"][0]))
+            assert relerr(np.asarray(got[1]) @ np.asarray(got[0]), d[p + "A_final"]) < 1e-9, k
+        else:
+            guarded += 1
+            guarded_equal += same
+    assert checked >= 12, (checked, guarded, guarded_equal)
+    print("pairs with a zero edge guard (all equal to the reference): %d; guarded: %d, of which equal all the same: %d" % (checked, guarded, guarded_equal))

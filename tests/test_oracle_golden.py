@@ -187,3 +187,27 @@ def test_oracle_reproduces_the_reference_on_36_random_small_clouds(oracle):
             assert int(inl) == int(d[p + "ransac_inl_" + tr][0]) and np.array_equal(np.asarray(A), d[p + "ransac_A_" + tr]), (k, tr)
             assert np.array_equal(np.asarray(oracle.perform_icp(mv, fx, 5, tr)), d[p + "icp_" + tr], equal_nan=True), (k, tr)
     assert entries == 39992 and off == 12, (off, entries)          # deterministic data: exactly these twelve, one ulp each
+
+
+def test_oracle_end_to_end_on_24_random_small_pairs(oracle):
+    """tests/golden/random_e2e.npz (gen_random_e2e.py: the unmodified reference end to end on generic, voxel, lattice and
+    asset-like pairs of 14-35 points).  Generic pairs: the eight assignment vectors, inlier counts, A_sc, every ICP correspondence
+    and A_final bit for bit.  Pairs with lattice structure: the same wherever no neighbour sits on a bin boundary (the oracle has no
+    guard of its own: the count of such pairs that agree is reported; the HIP path's guard is tested on the GPU)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "random_e2e.npz"))
+    agree = {0: [0, 0], 1: [0, 0], 2: [0, 0], 3: [0, 0]}
+    for k in range(int(d["cases"][0])):
+        p = "c%02d_" % k
+        kind = int(d[p + "kind"][0])
+        det = {}
+        got = oracle.estimate_transform(d[p + "moving"], d[p + "fixed"], ransac_trials=60, ransac_error=12.0, icp_iterations=4, seed=0, details=det)
+        same = (all(np.array_equal(det["lsa"][h][0], d[p + "lsa_rows"][h]) and np.array_equal(det["lsa"][h][1], d[p + "lsa_cols"][h]) for h in range(8))
+                and np.array_equal(got[2], d[p + "ransac_inliers"]) and np.array_equal(got[0], d[p + "A_sc"])
+                and np.array_equal(np.asarray(det["nn"]), d[p + "icp_nn"]) and np.array_equal(got[1] @ got[0], d[p + "A_final"]))
+        agree[kind][0] += same
+        agree[kind][1] += 1
+        if kind == 0:
+            assert same, k
+    assert agree[0] == [6, 6]
+    print("pairs equal to the reference end to end / pairs: generic %s, voxel %s, lattice %s, asset-like %s" % tuple(agree[k] for k in range(4)))
