@@ -123,7 +123,8 @@ while time.perf_counter() < t_end:
         counts["similar"] += transform == "Similar"
     except Exception as e:                                   # a refusal (ties beyond the solver, degenerate input) must be the SAME on both sides
         try:
-            oracle.estimate_transform(mv, fx, transform=transform, ransac_trials=80, ransac_error=25.0, icp_iterations=4, seed=rs)
+            oracle.estimate_transform(mv, fx, transform=transform, ransac_trials=80, ransac_error=25.0 * (np.abs(mv).max() / 300.0 + 1e-9),
+                                      icp_iterations=4, seed=rs)
             fails.append(tag + ": the product raised %s: %s, the oracle did not" % (type(e).__name__, str(e)[:200]))
         except Exception:
             counts["skipped_registration"] += 1
