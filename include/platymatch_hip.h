@@ -418,10 +418,14 @@ int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_ic
  * the search tables stay warm in L2, and an iteration ends with the reduction tree of pm_icp plus the publication of the
  * fitted transform through a generation word (no kernel boundary, no reload of the cloud, no gather of the previous matches).
  * CONTRACT: at most ONE pm_icp_one_launch may be in flight per device — two half-resident persistent grids can starve each
- * other; callers serialise (the Python mirror holds a per-device lock until the stream has drained).  Ordinary kernels on
+ * other.  The library enforces it (round 4): a per-device flag is taken by the call and handed back by a host function its
+ * stream runs when the call's work has finished; a second call on the same device meanwhile returns PM_ERR_UNSUPPORTED and
+ * enqueues nothing (call pm_icp instead, or wait).  (The only process-global state in the library besides the occupancy cache;
+ * the Python mirror additionally holds a per-device lock until the stream has drained, so it never sees the refusal.)  Ordinary kernels on
  * other streams may run beside it, but while they hold CUs that workgroups of this grid are waiting for, the resident ones
  * spin: meant for a device that is otherwise idle (one registration at a time) — a batch of registrations on many streams
- * should call pm_icp.  If the grid does not fit the device at once (more than 65 536 points), or iters < 3, the call runs
+ * should call pm_icp.  If the grid does not fit the device at once with one workgroup per CU to spare (about 49 000 points at four
+ * workgroups per CU on 256 CUs), or iters < 3, the call runs
  * pm_icp's launch-per-iteration path.  A workgroup that has waited 2 s for a round gives up and reports status1 = 2: results
  * are then undefined and the caller reruns with pm_icp. */
 int pm_icp_one_launch(double *mov, int n, const double *fix, int m, int iters, double *A_icp16,

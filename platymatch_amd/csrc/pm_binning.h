@@ -208,7 +208,12 @@ PM_HD int pm_bin_index(double x_, double y_, double z_, double r_, double r) {
 #define PM_TAN30F 0x1.279a74p-1f
 #define PM_TAN60F 0x1.bb67aep+0f
 
-PM_HD int pm_bin_fast32(float f0, float f1, float f2, const float fr[9], float k64) {
+// min_L: the float32 result is taken only for neighbours with |f|_1 > min_L.  The tile kernel passes 2^17 x the ABSOLUTE noise the
+// reference's inv()-based local coordinates carry for this query (PM_GUARD_REF x |p|_1, pm_shape_context.hip): a neighbour clear
+// of a boundary by 2^-17 L (relative to ITS OWN length) is then also clear of the reference's noise band, so whatever float32
+// decides lies outside the edge guard's reach; nearer neighbours (1e-5 away at coordinates of ~500) go to the float64 path, where
+// the guard counts them.  0 = no such floor (the host harness's default).
+PM_HD int pm_bin_fast32(float f0, float f1, float f2, const float fr[9], float k64, float min_L) {
     const float L = (__builtin_fabsf(f0) + __builtin_fabsf(f1)) + __builtin_fabsf(f2);
     const float vx = __builtin_fmaf(fr[2], f2, __builtin_fmaf(fr[1], f1, fr[0] * f0));
     const float vy = __builtin_fmaf(fr[5], f2, __builtin_fmaf(fr[4], f1, fr[3] * f0));
@@ -233,7 +238,7 @@ PM_HD int pm_bin_fast32(float f0, float f1, float f2, const float fr[9], float k
     const float nearQ = __builtin_fminf(__builtin_fabsf(dd1), __builtin_fabsf(dd3));
     const float nearL = __builtin_fminf(__builtin_fminf(__builtin_fabsf(vz), __builtin_fabsf(d1)),
                                         __builtin_fminf(__builtin_fabsf(d2), __builtin_fminf(ax, ay)));
-    const int safe = (nearQ > mQ) & (nearL > mL) & ((e - 40u) < 176u) & (dist >= 256u);
+    const int safe = (nearQ > mQ) & (nearL > mL) & ((e - 40u) < 176u) & (dist >= 256u) & (L > min_L);
     int ring = (E >> 1) + 1;                               // #{k : w >= 4^k, k = 0..3}
     ring = ring < 0 ? 0 : (ring > 4 ? 4 : ring);
     const int c = (dd1 > 0.0f) + (dd3 > 0.0f);

@@ -11,6 +11,7 @@
 // the (rare) remaining sliver — see NnBest.
 // Squared distances use the reference's operation order ((d0*d0 + d1*d1) + d2*d2, d = fixed - moving),
 // one rounding each, so indices match np.argmin bit for bit.
+#include <atomic>
 #include "pm_common.h"
 
 namespace pm {
@@ -298,9 +299,30 @@ int pm_icp(double *mov, int n, const double *fix, int m, int iters, double *A_ic
     return icp_run(false, mov, n, fix, m, iters, A_icp16, residuals, nn_all, status1, ws, ws_bytes, stream);
 }
 
+// One persistent grid in flight per device (two half-resident ones can starve each other): a flag per device, taken here and
+// handed back by a host function the stream runs once everything this call enqueued has finished.  A second call on the same
+// device while the flag is held is refused with PM_ERR_UNSUPPORTED (the caller takes pm_icp, or waits) — the library's own
+// enforcement of the contract in the header; the Python mirror's per-device lock merely avoids ever seeing the refusal.
+static std::atomic<int> g_one_launch_busy[64];
+static void one_launch_done(void *flag) { ((std::atomic<int> *)flag)->store(0, std::memory_order_release); }
+
 int pm_icp_one_launch(double *mov, int n, const double *fix, int m, int iters, double *A_icp16, double *residuals, int32_t *nn_all,
                       int32_t *status1, void *ws, size_t ws_bytes, void *stream) {
-    return icp_run(true, mov, n, fix, m, iters, A_icp16, residuals, nn_all, status1, ws, ws_bytes, stream);
+    if (!mov || !fix || !A_icp16 || n <= 0 || m <= 0 || iters < 0) return PM_ERR_INVALID_ARG;
+    if (iters < 3 || !pm::icp_loop_fits(n))               // the launch-per-iteration path: nothing persistent, nothing to reserve
+        return icp_run(false, mov, n, fix, m, iters, A_icp16, residuals, nn_all, status1, ws, ws_bytes, stream);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return PM_ERR_INVALID_ARG;
+    std::atomic<int> &busy = g_one_launch_busy[dev];
+    int expected = 0;
+    if (!busy.compare_exchange_strong(expected, 1, std::memory_order_acquire)) return PM_ERR_UNSUPPORTED;
+    const int rc = icp_run(true, mov, n, fix, m, iters, A_icp16, residuals, nn_all, status1, ws, ws_bytes, stream);
+    if (hipLaunchHostFunc((hipStream_t)stream, one_launch_done, &busy) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize((hipStream_t)stream);   // no callback: drain here, then hand the flag back
+        busy.store(0, std::memory_order_release);
+    }
+    return rc;
 }
 
 }  // extern "C"

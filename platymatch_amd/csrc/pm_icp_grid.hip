@@ -11,6 +11,7 @@
 // point that could tie or win lies within the explored radius; candidate order does not matter since ties are broken
 // on the stored original index explicitly.  Work per iteration drops from N*M to ~N * (points in ~27 cells).
 #include <algorithm>
+#include <atomic>
 #include "pm_common.h"
 #include "pm_solve.h"
 
@@ -951,27 +952,35 @@ size_t iter_counter_bytes(int n) { return iter_gen_offset(n) + 1024; }   // [tot
 
 // How many workgroups of the loop kernel the device holds at once; 0 if the query fails.  The occupancy query can be one high
 // when the SGPR count is what binds (MI355X_MICROARCH.md, "Residency and cooperative launch": admitted per CU =
-// min(query, 8, floor(800 / (ceil(sgpr/16)*16 + 16)))); at the architectural maximum of SGPRs that bound is 5, so the answer
-// is capped at 5 whatever the compiler allocated (the kernel is built for 4: __launch_bounds__(256, 4) and 37 KB of LDS).
+// min(query, 8, floor(800 / (ceil(sgpr/16)*16 + 16)))); at the architectural maximum of SGPRs that bound is 5, so the query is
+// capped at 5 whatever the compiler allocated (the kernel is built for 4: __launch_bounds__(256, 4) and 37 KB of LDS) — and ONE
+// workgroup per CU of that is kept back as margin for foreign kernels' workgroups already resident when the grid arrives.
 template <int L>
-static int loop_capacity_of() {
-    int dev = 0, cus = 0, per = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
+static int loop_capacity_of(int dev) {
+    int cus = 0, per = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, icp_loop_kernel<L>, 256, 0) != hipSuccess) return 0;
-    per = std::min(per, 5);
+    per = std::min(per, 5) - 1;
     return per > 0 ? per * cus : 0;
 }
 
 int icp_loop_lanes(int n) { return n >= GR_ITER_FEW_LANES_FROM ? 4 : 8; }
 
 bool icp_loop_fits(int n) {
-    static thread_local int cap4 = -1, cap8 = -1;        // (one device per calling thread in practice; a query costs microseconds)
+    // cached per DEVICE (CU count and partition mode differ between devices; a thread may switch): [device][lanes == 4]
+    constexpr int MAX_DEV = 64;
+    static std::atomic<int> cap[MAX_DEV][2];               // 0 = not asked yet (stored as capacity + 1)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
     const int lanes = icp_loop_lanes(n);
-    int &cap = lanes == 4 ? cap4 : cap8;
-    if (cap < 0) cap = lanes == 4 ? loop_capacity_of<4>() : loop_capacity_of<8>();
+    std::atomic<int> &slot = cap[dev][lanes == 4];
+    int c = slot.load(std::memory_order_relaxed);
+    if (c == 0) {
+        c = (lanes == 4 ? loop_capacity_of<4>(dev) : loop_capacity_of<8>(dev)) + 1;
+        slot.store(c, std::memory_order_relaxed);
+    }
     const long blocks = ((long)n * lanes + 255) / 256;
-    return blocks <= cap;
+    return blocks <= c - 1;
 }
 
 // iterations first_it .. iters-1 in one launch (first_it >= 1: the launch before fitted A_est and left its matches in nn_prev)

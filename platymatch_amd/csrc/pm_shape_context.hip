@@ -55,7 +55,7 @@ constexpr int SC_FR = 10;             // doubles per row of frames64
 //   redo     [tiles]    int32    1 = recompute this tile with the general kernel
 struct alignas(64) ScQuery {          // what the tile kernel needs of one queried point: 16 dwords, one scalar load
     float fr[9];
-    float pad;
+    float min_L;                       // 2^17 x PM_GUARD_REF x |p|_1: float32's verdict is only taken for neighbours longer than this (pm_bin_fast32)
     double p[3];
 };
 static_assert(sizeof(ScQuery) == 64, "one s_load_dwordx16");
@@ -110,9 +110,9 @@ __global__ __launch_bounds__(256) void sc_prepare_kernel(const double *__restric
 #pragma unroll
     for (int k = 0; k < 9; ++k) { frames64[(size_t)r * SC_FR + k] = fr[k]; rec.fr[k] = (float)fr[k]; }
     frames64[(size_t)r * SC_FR + 9] = fr[9];
-    rec.pad = 0.0f;
     const int i = row0 + r;
     rec.p[0] = xyz[i]; rec.p[1] = xyz[(size_t)n + i]; rec.p[2] = xyz[2 * (size_t)n + i];
+    rec.min_L = (float)(PM_GUARD_REF * 0x1p+17 * ((__builtin_fabs(rec.p[0]) + __builtin_fabs(rec.p[1])) + __builtin_fabs(rec.p[2]))) * 1.0001f;
     ((ScQuery *)frames32)[r] = rec;
 }
 
@@ -208,7 +208,9 @@ __global__ __launch_bounds__(SC_THREADS) void sc_tile_kernel(
         auto one_query = [&](const ScQuery &r, int q) {
             const double v0 = pj0 - r.p[0], v1 = pj1 - r.p[1], v2 = pj2 - r.p[2];   // np.delete (:168): the point itself gives v = 0, dropped below as NaN
             const float fr[9] = {r.fr[0], r.fr[1], r.fr[2], r.fr[3], r.fr[4], r.fr[5], r.fr[6], r.fr[7], r.fr[8]};
-            int bin = fast_ok ? pm_bin_fast32((float)v0, (float)v1, (float)v2, fr, k64) : -1;
+            // the reference's inv() leaves PM_GUARD_REF x |p|_1 on every local coordinate of this query: float32's verdict is taken
+            // only for neighbours whose own 2^-17 clearance exceeds it (r.min_L, from the prepare kernel; pm_bin_fast32)
+            int bin = fast_ok ? pm_bin_fast32((float)v0, (float)v1, (float)v2, fr, k64, r.min_L) : -1;
             if (bin < 0 && valid) {
                 // not clear of a boundary in float32 (or the pair of the point with itself / a duplicate: v = 0 -> NaN -> not
                 // counted, exactly as arccos(0/0) in the reference): the float64 expressions decide

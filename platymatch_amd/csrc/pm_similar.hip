@@ -112,6 +112,7 @@ __global__ __launch_bounds__(SM_THREADS) void sim_leaf_kernel(const SimSrc s, co
     const int tid = blockIdx.x * SM_THREADS + threadIdx.x;
     const int k = tid >> 3, j = tid & 7;
     const int leaves = plan->leaves;
+    if (leaves <= 0) return;                             // plan overflow (plan->bad; sim_combine reports NaN): uniform exit, nothing to read
     const int kc = min(k, leaves - 1);                   // surplus groups shadow the last leaf (no divergent exit before shuffles)
     const int o = off[kc], len = off[kc + 1] - o;
     double r[Q];
@@ -170,6 +171,7 @@ __global__ void sim_combine_kernel(const double *__restrict__ leafsum, int leaf_
                                    double *__restrict__ out) {
     const int q = threadIdx.x;
     if (q >= Q) return;
+    if (plan->bad) { out[q] = __builtin_nan(""); return; }     // the leaf plan did not fit its capacities: say so loudly, not garbage with PM_OK
     const double total = pm_pw_combine(leafsum + (size_t)q * leaf_cap, off, chunk_first, plan->chunks, n);
     out[q] = divide_by_n ? total / (double)n : total;
 }

@@ -6,6 +6,11 @@
 
 namespace pm {
 
+// the partial pieces below plan their leaves into 160 offsets / 4 chunk slots: a piece has at most PM_PW_CHUNK elements, i.e. at most
+// PM_PW_CHUNK / 57 + 2 leaves in one chunk, so pm_pw_plan cannot overflow there (its return value is the leaf count, never -1)
+static_assert(PM_PW_CHUNK / 57 + 3 <= 160, "leaf capacity of a piece");
+
+
 constexpr int STAT_THREADS = 1024;
 
 // ---- centroid in NumPy's own summation order (round 3) ------------------------------------------------------------------

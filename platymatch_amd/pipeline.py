@@ -42,31 +42,61 @@ def _cost_key(device):
     return (device.index, torch.cuda.current_stream(device).cuda_stream)
 
 
+class _CostLease:
+    """A registration's hold on the kept cost buffer of its (device, stream): release() — always from a finally — makes the
+    buffer available to the next registration.  A buffer is handed to ONE registration at a time: two host threads registering
+    on the same stream (e.g. both on the default stream) must not write their matrices into the same storage while the other's
+    assignment passes still read it."""
+
+    def __init__(self, key, view):
+        self.key, self.view = key, view
+
+    def release(self):
+        with _COST_LOCK:
+            e = _COST_CACHE.get(self.key)
+            if e is not None and e["lease"] is self:
+                e["lease"] = None
+        self.view = None
+
+
 def cost_buffer(device, shape):
-    """A float64 [shape] view of this (device, stream)'s kept buffer, grown if it is too small (the old one is released first)."""
+    """Lease a float64 [shape] view of this (device, stream)'s kept buffer, grown if it is too small (the old one is released
+    first).  -> _CostLease, or None when another registration holds the buffer: the caller then takes a fresh allocation."""
     import torch
     need = int(np.prod(shape))
     key = _cost_key(device)
     with _COST_LOCK:
-        t = _COST_CACHE.get(key)
-        if t is None or t.numel() < need:
+        e = _COST_CACHE.get(key)
+        if e is not None and e["lease"] is not None:
+            return None
+        if e is None or e["t"].numel() < need:
             _COST_CACHE.pop(key, None)
-            t = None                                       # (released before the larger one is asked for)
-            t = torch.empty(need, dtype=torch.float64, device=device)
-            _COST_CACHE[key] = t
-    return t[:need].view(*shape)
+            e = None                                       # (released before the larger one is asked for)
+            e = {"t": torch.empty(need, dtype=torch.float64, device=device), "lease": None}
+            _COST_CACHE[key] = e
+        lease = _CostLease(key, e["t"][:need].view(*shape))
+        e["lease"] = lease
+    return lease
 
 
 def kept_cost_bytes(device):
+    """Bytes of this (device, stream)'s kept buffer that a new registration can have (0 while another one holds it)."""
     with _COST_LOCK:
-        t = _COST_CACHE.get(_cost_key(device))
-    return 0 if t is None else t.numel() * 8
+        e = _COST_CACHE.get(_cost_key(device))
+        return 0 if (e is None or e["lease"] is not None) else e["t"].numel() * 8
 
 
 def release_cost_buffers():
-    """Hand every kept cost buffer back to torch's allocator (and, with torch.cuda.empty_cache(), to the driver)."""
+    """Hand every kept cost buffer that no registration holds back to torch's allocator (and, with torch.cuda.empty_cache(), to
+    the driver); a buffer in use goes when its registration releases it... the next call of this function."""
     with _COST_LOCK:
-        _COST_CACHE.clear()
+        for key in [k for k, e in _COST_CACHE.items() if e["lease"] is None]:
+            del _COST_CACHE[key]
+
+
+class EdgeGuardWarning(UserWarning):
+    """estimate_transform met neighbours that sit on a bin boundary of the shape context within the reference's own rounding
+    noise: the integer histograms are then not defined by the reference's source alone."""
 
 
 class GpuBackend:
@@ -763,8 +793,9 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         draws = _SampleDraws(be, min(mov.shape[1], fix.shape[1]), int(ransac_samples), 0 if on_device else int(ransac_trials),
                              seed, private_rng)
         a_info = None if details is None else details.setdefault("assignment", {})
+        lease = None
         try:
-            guards = [] if details is not None else None
+            guards = [] if getattr(be, "device_sampler", False) else None     # (the GPU backend: its descriptor launches count)
             sc_m, sc_f, bn = build_descriptors(be, mov, fix, group, guards=guards)
             # all eight matrices at once when they fit (four assignments then run side by side); otherwise two at a time
             need = cost_bytes(sc_m.shape[1], mov.shape[1], sc_f.shape[1], world)
@@ -777,12 +808,14 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                 streamed = bool(agree_max(1 if streamed else 0, group, mov.device))
             if streamed:
                 U = None
-            elif keep_cost_buffer and mov.is_cuda and need >= COST_CACHE_MIN_BYTES and world == 1:
-                U = be.chi2_cost8(sc_m, sc_f, out=cost_buffer(mov.device, (8, sc_m.shape[1], sc_f.shape[1])))
             else:
-                U = be.chi2_cost8(sc_m, sc_f)
+                if keep_cost_buffer and mov.is_cuda and need >= COST_CACHE_MIN_BYTES and world == 1:
+                    lease = cost_buffer(mov.device, (8, sc_m.shape[1], sc_f.shape[1]))     # None: another registration holds it
+                U = be.chi2_cost8(sc_m, sc_f, out=None if lease is None else lease.view)
         except BaseException:
             draws.thread.join()
+            if lease is not None:
+                lease.release()
             raise
         t0 = mark("gpu_descriptors_costs", t0)
         try:
@@ -793,6 +826,10 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                 lsa = assign(U, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None), accept_near_ties=accept_near_ties)
         finally:
             del U, sc_m, sc_f
+            if lease is not None:
+                if mov.is_cuda:
+                    torch.cuda.current_stream(mov.device).synchronize()     # the assignment's last passes have read the buffer
+                lease.release()
             t0 = mark("host_assignment", t0)
             sets = draws.result()                    # every rank draws the same 8 x trials: same RNG stream everywhere
             t0 = mark("host_draws_exposed", t0)
@@ -823,11 +860,22 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         t0 = mark("gpu_ransac", t0)
         if details is not None:
             details.update(lsa=lsa, ransac_A=torch.stack(A_h).cpu().numpy())
-            if guards:
-                # neighbours (of this rank's rows) whose bin the tested accuracy of the mean distance / PCA axis does not settle:
-                # 0 everywhere = the integer histograms are the reference's by construction for this call
-                gm, gf = (g.cpu().numpy() for g in guards[:2])
-                details["edge_guard"] = {"moving": {"ring": int(gm[0]), "sector": int(gm[1])}, "fixed": {"ring": int(gf[0]), "sector": int(gf[1])}}
+        if guards:
+            # neighbours (of this rank's rows) whose bin the tested accuracy of the mean distance / PCA axis does not settle:
+            # 0 everywhere = the integer histograms are the reference's by construction for this call
+            gm, gf = (g.cpu().numpy() for g in guards[:2])
+            guard = {"moving": {"ring": int(gm[0]), "sector": int(gm[1])}, "fixed": {"ring": int(gf[0]), "sector": int(gf[1])}}
+            if details is not None:
+                details["edge_guard"] = guard
+            if int(gm.sum()) + int(gf.sum()) > 0:
+                import warnings
+                warnings.warn("estimate_transform: %d neighbour relations of the moving cloud and %d of the fixed cloud lie on a bin "
+                              "boundary of the shape context (ring radius, sector plane, polar cone, or a duplicate of the queried "
+                              "nucleus) to within the rounding noise of the reference's own np.linalg.inv (shape_context.py:61-84): "
+                              "the reference bins them as its LAPACK build happens to round, so its histograms — and what follows "
+                              "from them — are not reproducible for this input (lattice / voxel coordinates, planar clouds, "
+                              "duplicates); details['edge_guard'] has the counts" % (int(gm.sum()), int(gf.sum())),
+                              EdgeGuardWarning, stacklevel=2)
     elif mode == 'supervised':
         if keypoints is None:
             raise ValueError("supervised mode needs keypoints=(moving_keypoints, fixed_keypoints)")

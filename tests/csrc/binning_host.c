@@ -42,7 +42,7 @@ int pmt_bin_fast32(const double *v, int n, const double *fr, double md, int32_t 
     const float k64 = ok ? (float)k64d : 0.0f;
     for (int i = 0; i < n; ++i) {
         const double v0 = v[3 * i], v1 = v[3 * i + 1], v2 = v[3 * i + 2];
-        out[i] = ok ? pm_bin_fast32((float)v0, (float)v1, (float)v2, fr32, k64) : -1;
+        out[i] = ok ? pm_bin_fast32((float)v0, (float)v1, (float)v2, fr32, k64, 0.0f) : -1;
         if (proj) {
             proj[3 * i] = (fr[0] * v0 + fr[1] * v1) + fr[2] * v2;
             proj[3 * i + 1] = (fr[3] * v0 + fr[4] * v1) + fr[5] * v2;

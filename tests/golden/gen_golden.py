@@ -88,7 +88,7 @@ def counts_from_sc(sc):
     return counts, totals
 
 
-def run_pipeline(ref, moving, fixed, ransac_trials, ransac_error, icp_iters, u_row_step, tag):
+def run_pipeline(ref, moving, fixed, ransac_trials, ransac_error, icp_iters, u_row_step, tag, seed=0):
     sc_mod, ft, at, icp_mod, utils = ref
     from scipy.optimize import linear_sum_assignment
     from sklearn.decomposition import PCA
@@ -140,14 +140,14 @@ def run_pipeline(ref, moving, fixed, ransac_trials, ransac_error, icp_iters, u_r
     out["lsa_cols"] = np.stack([c for _, c in lsa]).astype(np.int32)
 
     t0 = time.time()
-    np.random.seed(0)
+    np.random.seed(seed)
     A_r, inl = [], []
     for r, c in lsa:
         A, k = sc_mod.do_ransac(moving[:, r], fixed[:, c], min_samples=4, trials=ransac_trials,
                                 error=ransac_error, transform="Affine")
         A_r.append(np.asarray(A, dtype=np.float64))
         inl.append(k)
-    out["ransac_seed"] = np.int64(0)
+    out["ransac_seed"] = np.int64(seed)
     out["ransac_trials"] = np.int64(ransac_trials)
     out["ransac_error"] = np.float64(ransac_error)
     out["ransac_A"] = np.stack(A_r)

@@ -37,18 +37,13 @@ def d(x):
     return nat.to_dev(np.ascontiguousarray(x, dtype=np.float64), dev=dev)
 
 
-from soak_cases import make_case as _make_case  # noqa: E402
+from soak_cases import make_case as _make_case, make_case_lopsided  # noqa: E402
 
 
 def make_case(seed):
-    mv, fx, lattice, transform, rs = _make_case(seed, max_points)
     if os.environ.get("PM_SOAK_LOPSIDED") == "1":        # one cloud cut down to 4..12 points: N >> M and N << M
-        k = 4 + seed % 9
-        if seed % 2:
-            fx = np.ascontiguousarray(fx[:, :k])
-        else:
-            mv = np.ascontiguousarray(mv[:, :k])
-    return mv, fx, lattice, transform, rs
+        return make_case_lopsided(seed, max_points)
+    return _make_case(seed, max_points)
 
 
 def relerr(a, b):

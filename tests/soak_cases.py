@@ -27,6 +27,23 @@ def make_case(seed, max_points=500):
             "Similar" if seed % 3 == 2 else "Affine", int(rng.integers(0, 2 ** 31)))
 
 
+def make_case_lopsided(seed, max_points=600):
+    """make_case with one cloud cut down to 4..12 points (N >> M and N << M): the family of profiles/r03_soak_parity_lopsided.txt."""
+    mv, fx, lattice, transform, rs = make_case(seed, max_points)
+    k = 4 + seed % 9
+    if seed % 2:
+        fx = np.ascontiguousarray(fx[:, :k])
+    else:
+        mv = np.ascontiguousarray(mv[:, :k])
+    return mv, fx, lattice, transform, rs
+
+
+# the lopsided lattice seeds on which the HIP path and the oracle disagreed in round 3 (all with a non-zero edge guard), and
+# controls of the same family on which they agreed: tests/golden/gen_lopsided.py asks the unmodified reference for its verdict
+LOPSIDED_DIFFERING = (30114, 30244, 30744, 30889, 31644, 31734, 32014, 32184)
+LOPSIDED_CONTROLS = (30004, 30009, 30019, 30034, 30049, 30064, 30079, 30094)
+
+
 def make_case_b(seed, max_points=400):
     """A second family, the awkward corners -> dict(mv, fx, kind, kwargs for estimate_transform):
     0 integer voxel coordinates; 1 the same cloud twice (permuted: zero-cost matches, exact ties); 2 tiny clouds (4..12 points);

@@ -126,3 +126,42 @@ def test_concurrent_callers_are_serialised_and_ordinary_kernels_overlap(g):
     for key, (A, res, nn, s) in results.items():
         assert s == 0, key
         assert np.array_equal(A, quiet[0]) and np.array_equal(res, quiet[1]) and np.array_equal(nn, quiet[2]), key
+
+
+def test_the_library_refuses_a_second_persistent_grid_on_the_same_device(g):
+    """include/platymatch_hip.h: at most one pm_icp_one_launch in flight per device — enforced by the library itself (round 4),
+    not only by the mirror's lock: while one call's work is still running, a second call (another stream, the C ABI directly)
+    returns PM_ERR_UNSUPPORTED and enqueues nothing; once the first has drained the same call is accepted and gives pm_icp's bits."""
+    t, nat = g.t, g.nat
+    lib = nat.load()
+    n = 40000
+    mv, fx, start = bench.synth(n, seed=2)
+    fix = nat.to_dev(fx, dev=g.dev)
+    iters = 400
+
+    def args(w, stream):
+        ws = nat.workspace(lib.pm_icp_workspace(n, n), g.dev)
+        A = t.empty(16, dtype=t.float64, device=g.dev)
+        res = t.empty(iters, dtype=t.float64, device=g.dev)
+        return (nat.ptr(w), n, nat.ptr(fix), n, iters, nat.ptr(A), nat.ptr(res), None, None, nat.ptr(ws), ws.numel(), stream.cuda_stream), (A, res, ws)
+
+    s1, s2 = t.cuda.Stream(device=g.dev), t.cuda.Stream(device=g.dev)
+    t.cuda.synchronize()
+    w1, w2 = nat.to_dev(start, dev=g.dev), nat.to_dev(start, dev=g.dev)
+    a1, keep1 = args(w1, s1)
+    a2, keep2 = args(w2, s2)
+    t.cuda.synchronize()
+    rc1 = lib.pm_icp_one_launch(*a1)           # ~400 iterations: several milliseconds of device time
+    rc2 = lib.pm_icp_one_launch(*a2)           # asked while the first is in flight
+    assert rc1 == 0
+    assert rc2 == -4, rc2                      # PM_ERR_UNSUPPORTED
+    s1.synchronize()
+    t.cuda.synchronize()
+    rc3 = lib.pm_icp_one_launch(*a2)           # the flag came back with the first call's completion
+    assert rc3 == 0
+    s2.synchronize()
+    assert np.array_equal(keep1[0].cpu().numpy(), keep2[0].cpu().numpy()) and np.array_equal(keep1[1].cpu().numpy(), keep2[1].cpu().numpy())
+    w3 = nat.to_dev(start, dev=g.dev)
+    A3, res3, _ = g.K.icp(w3, fix, iters)
+    t.cuda.synchronize()
+    assert np.array_equal(A3.cpu().numpy().reshape(16), keep1[0].cpu().numpy()) and np.array_equal(res3.cpu().numpy(), keep1[1].cpu().numpy())

@@ -133,6 +133,22 @@ def test_eight_assignments_of_a_3000_point_pair_equal_scipy(dev):
     print({k: info["details"][0].get(k) for k in ("rounds", "edges", "steps", "violated_per_round", "max_matched_slack", "tight")})
 
 
+def test_config2_all_eight_assignments_of_a_5000_point_pair_equal_scipy(dev):
+    """BASELINE config 2 literally ("5k-nucleus pair: shape-context + chi-square cost + Hungarian on 1 MI355X"): all eight
+    assignments of a 5 000 x 5 000 synthetic pair by the device-resident route == scipy.optimize.linear_sum_assignment on the
+    same device-built matrices copied to the host (_dock_widget.py:604-611) — the dense solve the certificate stands in for."""
+    from platymatch_amd import lsap as L, pipeline as P
+    mv, fx, _ = synth_pair(5000, 42)
+    be = P.GpuBackend()
+    U, _ = P.build_costs(be, be.cloud(mv), be.cloud(fx))
+    info = {}
+    got = L.solve_eight_on_device(U, info=info)
+    assert all(r.startswith("device") for r in info["routes"]), info["routes"]
+    for h in range(8):
+        rs, cs = scipy_lsa(U[h].cpu().numpy())
+        assert np.array_equal(got[h][0], rs) and np.array_equal(got[h][1], cs), h
+
+
 def test_eight_assignments_with_more_moving_than_fixed_points(dev):
     """N > M: the solver works on the transposed matrices (rows = the short side, as SciPy does); answers in U's own indexing."""
     from platymatch_amd import lsap as L, pipeline as P

@@ -199,3 +199,55 @@ def test_product_end_to_end_on_the_references_24_random_small_pairs(ready):
             guarded_equal += same
     assert checked >= 12, (checked, guarded, guarded_equal)
     print("pairs with a zero edge guard (all equal to the reference): %d; guarded: %d, of which equal all the same: %d" % (checked, guarded, guarded_equal))
+
+
+def test_lopsided_lattice_pairs_against_the_references_own_verdict(ready, oracle):
+    """tests/golden/lopsided.npz: the unmodified reference on the eight lopsided lattice pairs on which the HIP path and the oracle
+    disagreed in round 3's soak (profiles/r03_soak_parity_lopsided.txt) and on eight controls of the same family.  Statements:
+      1. a call whose edge guard is zero returns the reference's assignments, inlier counts, A_sc and ICP correspondences;
+      2. every pair on which the HIP path differs from the reference announces it: edge guard > 0 AND an EdgeGuardWarning;
+      3. wherever the CPU oracle reproduces the reference end to end, so does the HIP path (it is never the odd one out);
+      4. who agrees with whom on the rest is recorded (printed): on those the reference's own histograms hang on the rounding of
+         its np.linalg.inv (every neighbour of a lattice cloud sits on a bin boundary), so there is no side to take."""
+    import os
+    import warnings
+    import platymatch_amd
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    from platymatch_amd.pipeline import EdgeGuardWarning
+    pi.VERBOSE = False
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lopsided.npz"))
+    table = []
+    for seed in d["seeds"]:
+        p = "s%d_" % seed
+        mv, fx = d[p + "moving"], d[p + "fixed"]
+        kw = dict(transform="Affine", ransac_trials=80, ransac_error=float(d[p + "ransac_error"][0]), icp_iterations=4,
+                  seed=int(d[p + "ransac_seed"][0]))
+        det, odet = {}, {}
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            got = platymatch_amd.register(mv, fx, details=det, **kw)
+        warned = any(issubclass(w.category, EdgeGuardWarning) for w in caught)
+        ref_o = oracle.estimate_transform(mv, fx, details=odet, **kw)
+
+        def same_as_reference(lsa, inl):
+            return (all(np.array_equal(lsa[h][0], d[p + "lsa_rows"][h]) and np.array_equal(lsa[h][1], d[p + "lsa_cols"][h]) for h in range(8))
+                    and np.array_equal(inl, d[p + "ransac_inliers"]))
+        g = det["edge_guard"]
+        guard = sum(v for side in g.values() for v in side.values())
+        prod_ref = same_as_reference(det["lsa"], got[2])
+        orac_ref = same_as_reference(odet["lsa"], ref_o[2])
+        prod_orac = (all(np.array_equal(det["lsa"][h][1], odet["lsa"][h][1]) for h in range(8)) and np.array_equal(got[2], ref_o[2]))
+        table.append((int(seed), mv.shape[1], fx.shape[1], guard, prod_ref, orac_ref, prod_orac))
+        assert warned == (guard > 0), seed                               # the warning is the guard, said aloud
+        if guard == 0:
+            assert prod_ref, seed                                        # 1.
+        if not prod_ref:
+            assert guard > 0 and warned, seed                            # 2.
+        if orac_ref:
+            assert prod_ref, seed                                        # 3.
+            if np.isfinite(d[p + "A_sc"]).all() and np.linalg.cond(d[p + "A_sc"]) < 1e8:
+                assert np.array_equal(np.asarray(got[0]), d[p + "A_sc"]) and np.array_equal(np.asarray(det["nn"]), d[p + "icp_nn"]), seed
+    print("seed, N, M, edge guard, product == reference, oracle == reference, product == oracle")
+    for row in table:
+        print("  %d  %4d %4d  %7d  %5s %5s %5s" % row)
+    assert sum(r[5] for r in table) == 3                                 # (the oracle's score, as in tests/test_oracle_golden.py)

@@ -211,3 +211,33 @@ def test_oracle_end_to_end_on_24_random_small_pairs(oracle):
             assert same, k
     assert agree[0] == [6, 6]
     print("pairs equal to the reference end to end / pairs: generic %s, voxel %s, lattice %s, asset-like %s" % tuple(agree[k] for k in range(4)))
+
+
+# ------------------------------------------------------------------------------------------------ lopsided lattice pairs (round 4)
+LOPSIDED_ORACLE_EQUALS_REFERENCE = (30009, 30019, 30034)       # end to end; the other thirteen differ in a histogram that matters
+
+
+def test_oracle_against_the_reference_on_the_lopsided_lattice_pairs(oracle):
+    """tests/golden/lopsided.npz (gen_lopsided.py): the unmodified reference on sixteen pairs of one tiny (4-12 points) and one
+    larger cloud, both on a half-integer lattice with duplicates — the family on which the HIP path and this oracle disagreed eight
+    times in round 3's soak.  What holds on all sixteen: centroid-independent statistics (mean distances) bit for bit.  What the
+    reference's verdict is: on every pair at least one histogram differs from the oracle's — every neighbour of such a cloud sits
+    ON a ring radius / sector plane, where the reference bins by the rounding noise of its np.linalg.inv — and
+    only three pairs come out equal end to end.  Neither the oracle nor the HIP path is "right" on the others: the reference's
+    own result there is a property of its LAPACK build (the GPU test asserts that the edge guard says so for every such pair)."""
+    d = load_golden("lopsided")
+    equal = []
+    for seed in d["seeds"]:
+        p = "s%d_" % seed
+        mv, fx = d[p + "moving"], d[p + "fixed"]
+        assert oracle.get_mean_distance(mv, False) == d[p + "mean_dist_m"] and oracle.get_mean_distance(fx, False) == d[p + "mean_dist_f"]
+        det = {}
+        got = oracle.estimate_transform(mv, fx, transform="Affine", ransac_trials=80, ransac_error=float(d[p + "ransac_error"][0]),
+                                        icp_iterations=4, seed=int(d[p + "ransac_seed"][0]), details=det)
+        same = (all(np.array_equal(det["lsa"][h][0], d[p + "lsa_rows"][h]) and np.array_equal(det["lsa"][h][1], d[p + "lsa_cols"][h]) for h in range(8))
+                and np.array_equal(got[2], d[p + "ransac_inliers"]))
+        if same:
+            equal.append(int(seed))
+            if np.isfinite(d[p + "A_sc"]).all() and np.linalg.cond(d[p + "A_sc"]) < 1e8:
+                assert np.array_equal(got[0], d[p + "A_sc"]) and np.array_equal(np.asarray(det["nn"]), d[p + "icp_nn"]), seed
+    assert tuple(equal) == LOPSIDED_ORACLE_EQUALS_REFERENCE, equal
