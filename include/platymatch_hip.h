@@ -276,6 +276,13 @@ int pm_lsap_core_add(void *core, int k, const int32_t *cols, const double *costs
  * would any other feasible start.  May be called repeatedly (e.g. after pm_lsap_core_reprice added edges) as long as
  * pm_lsap_core_solve has not run.  max_bids > 0 bounds the work of this call; bids (may be NULL): bids placed so far. */
 int pm_lsap_core_auction(void *core, double eps0, double eps_min, double factor, long max_bids, long *bids);
+/* The same auction continued from a state produced elsewhere (round 4: the device's Jacobi rounds over the same core,
+ * pm_lsap_auction_dev below): price[nc] (= -v) and assigned[nr] (-1 = unassigned; otherwise a column of that row's core edges,
+ * no column twice — PM_ERR_INVALID_ARG if not).  The first phase (eps0) does not reset the assignment: only the unassigned rows
+ * bid — the narrow, sequential tail of the device's last phase; further phases down to eps_min (if eps0 > eps_min) run as in
+ * pm_lsap_core_auction.  Ends with the same tightening; pm_lsap_core_solve completes the rest. */
+int pm_lsap_core_auction_resume(void *core, const double *price, const int32_t *assigned, double eps0, double eps_min,
+                                double factor, long max_bids, long *bids);
 int pm_lsap_core_solve(void *core);
 int pm_lsap_core_reprice(void *core, int k, const int32_t *cand_col, const double *cand_cost, double delta, int *n_violated);
 int pm_lsap_core_get(void *core, double *u, double *v, int32_t *col4row, long *stats4);

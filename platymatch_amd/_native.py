@@ -51,6 +51,7 @@ SIGNATURES = {
     "pm_lsap_core_solve": (_c_int, [_c_void_p]),
     "pm_transpose_f64": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_size_t, _c_void_p]),
     "pm_lsap_core_auction": (_c_int, [_c_void_p, _c_double, _c_double, _c_double, ctypes.c_long, _c_void_p]),
+    "pm_lsap_core_auction_resume": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_double, _c_double, _c_double, ctypes.c_long, _c_void_p]),
     "pm_lsap_core_reprice": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_double, _c_void_p]),
     "pm_lsap_core_get": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "pm_lsap_unique": (_c_int, [_c_int, _c_int, _c_void_p, _c_void_p, _c_double, _c_double, _c_void_p, _c_int]),

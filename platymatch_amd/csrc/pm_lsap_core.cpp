@@ -324,17 +324,40 @@ struct Core {
     // it without a search (solve()); rows that then prefer it are freed and find it in one step.
     // max_bids (> 0) bounds the work: rows contesting near-equal columns raise prices by eps per bid (a "price war");
     // stopping early is harmless, the rows still unassigned simply stay free.  bids = work done.
+    // RESUME (round 4; price_in / assigned_in not null): the auction continues from prices and a partial assignment produced
+    // elsewhere — the device's Jacobi rounds over the same core (pm_lsap_auction_dev.hip), which do the wide part of every
+    // eps phase (thousands of rows bidding at once) and leave the narrow, inherently sequential tails (eviction chains, price
+    // wars of a handful of rows) to this loop: the first phase here does NOT reset the assignment, only the rows still
+    // unassigned bid.  assigned_in[i] must be -1 or a column of row i's core edges, no column held twice (else INVALID_ARG).
     long bids = 0;
-    int auction(double eps0, double eps_min, double factor, long max_bids) {
+    int auction(double eps0, double eps_min, double factor, long max_bids, const double *price_in = nullptr,
+                const int32_t *assigned_in = nullptr) {
         if (!cold || !(eps0 > 0.0) || !(eps_min > 0.0) || !(factor > 1.0)) return PM_ERR_INVALID_ARG;
+        if ((price_in == nullptr) != (assigned_in == nullptr)) return PM_ERR_INVALID_ARG;
         const long stop_at = max_bids > 0 ? bids + max_bids : std::numeric_limits<long>::max();
         const int n = nr;
         for (int i = 0; i < n; ++i)
             if (adj[i].empty()) return PM_ERR_UNSUPPORTED;
         std::vector<double> price(nc);
-        for (int j = 0; j < nc; ++j) price[j] = -col[j].v;
+        for (int j = 0; j < nc; ++j) price[j] = price_in ? price_in[j] : -col[j].v;
         std::vector<int32_t> owner(nc), assigned(n), queue(n);
         std::vector<double> held_cost(n, 0.0);            // cost of the edge a row holds
+        bool resume = price_in != nullptr;
+        if (resume) {
+            std::fill(owner.begin(), owner.end(), -1);
+            for (int i = 0; i < n; ++i) {
+                const int a = assigned_in[i];
+                assigned[i] = -1;
+                if (a < 0) continue;
+                if (a >= nc || owner[a] >= 0) return PM_ERR_INVALID_ARG;
+                bool found = false;
+                for (const Edge &e : adj[i])
+                    if (e.col == a) { held_cost[i] = e.cost; found = true; break; }
+                if (!found) return PM_ERR_INVALID_ARG;
+                owner[a] = i;
+                assigned[i] = a;
+            }
+        }
         const double lone = eps0 * 1e6;                    // a row with a single edge outbids everyone for it
         // the core by columns (for the reverse steps below and the final tightening)
         std::vector<int32_t> cstart(nc + 1, 0);
@@ -350,10 +373,17 @@ struct Core {
         }
         std::vector<int32_t> stack;
         for (double eps = eps0;; eps = std::max(eps / factor, eps_min)) {
-            std::fill(owner.begin(), owner.end(), -1);
-            std::fill(assigned.begin(), assigned.end(), -1);
-            for (int i = 0; i < n; ++i) queue[i] = i;
-            size_t head = 0, count = (size_t)n;            // ring buffer of the unassigned rows (first in, first out)
+            size_t head = 0, count = 0;                    // ring buffer of the unassigned rows (first in, first out)
+            if (resume) {                                  // the imported state: only the rows it left unassigned bid
+                for (int i = 0; i < n; ++i)
+                    if (assigned[i] < 0) queue[count++] = i;
+                resume = false;
+            } else {
+                std::fill(owner.begin(), owner.end(), -1);
+                std::fill(assigned.begin(), assigned.end(), -1);
+                for (int i = 0; i < n; ++i) queue[i] = i;
+                count = (size_t)n;
+            }
             // A PRICE WAR — a handful of rows contesting near-equal columns, each bid worth eps — shows as a round whose tail, with
             // hardly any row still unassigned (<= 0.5 %), goes on for many bids per row of the problem (16 x n; PM_LSAP_WAR_TAIL
             // overrides, for experiments): the search settles those few rows in a fraction of the bids.  Measured, eight
@@ -715,6 +745,19 @@ int pm_lsap_core_auction(void *h, double eps0, double eps_min, double factor, lo
     if (!c) return PM_ERR_INVALID_ARG;
     try {
         const int rc = c->auction(eps0, eps_min, factor, max_bids);
+        if (bids) *bids = c->bids;
+        return rc;
+    } catch (...) {
+        return PM_ERR_WORKSPACE;
+    }
+}
+
+int pm_lsap_core_auction_resume(void *h, const double *price, const int32_t *assigned, double eps0, double eps_min, double factor,
+                                long max_bids, long *bids) {
+    Core *c = static_cast<Core *>(h);
+    if (!c || !price || !assigned) return PM_ERR_INVALID_ARG;
+    try {
+        const int rc = c->auction(eps0, eps_min, factor, max_bids, price, assigned);
         if (bids) *bids = c->bids;
         return rc;
     } catch (...) {

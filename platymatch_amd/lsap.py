@@ -108,6 +108,17 @@ class _Core:
         nat.check(self.lib.pm_lsap_core_auction(self.h, float(eps0), float(eps_min), float(factor), int(max_bids), ctypes.byref(bids)))
         return bids.value
 
+    def auction_resume(self, price, assigned, eps0, eps_min, factor, max_bids=0):
+        import ctypes
+        price = np.ascontiguousarray(price, dtype=np.float64)
+        assigned = np.ascontiguousarray(assigned, dtype=np.int32)
+        if price.size != self.nc or assigned.size != self.nr:
+            raise ValueError("price [nc] and assigned [nr] expected")
+        bids = ctypes.c_long(0)
+        nat.check(self.lib.pm_lsap_core_auction_resume(self.h, price.ctypes.data, assigned.ctypes.data, float(eps0), float(eps_min),
+                                                       float(factor), int(max_bids), ctypes.byref(bids)))
+        return bids.value
+
     def solve(self):
         rc = self.lib.pm_lsap_core_solve(self.h)
         if rc == -4:
@@ -148,8 +159,9 @@ class DeviceMatrix:
         self.shape = tuple(U.shape)
         self.ld = U.stride(0) if U.shape[0] > 1 else U.shape[1]      # a one-row tensor's row stride is arbitrary
 
-    def row_select(self, v, k):
-        """-> (cols [nr, k] int32, costs [nr, k] float64, nonfinite flag): pm_lsap_row_select."""
+    def row_select_t(self, v, k):
+        """pm_lsap_row_select with everything left on the device -> (cols [nr, k] int32, costs [nr, k] float64, nonfinite flag [1]
+        int32) GPU tensors; v: None, a host array or a GPU tensor [nc]."""
         torch = nat.torch_mod()
         U = self.U
         nr, nc = U.shape
@@ -157,8 +169,15 @@ class DeviceMatrix:
         costs = torch.empty((nr, k), dtype=torch.float64, device=U.device)
         flag = torch.empty(1, dtype=torch.int32, device=U.device)
         v_dev = None if v is None else nat.to_dev(v, dev=U.device)
+        if v_dev is not None and v_dev.numel() != nc:
+            raise ValueError("v must hold one dual per column")
         nat.check(nat.load().pm_lsap_row_select(nat.ptr(U), nr, nc, self.ld, nat.ptr(v_dev), k, nat.ptr(cols), nat.ptr(costs),
                                                 nat.ptr(flag), nat.stream_ptr(U)))
+        return cols, costs, flag
+
+    def row_select(self, v, k):
+        """-> (cols [nr, k] int32, costs [nr, k] float64, nonfinite flag): pm_lsap_row_select."""
+        cols, costs, flag = self.row_select_t(v, k)
         return cols.cpu().numpy(), costs.cpu().numpy(), int(flag.item())
 
     def diagonal(self, n):

@@ -9,12 +9,26 @@ column duals (8 M bytes per pricing round), a few counters.  At 50 000 x 50 000 
 the 20 GB a gather of the matrix moves, and it is the only way to assign a matrix that does not fit one GPU (BASELINE
 config 4: 200 000 x 200 000 is 320 GB; a rank's block of one hypothesis is 40 GB).
 
-Protocol: the root broadcasts (operation, which matrix, arguments); every rank, the root included, runs it on its block;
-the answers are gathered on the root.  Workers loop in `serve` until the root says stop.  Rows must be the short side
-(N <= M): with N > M the solver works on the transpose, whose rows are this layout's columns."""
+Protocol (round 4: TENSOR collectives only — no pickled objects; every buffer has a shape all ranks can derive):
+  1. the root broadcasts a header, int64 [8] = (operation, which matrix, k or cap, listed rows, has v, 0, 0, 0);
+  2. the operation's arguments follow as fixed-shape broadcasts (float64 v [M]; int64 row / column lists; for the certificate
+     one float64 vector u | v | delta | eps and int32 col4row);
+  3. every rank, the root included, answers for its own block; the answers are gathered on the root (torch.distributed.gather
+     into ONE allocation, blocks padded to the largest): first a status record, int32 [2 + 64] = (failed, flag, message bytes),
+     then the operation's payload (candidates int32 / float64 [rows, k]; for the certificate four float64 counters, then —
+     the root having broadcast the largest list length — the near-tight entries).
+A rank whose share raises still takes part in every collective of the query (zeros as payload) and the root raises its message
+on all ranks afterwards.  Workers loop in `serve` until the root sends the stop header.  With the "nccl" backend (RCCL) the
+buffers live on the GPU and a rank's candidates go from the kernel's output straight into the gather (DeviceMatrix.row_select_t);
+with "gloo" they are host tensors.  Rows must be the short side (N <= M): with N > M the solver works on the transpose, whose
+rows are this layout's columns."""
 import numpy as np
 
 from . import lsap
+
+OP_STOP, OP_ROW_SELECT, OP_DIAGONAL, OP_COL_MIN, OP_BID, OP_ENTRIES, OP_CERTIFICATE = range(7)
+OP_NAMES = ("stop", "row_select", "diagonal", "col_min", "bid", "entries", "certificate")
+_MSG_WORDS = 64          # 256 bytes of error message per rank
 
 
 def _dist():
@@ -22,105 +36,9 @@ def _dist():
     return dist
 
 
-def _answer(local, row0, rows, op, args):
-    """One rank's share of a query on its block `local` (rows [row0, row0 + rows) of the matrix)."""
-    if op == "row_select":
-        v, k = args
-        return local.row_select(v, k)
-    if op == "diagonal":
-        # entry (i, i) of the global matrix for the block's rows
-        return local.block_diagonal(row0) if hasattr(local, "block_diagonal") else None
-    if op == "col_min":
-        return local.col_min()
-    if op == "bid":                                      # the listed matrix rows that live in this block
-        v, all_rows = args
-        sel = np.flatnonzero((all_rows >= row0) & (all_rows < row0 + rows))
-        j1, u1, u2 = local.bid(v, all_rows[sel] - row0)
-        return sel, j1, u1, u2
-    if op == "entries":
-        all_rows, all_cols = args
-        sel = np.flatnonzero((all_rows >= row0) & (all_rows < row0 + rows))
-        return sel, local.entries(all_rows[sel] - row0, all_cols[sel])
-    if op == "certificate":
-        u, v, c4r, delta, eps, cap = args
-        viol, loose, tight, red, bound = local.certificate(u[row0:row0 + rows], v, c4r[row0:row0 + rows], delta, eps, cap)
-        if tight is not None and len(tight):
-            tight = tight.copy()
-            tight[:, 0] += row0                           # block rows -> matrix rows
-        return viol, loose, tight, red, bound
-    raise ValueError("unknown operation %r" % (op,))
-
-
-class _Failed:
-    """What a rank gathers instead of an answer when its share of a query raised (e.g. out of device memory while allocating
-    the certificate's buffers): the two collectives of a query stay matched on every rank, and the root turns the message
-    into the error solve_pair_sharded raises on ALL ranks."""
-
-    def __init__(self, rank, exc):
-        self.message = "rank %d: %s: %s" % (rank, type(exc).__name__, exc)
-
-
-def _safe_answer(rank, local, row0, rows, op, args):
-    try:
-        return _answer(local, row0, rows, op, args)
-    except Exception as e:                               # never leave the query between its broadcast and its gather
-        return _Failed(rank, e)
-
-
-class ShardedMatrix:
-    """lsap.DeviceMatrix's interface over row blocks on several ranks — the object the ROOT hands to lsap.solve_core /
-    lsap.certify.  `locals_` are this rank's blocks of the matrices that may be queried (e.g. a hypothesis and its twin)."""
-
-    def __init__(self, locals_, which, bounds, group, root, n_cols):
-        self.locals, self.which, self.bounds, self.group, self.root = locals_, which, bounds, group, root
-        self.shape = (bounds[-1], n_cols)
-
-    def _ask(self, op, args):
-        dist = _dist()
-        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
-        dist.broadcast_object_list([(op, self.which, args)], src=_global(self.group, self.root), group=self.group)
-        mine = _safe_answer(rank, self.locals[self.which], self.bounds[rank], self.bounds[rank + 1] - self.bounds[rank], op, args)
-        parts = [None] * world
-        dist.gather_object(mine, parts, dst=_global(self.group, self.root), group=self.group)
-        failed = [p.message for p in parts if isinstance(p, _Failed)]
-        if failed:                                        # raised with both collectives of the query completed on every rank
-            raise RuntimeError("query %r failed on " % (op,) + "; ".join(failed))
-        return parts
-
-    def row_select(self, v, k):
-        parts = self._ask("row_select", (v, k))
-        return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), int(max(p[2] for p in parts)))
-
-    def diagonal(self, n):
-        return np.concatenate(self._ask("diagonal", None))[:n]
-
-    def col_min(self):
-        return np.minimum.reduce(self._ask("col_min", None))
-
-    def bid(self, v, rows):
-        rows = np.asarray(rows, dtype=np.int64)
-        j1, u1, u2 = np.full(rows.size, -1, np.int32), np.full(rows.size, np.inf), np.full(rows.size, np.inf)
-        for sel, a, b, c in self._ask("bid", (v, rows)):
-            j1[sel], u1[sel], u2[sel] = a, b, c
-        return j1, u1, u2
-
-    def entries(self, rows, cols):
-        rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
-        out = np.empty(rows.size)
-        for sel, vals in self._ask("entries", (rows, cols)):
-            out[sel] = vals
-        return out
-
-    def certificate(self, u, v, col4row, delta, eps, cap):
-        parts = self._ask("certificate", (u, v, col4row, delta, eps, cap))
-        viol, loose = sum(p[0] for p in parts), sum(p[1] for p in parts)
-        bound = float(sum(p[4] for p in parts))
-        if any(p[2] is None for p in parts) or sum(len(p[2]) for p in parts) > cap:
-            return viol, loose, None, None, bound
-        return viol, loose, np.concatenate([p[2] for p in parts]), np.concatenate([p[3] for p in parts]), bound
-
-    def stop(self):
-        _dist().broadcast_object_list([("stop", 0, None)], src=_global(self.group, self.root), group=self.group)
+def _torch():
+    import torch
+    return torch
 
 
 def _global(group, group_rank):
@@ -130,18 +48,256 @@ def _global(group, group_rank):
     return dist.get_global_rank(group, group_rank)
 
 
-def serve(locals_, bounds, group, root):
-    """A worker's side: answer the root's queries about this rank's blocks until it says stop."""
-    dist = _dist()
-    rank = dist.get_rank(group)
-    row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
-    while True:
-        box = [None]
-        dist.broadcast_object_list(box, src=_global(group, root), group=group)
-        op, which, args = box[0]
-        if op == "stop":
-            return
-        dist.gather_object(_safe_answer(rank, locals_[which], row0, rows, op, args), None, dst=_global(group, root), group=group)
+class _Wire:
+    """The collectives of one solve: where the buffers live (host for gloo, the current GPU for RCCL) and the three moves."""
+
+    def __init__(self, bounds, n_cols, group, root):
+        dist, torch = _dist(), _torch()
+        self.group, self.root = group, root
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.src = _global(group, root)
+        self.bounds, self.nc, self.nr = bounds, int(n_cols), int(bounds[-1])
+        self.row0, self.rows = bounds[self.rank], bounds[self.rank + 1] - bounds[self.rank]
+        self.biggest = max(bounds[g + 1] - bounds[g] for g in range(self.world))
+        self.on_host = dist.get_backend(group) == "gloo"
+        self.dev = torch.device("cpu") if self.on_host else torch.device("cuda", torch.cuda.current_device())
+        self.is_root = self.rank == root
+
+    def tensor(self, a, dtype):
+        torch = _torch()
+        if lsap.nat.is_torch(a):
+            return a.to(device=self.dev, dtype=dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device=self.dev, dtype=dtype)
+
+    def empty(self, shape, dtype):
+        return _torch().empty(shape, dtype=dtype, device=self.dev)
+
+    def zeros(self, shape, dtype):
+        return _torch().zeros(shape, dtype=dtype, device=self.dev)
+
+    def bcast(self, t):
+        _dist().broadcast(t, src=self.src, group=self.group)
+        return t
+
+    def gather(self, t):
+        """-> [world, *t.shape] on the root (one allocation), None elsewhere."""
+        whole = self.empty((self.world,) + tuple(t.shape), t.dtype) if self.is_root else None
+        _dist().gather(t.contiguous(), [whole[g] for g in range(self.world)] if self.is_root else None, dst=self.src, group=self.group)
+        return whole
+
+
+def _host(t):
+    return t.cpu().numpy()
+
+
+def _status(wire, failed, flag, message):
+    st = np.zeros(2 + _MSG_WORDS, dtype=np.int32)
+    st[0], st[1] = int(failed), int(flag)
+    if message:
+        raw = message.encode("utf-8", "replace")[:4 * _MSG_WORDS]
+        st[2:].view(np.uint8)[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+    return wire.tensor(st, _torch().int32)
+
+
+def _message(words):
+    raw = np.ascontiguousarray(words, dtype=np.int32).view(np.uint8).tobytes()
+    return raw.split(b"\0", 1)[0].decode("utf-8", "replace")
+
+
+def _query(wire, locals_, request=None):
+    """One query, executed by EVERY rank: the root passes request = (op, which, dict of arguments), the workers None.
+    -> ("stop", None) / (op, gathered answer on the root | None elsewhere).  All collectives of the query complete on every rank
+    before the root raises a rank's failure."""
+    torch = _torch()
+    i64, i32, f64 = torch.int64, torch.int32, torch.float64
+    args = {}
+    if wire.is_root:
+        op, which, args = request
+        h = np.zeros(8, dtype=np.int64)
+        h[:5] = (op, which, int(args.get("k", args.get("cap", 0))), int(len(args["rows"])) if "rows" in args else 0,
+                 1 if args.get("v") is not None else 0)
+        hdr = wire.tensor(h, i64)
+    else:
+        hdr = wire.empty(8, i64)
+    wire.bcast(hdr)
+    op, which, a, n_listed, has_v = (int(x) for x in _host(hdr)[:5])
+    if op == OP_STOP:
+        return "stop", None
+    nr, nc, rows, row0, big = wire.nr, wire.nc, wire.rows, wire.row0, wire.biggest
+    # ---- arguments
+    v_t = rows_t = cols_t = uv_t = c4r_t = None
+    if op in (OP_ROW_SELECT, OP_BID) and has_v:
+        v_t = wire.bcast(wire.tensor(args["v"], f64) if wire.is_root else wire.empty(nc, f64))
+    if op in (OP_BID, OP_ENTRIES):
+        rows_t = wire.bcast(wire.tensor(args["rows"], i64) if wire.is_root else wire.empty(n_listed, i64))
+    if op == OP_ENTRIES:
+        cols_t = wire.bcast(wire.tensor(args["cols"], i64) if wire.is_root else wire.empty(n_listed, i64))
+    if op == OP_CERTIFICATE:
+        if wire.is_root:
+            uv = np.concatenate([np.asarray(args["u"], dtype=np.float64), np.asarray(args["v"], dtype=np.float64),
+                                 [float(args["delta"]), float(args["eps"])]])
+        uv_t = wire.bcast(wire.tensor(uv, f64) if wire.is_root else wire.empty(nr + nc + 2, f64))
+        c4r_t = wire.bcast(wire.tensor(args["col4row"], i32) if wire.is_root else wire.empty(nr, i32))
+    # ---- this rank's share (never leaves the query between its broadcasts and its gathers)
+    local = locals_[which]
+    failed, flag, message, ans = 0, 0, "", None
+    try:
+        if op == OP_ROW_SELECT:
+            if hasattr(local, "row_select_t") and not wire.on_host:
+                ans = local.row_select_t(v_t, a)                                   # device tensors, straight into the gather
+                flag = int(ans[2].item())
+            else:
+                ans = local.row_select(None if v_t is None else _host(v_t), a)
+                flag = int(ans[2])
+        elif op == OP_DIAGONAL:
+            ans = local.block_diagonal(row0)
+        elif op == OP_COL_MIN:
+            ans = local.col_min()
+        elif op == OP_BID:
+            all_rows = _host(rows_t)
+            sel = np.flatnonzero((all_rows >= row0) & (all_rows < row0 + rows))
+            ans = (sel,) + tuple(local.bid(_host(v_t), all_rows[sel] - row0))
+        elif op == OP_ENTRIES:
+            all_rows, all_cols = _host(rows_t), _host(cols_t)
+            sel = np.flatnonzero((all_rows >= row0) & (all_rows < row0 + rows))
+            ans = (sel, local.entries(all_rows[sel] - row0, all_cols[sel]))
+        elif op == OP_CERTIFICATE:
+            uv = _host(uv_t)
+            c4r = _host(c4r_t)
+            ans = local.certificate(uv[row0:row0 + rows], uv[nr:nr + nc], c4r[row0:row0 + rows], float(uv[nr + nc]), float(uv[nr + nc + 1]), a)
+        else:
+            raise ValueError("unknown operation %d" % op)
+    except Exception as e:
+        failed, message, ans = 1, "rank %d: %s: %s" % (wire.rank, type(e).__name__, e), None
+    status = wire.gather(_status(wire, failed, flag, message))
+    # ---- answers (fixed shapes; a failed rank sends zeros)
+    out = None
+    if op == OP_ROW_SELECT:
+        c_t, x_t = wire.zeros((big, a), i32), wire.zeros((big, a), f64)
+        if ans is not None:
+            c_t[:rows] = wire.tensor(ans[0], i32)
+            x_t[:rows] = wire.tensor(ans[1], f64)
+        C, X = wire.gather(c_t), wire.gather(x_t)
+        if wire.is_root:
+            b = wire.bounds
+            out = (np.concatenate([_host(C[g, :b[g + 1] - b[g]]) for g in range(wire.world)]),
+                   np.concatenate([_host(X[g, :b[g + 1] - b[g]]) for g in range(wire.world)]),
+                   int(_host(status[:, 1]).max()))
+    elif op == OP_DIAGONAL:
+        d_t = wire.zeros(big, f64)
+        if ans is not None:
+            d_t[:len(ans)] = wire.tensor(ans, f64)
+        D = wire.gather(d_t)
+        if wire.is_root:
+            b = wire.bounds
+            out = np.concatenate([_host(D[g, :max(0, min(b[g + 1] - b[g], nc - b[g]))]) for g in range(wire.world)])
+    elif op == OP_COL_MIN:
+        V = wire.gather(wire.tensor(ans, f64) if ans is not None else wire.zeros(nc, f64))
+        if wire.is_root:
+            out = np.minimum.reduce(_host(V))
+    elif op == OP_BID:
+        j_t, u_t = wire.zeros(n_listed, i32), wire.zeros((2, n_listed), f64)
+        if ans is not None and len(ans[0]):
+            sel = wire.tensor(ans[0], i64)
+            j_t[sel] = wire.tensor(ans[1], i32)
+            u_t[0, sel], u_t[1, sel] = wire.tensor(ans[2], f64), wire.tensor(ans[3], f64)
+        J, Uu = wire.gather(j_t), wire.gather(u_t)
+        if wire.is_root:
+            owner = np.searchsorted(np.asarray(wire.bounds), _host(rows_t), side="right") - 1
+            pick = np.arange(n_listed)
+            out = (_host(J)[owner, pick], _host(Uu)[owner, 0, pick], _host(Uu)[owner, 1, pick])
+    elif op == OP_ENTRIES:
+        e_t = wire.zeros(n_listed, f64)
+        if ans is not None and len(ans[0]):
+            e_t[wire.tensor(ans[0], i64)] = wire.tensor(ans[1], f64)
+        E = wire.gather(e_t)
+        if wire.is_root:
+            owner = np.searchsorted(np.asarray(wire.bounds), _host(rows_t), side="right") - 1
+            out = _host(E)[owner, np.arange(n_listed)]
+    elif op == OP_CERTIFICATE:
+        cnt = np.zeros(4)
+        if ans is not None:
+            viol, loose, tight, red, bound = ans
+            cnt[:] = (viol, loose, -1.0 if tight is None else len(tight), bound)
+        CNT = wire.gather(wire.tensor(cnt, f64))
+        most = wire.zeros(1, i64)
+        if wire.is_root:
+            counts = _host(CNT)[:, 2]
+            overflow = bool((counts < 0).any()) or counts.sum() > a
+            most[0] = 0 if overflow else int(counts.max())
+        wire.bcast(most)
+        most = int(most.item())
+        T = R = None
+        if most > 0:
+            t_t, r_t = wire.zeros((most, 2), i32), wire.zeros(most, f64)
+            if ans is not None and ans[2] is not None and len(ans[2]):
+                tt = np.array(ans[2], dtype=np.int32, copy=True)
+                tt[:, 0] += row0                                                    # block rows -> matrix rows
+                t_t[:len(tt)] = wire.tensor(tt, i32)
+                r_t[:len(tt)] = wire.tensor(ans[3], f64)
+            T, R = wire.gather(t_t), wire.gather(r_t)
+        if wire.is_root:
+            c = _host(CNT)
+            viol, loose, bound = int(c[:, 0].sum()), int(c[:, 1].sum()), float(c[:, 3].sum())
+            if overflow:
+                out = (viol, loose, None, None, bound)
+            elif most == 0:
+                out = (viol, loose, np.zeros((0, 2), dtype=np.int32), np.zeros(0), bound)
+            else:
+                lens = c[:, 2].astype(np.int64)
+                out = (viol, loose, np.concatenate([_host(T[g, :lens[g]]) for g in range(wire.world)]),
+                       np.concatenate([_host(R[g, :lens[g]]) for g in range(wire.world)]), bound)
+    if wire.is_root:
+        st = _host(status)
+        bad = [_message(st[g, 2:]) for g in range(wire.world) if st[g, 0]]
+        if bad:                                           # raised with every collective of the query completed on every rank
+            raise RuntimeError("query %r failed on " % (OP_NAMES[op],) + "; ".join(bad))
+    return op, out
+
+
+class ShardedMatrix:
+    """lsap.DeviceMatrix's interface over row blocks on several ranks — the object the ROOT hands to lsap.solve_core /
+    lsap.certify.  `locals_` are this rank's blocks of the matrices that may be queried (e.g. a hypothesis and its twin)."""
+
+    def __init__(self, locals_, which, wire):
+        self.locals, self.which, self.wire = locals_, which, wire
+        self.shape = (wire.nr, wire.nc)
+
+    def _ask(self, op, **args):
+        return _query(self.wire, self.locals, (op, self.which, args))[1]
+
+    def row_select(self, v, k):
+        return self._ask(OP_ROW_SELECT, v=v, k=int(k))
+
+    def diagonal(self, n):
+        return self._ask(OP_DIAGONAL)[:n]
+
+    def col_min(self):
+        return self._ask(OP_COL_MIN)
+
+    def bid(self, v, rows):
+        rows = np.asarray(rows, dtype=np.int64)
+        if rows.size == 0:
+            return np.zeros(0, np.int32), np.zeros(0), np.zeros(0)
+        return self._ask(OP_BID, v=v, rows=rows)
+
+    def entries(self, rows, cols):
+        rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+        if rows.size == 0:
+            return np.zeros(0)
+        return self._ask(OP_ENTRIES, rows=rows, cols=cols)
+
+    def certificate(self, u, v, col4row, delta, eps, cap):
+        return self._ask(OP_CERTIFICATE, u=u, v=v, col4row=col4row, delta=delta, eps=eps, cap=int(cap))
+
+    def stop(self):
+        _query(self.wire, self.locals, (OP_STOP, 0, {}))
+
+
+def serve(locals_, wire):
+    """A worker's side: answer the root's queries about this rank's blocks until it sends the stop header."""
+    while _query(wire, locals_)[0] != "stop":
+        pass
 
 
 def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=None, accept_near_ties=False):
@@ -150,15 +306,15 @@ def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=No
     hypothesis or None, col4row of the twin or None) on EVERY rank; None = not certified (the caller takes another route
     for that matrix).  N <= M required.  accept_near_ties: an assignment certified optimal but not proven unique
     (lsap.certify: info["optimal"]) is returned instead of None; info["near_tie"] lists which (0 = hypothesis, 1 = twin)."""
-    dist = _dist()
-    rank = dist.get_rank(group)
+    torch = _torch()
+    wire = _Wire(bounds, n_cols, group, root)
     locals_ = [local_h] + ([local_twin] if local_twin is not None else [])
     out = [None, None, None]                              # col4row, twin's col4row, error message
-    if rank == root:
+    if wire.is_root:
         try:
             info = {} if info is None else info
             near = info["near_tie"] = []
-            M = ShardedMatrix(locals_, 0, bounds, group, root, n_cols)
+            M = ShardedMatrix(locals_, 0, wire)
             sol = lsap.solve_core(M, info)
             certified = sol is not None and lsap.certify(M, *sol, info=info)
             if certified:
@@ -167,7 +323,7 @@ def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=No
                 out[0] = sol[2]
                 near.append(0)
             if local_twin is not None:
-                Mt = ShardedMatrix(locals_, 1, bounds, group, root, n_cols)
+                Mt = ShardedMatrix(locals_, 1, wire)
                 tinfo = info["twin"] = {}
                 if certified and lsap.certify(Mt, *sol, info=tinfo):
                     out[1] = sol[2]
@@ -184,11 +340,24 @@ def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=No
         except Exception as e:                            # the workers are waiting for queries: release them, then raise everywhere
             out[2] = "%s: %s" % (type(e).__name__, e)
         finally:
-            ShardedMatrix(locals_, 0, bounds, group, root, n_cols).stop()
+            ShardedMatrix(locals_, 0, wire).stop()
     else:
-        serve(locals_, bounds, group, root)
-    box = [out]
-    dist.broadcast_object_list(box, src=_global(group, root), group=group)
-    if box[0][2] is not None:
-        raise RuntimeError("sharded assignment failed on rank %d: %s" % (root, box[0][2]))
-    return box[0][0], box[0][1]
+        serve(locals_, wire)
+    # the result, to every rank: int64 (has hypothesis, has twin, failed) | int32 [2, N] | the message if it failed
+    if wire.is_root:
+        res = wire.tensor(np.array([out[0] is not None, out[1] is not None, out[2] is not None], dtype=np.int64), torch.int64)
+        both = np.zeros((2, wire.nr), dtype=np.int32)
+        for k in range(2):
+            if out[k] is not None:
+                both[k] = np.asarray(out[k])
+        c4r = wire.tensor(both, torch.int32)
+    else:
+        res, c4r = wire.empty(3, torch.int64), wire.empty((2, wire.nr), torch.int32)
+    wire.bcast(res)
+    wire.bcast(c4r)
+    has_h, has_t, err = (int(x) for x in _host(res))
+    if err:
+        msg = wire.bcast(_status(wire, 1, 0, out[2] if wire.is_root else ""))
+        raise RuntimeError("sharded assignment failed on rank %d: %s" % (root, _message(_host(msg)[2:])))
+    got = _host(c4r)
+    return (got[0].copy() if has_h else None), (got[1].copy() if has_t else None)

@@ -258,21 +258,33 @@ def _global_rank(group, group_rank):
 
 
 def all_gather_rows(local, bounds, dim, group):
-    """All-gather blocks of unequal row counts along `dim` (padded to the largest block: RCCL's
-    all-gather wants equal contributions)."""
+    """All-gather blocks of unequal row counts along `dim` (0 or 1) -> the complete tensor on every rank.  One
+    all_gather_into_tensor per leading slice, each rank's block landing where it belongs in ONE output allocation: with equal
+    blocks (rows divisible by the ranks) that allocation IS the result — the 144 MB of frame-1 descriptors at 50k are written
+    once, by RCCL —; unequal blocks are padded to the largest and squeezed by one copy afterwards."""
     import torch
     dist = _dist()
     world = len(bounds) - 1
     if world == 1:
         return local
-    biggest = max(bounds[g + 1] - bounds[g] for g in range(world))
-    shape = list(local.shape)
-    shape[dim] = biggest
-    padded = torch.zeros(shape, dtype=local.dtype, device=local.device)
-    padded.narrow(dim, 0, local.shape[dim]).copy_(local)
-    gathered = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(gathered, padded.contiguous(), group=group)
-    return torch.cat([gathered[g].narrow(dim, 0, bounds[g + 1] - bounds[g]) for g in range(world)], dim=dim)
+    if dim not in (0, 1) or (dim == 1 and local.dim() < 2):
+        raise ValueError("all_gather_rows gathers along dimension 0 or 1")
+    sizes = [bounds[g + 1] - bounds[g] for g in range(world)]
+    biggest = max(sizes)
+    lead = local.shape[0] if dim == 1 else 1                  # leading slices gathered one by one (frames of a descriptor set)
+    tail = tuple(local.shape[dim + 1:])
+    src = local if dim == 1 else local.unsqueeze(0)           # [lead, rows_g, *tail]
+    if sizes[dist.get_rank(group)] != biggest:
+        padded = torch.zeros((lead, biggest) + tail, dtype=local.dtype, device=local.device)
+        padded[:, :src.shape[1]].copy_(src)
+        src = padded
+    src = src.contiguous()
+    out = torch.empty((lead, world * biggest) + tail, dtype=local.dtype, device=local.device)
+    for f in range(lead):
+        dist.all_gather_into_tensor(out[f], src[f], group=group)
+    if any(sz != biggest for sz in sizes):
+        out = torch.cat([out[:, g * biggest:g * biggest + sizes[g]] for g in range(world)], dim=1)
+    return out if dim == 1 else out[0]
 
 
 def cloud_statistics(be, xyz, group=None):
@@ -624,7 +636,7 @@ def icp_sharded(be, moved, fix, iters, group=None):
     # ranks hold bit-identical sums and solve the identical 4x4 — they stay in lockstep without a broadcast.
     mine = torch.zeros(26, dtype=torch.float64, device=moved.device)       # [0:24] moment sums, [24:26] residual parts
     sums_view, rp_view = mine[:24], mine[24:]
-    gathered = [torch.empty_like(mine) for _ in range(world)] if world > 1 else None
+    gathered = torch.empty(world * 26, dtype=torch.float64, device=moved.device) if world > 1 else None     # (rank-major concatenation)
     res_buf = torch.zeros((max(iters, 1), 2), dtype=torch.float64, device=moved.device)
     status = torch.zeros(1, dtype=torch.int32, device=moved.device) if moved.is_cuda else None
     for it in range(iters + (1 if world > 1 and iters else 0)):
@@ -633,8 +645,8 @@ def icp_sharded(be, moved, fix, iters, group=None):
             nn = be.icp_nn(loc, fix, grid) if grid is not None else be.icp_nn(loc, fix)
             be.icp_accumulate(loc, fix, nn, origin, out=sums_view)
         if world > 1:
-            dist.all_gather(gathered, mine, group=group)
-            total = torch.stack(gathered).sum(0)
+            dist.all_gather_into_tensor(gathered, mine, group=group)
+            total = gathered.view(world, 26).sum(0)
             if it > 0:
                 res_buf[it - 1].copy_(total[24:])
             sums = total[:24]

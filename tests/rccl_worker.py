@@ -6,12 +6,12 @@ Collectives of the product (platymatch_amd/pipeline.py, lsap_sharded.py, bench.p
   all_reduce SUM f64   cloud_statistics (mean-distance tile sums), estimate_transform_batch (result table)
   all_reduce MAX i32   gather_fixed_descriptors (symmetry flag), assign (status words)
   all_reduce MAX f64   bench.py (max-over-ranks step time)
-  all_gather f64 list  all_gather_rows (fixed descriptors), icp_sharded (26 doubles per iteration)
-  all_gather i32 list  cost_row_argmins
-  gather f64           assign (row blocks of an uncertified hypothesis to its owner)
-  broadcast i64        assign (index vectors from the owner)
-  broadcast/gather of Python objects   lsap_sharded query protocol
+  all_gather_into_tensor f64 / i32   all_gather_rows (fixed descriptors; cost_row_argmins), icp_sharded (26 doubles per iteration)
+  gather f64 / i32     assign (row blocks of an uncertified hypothesis to its owner); lsap_sharded (candidates, counters, status)
+  broadcast i64 / i32 / f64          assign (index vectors from the owner); lsap_sharded (header, duals, result)
   barrier              bench.py
+No Python object crosses the wire (round 4): the sharded assignment's query protocol is tensor collectives only, and runs here
+through RCCL with the real DeviceMatrix (solve_pair_sharded on a world of one).
 """
 import json
 import os
@@ -60,11 +60,12 @@ def main():
     keep = b.clone()
     dist.broadcast(b, src=0, group=g)
     out["broadcast_i64"] = bool(torch.equal(b, keep))
-    objs = [("row_select", {"k": 16})]
-    dist.broadcast_object_list(objs, src=0, group=g)
-    parts = [None]
-    dist.gather_object(("answer", np.arange(3)), parts, dst=0, group=g)
-    out["objects"] = objs[0][0] == "row_select" and parts[0][0] == "answer"
+    into = torch.empty((37, 360), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(into, blk[0], group=g)
+    out["all_gather_into_tensor_f64"] = bool(torch.equal(into, blk[0]))
+    into_i = torch.empty(11, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(into_i, idx[3], group=g)
+    out["all_gather_into_tensor_i32"] = bool(torch.equal(into_i, idx[3]))
     dist.barrier(group=g)
     torch.cuda.synchronize()
 
@@ -90,6 +91,21 @@ def main():
     dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=g)
     out["symmetry_flag_dtype"] = str(flag.dtype)
     out["symmetry_flag"] = int(flag.item())
+
+    # the sharded assignment's query protocol (tensor collectives only) through RCCL with the real kernels behind it: a hypothesis
+    # and its twin of a 1 400-point pair by solve_pair_sharded on this world of one == SciPy on the same matrices
+    from scipy.optimize import linear_sum_assignment as scipy_lsa
+    from platymatch_amd import lsap as L
+    from platymatch_amd.lsap_sharded import solve_pair_sharded
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import synth_pair
+    mv, fx2, _ = synth_pair(1400, 9)
+    U8, bn = P.build_costs(be, be.cloud(mv), be.cloud(fx2))
+    sinfo = {}
+    c_h, c_t = solve_pair_sharded(L.DeviceMatrix(U8[0]), L.DeviceMatrix(U8[5]), bn, U8.shape[2], g, 0, sinfo)
+    out["sharded_query_protocol"] = bool(c_h is not None and c_t is not None
+                                         and np.array_equal(c_h, scipy_lsa(U8[0].cpu().numpy())[1])
+                                         and np.array_equal(c_t, scipy_lsa(U8[5].cpu().numpy())[1]))
 
     # the headless driver with group=WORLD against the reference fixture (tests/golden/synth128.npz)
     fx = np.load(os.path.join(ROOT, "tests", "golden", "synth128.npz"))

@@ -30,6 +30,16 @@ def test_two_ranks_are_spawned_and_rendezvous_over_gloo():
     assert lines[0] == {"dry_run": True, "n_gpus": 2, "max_rank_plus_one": 2.0, "spawned": True, "local_rank": 0}
 
 
+def test_eight_ranks_are_spawned_and_rendezvous_over_gloo():
+    """The driver's scaling run at its widest (--gpus 8): eight children rendezvous (gloo, dry run, no GPU), rank 0 alone reports."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-run"], env=_clean_env(OMP_NUM_THREADS="1"), capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    assert lines[0] == {"dry_run": True, "n_gpus": 8, "max_rank_plus_one": 8.0, "spawned": True, "local_rank": 0}
+
+
 def test_launcher_does_not_import_torch():
     """The parent must stay clear of the GPU runtime: it may not even import torch."""
     code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '2', '--dry-run']\n"

@@ -38,7 +38,7 @@ def test_backend_is_rccl(report):
 
 
 @pytest.mark.parametrize("what", ["all_reduce_sum_f64", "all_reduce_max_i32", "all_reduce_max_f64", "all_gather_f64", "all_gather_i32",
-                                  "gather_f64", "broadcast_i64", "objects", "all_gather_rows", "sharded_mean_distance_bits"])
+                                  "gather_f64", "broadcast_i64", "all_gather_into_tensor_f64", "all_gather_into_tensor_i32", "sharded_query_protocol", "all_gather_rows", "sharded_mean_distance_bits"])
 def test_collective_of_the_sharded_pipeline_through_rccl(report, what):
     assert report[what] is True
 
