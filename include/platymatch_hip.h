@@ -181,6 +181,18 @@ int pm_chi2_cost8_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, 
 int pm_chi2_cost_pair_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out2, size_t ld,
                           size_t matrix_stride, void *stream);
 
+/* OPT-IN EXPERIMENT, never the default (round 4): the same eight matrices in RELAXED float64 arithmetic — no bit identity with
+ * the reference's scalar loop (shape_context.py:88-99), every entry within pm_chi2_relaxed_delta() (absolute) of it.
+ * U = 0.5 (sum a + sum b) - 2 sum_k a_k b_k / (a_k + b_k): four running sums per row instead of eight (the twins U11/U22,
+ * U12/U21, U13/U24, U14/U23 coincide once the order of summation is free and are written twice), v_rcp_f64 + one Newton step
+ * instead of a correctly rounded division.  An assignment read off these matrices is the exact matrices' only if its
+ * uniqueness margin exceeds 2 min(N, M) delta (the Python mirror: lsap.certify(min_eps=...)).  variant 0: every term computed;
+ * 1 / 2: sparsely filled shells from a 94 x 94 / 64 x 64 table of relaxed terms. */
+size_t pm_chi2_relaxed_workspace_bytes(int nM, int nF);
+double pm_chi2_relaxed_delta(void);
+int pm_chi2_cost8_relaxed(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
+                          size_t matrix_stride, void *ws, size_t ws_bytes, int variant, void *stream);
+
 /* The same two calls with a caller-provided workspace (pm_chi2_sym_workspace_bytes, 16-byte aligned device memory), which lets
  * the kernel take most terms of the sparsely filled inner shells from a table: a descriptor value is count / total
  * (get_shape_context's sc / sc.sum(), shape_context.py:40-43), so (a-b)^2/(a+b) is a function of two small integers.  The

@@ -297,6 +297,28 @@ def chi2_cost8_frame1(sc_m1, sc_f1, out=None, info=None):
     return out
 
 
+def chi2_cost8_relaxed(sc_m1, sc_f1, out=None, variant=1):
+    """OPT-IN EXPERIMENT (never the default): the eight matrices from the frame-1 descriptors in relaxed float64 arithmetic —
+    U = 0.5 (sum a + sum b) - 2 sum ab/(a+b), reciprocal with one Newton step, sums in any order, the twins identical
+    (pm_chi2_cost8_relaxed; csrc/pm_chi2.hip: RELAX).  Every entry is within chi2_relaxed_delta() of the exact value, NOT bit-
+    identical to it: an assignment taken from these matrices counts only with lsap.certify(min_eps = 2 min(N, M) delta).
+    variant 0: every shell computed; 1: sparsely filled shells from a 94 x 94 term table; 2: 64 x 64 table, three waves per SIMD."""
+    torch = _t()
+    a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
+    nM, nF = a.shape[0], b.shape[0]
+    out = _out8(out, nM, nF, a.device)
+    lib = nat.load()
+    ws = torch.empty(int(lib.pm_chi2_relaxed_workspace_bytes(nM, nF)), dtype=torch.uint8, device=a.device)
+    check(lib.pm_chi2_cost8_relaxed(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(), int(variant),
+                                    nat.stream_ptr()))
+    return out
+
+
+def chi2_relaxed_delta():
+    """Absolute per-entry error bound of chi2_cost8_relaxed against the exact cost (csrc/pm_chi2.hip: PM_CHI2_RELAX_DELTA)."""
+    return float(nat.load().pm_chi2_relaxed_delta())
+
+
 def _sym_workspace(lib, nM, nF, device):
     """Device scratch of the half-cost kernel's term table (the integer counts behind the descriptor values; include/platymatch_hip.h)."""
     return _t().empty(int(lib.pm_chi2_sym_workspace_bytes(nM, nF)), dtype=_t().uint8, device=device)

@@ -177,14 +177,33 @@ struct SymMeta {
     int maxc[2][CH_NSHELL];            // largest count per (r, theta) shell, saturated at 255
 };
 
-template <int SY_RI, int MINW, int TSEL = -1, int TL = 0>   // rows per wave; min waves per SIMD for the register allocator; pairing; table size
+// RELAX (round 4, opt-in, never the default): the same eight matrices WITHOUT the bit-identity contract — an experiment on what
+// the exact formulation costs.  (a-b)^2/(a+b) = (a+b) - 4ab/(a+b), so
+//     U = 0.5 sum_k (a_k - b_k)^2/(a_k + b_k) = 0.5 (sum a + sum b) - 2 sum_k a_k b_k / (a_k + b_k)
+// and with the order of summation free the natural- and rolled-order twins coincide: FOUR running sums per row instead of
+// eight, each term an add, a multiply, v_rcp_f64 + ONE Newton step (relative error 2^-48.8, no residual correction) and one
+// fused multiply-add into the sum: 6 instructions / 9 issue slots per term against 12 / 15.  Row sums (sum a, sum b) come from
+// a small pre-kernel (relaxed_rowsum_kernel).  Per-entry error against the exact value: <= PM_CHI2_RELAX_DELTA (absolute; the
+// terms' 2e-15 relative, the 360 additions' roundings and the row sums'), which the caller's uniqueness certificate has to
+// cover (lsap.certify(min_eps=...)).
+#define PM_CHI2_RELAX_DELTA 2e-13
+
+__device__ __forceinline__ double relaxed_recip(double s) {
+    double r = __builtin_amdgcn_rcp(s);
+    const double e = __builtin_fma(-s, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+template <int SY_RI, int MINW, int TSEL = -1, int TL = 0, bool RELAX = false>   // rows per wave; min waves per SIMD for the register allocator; pairing; table size; relaxed arithmetic
 __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double *__restrict__ scA, int nA,
                                                                  const double *__restrict__ scB, int nB,
                                                                  double *__restrict__ out, size_t ld, size_t mstride,
                                                                  int nTi, unsigned int nblocks,
                                                                  const unsigned char *__restrict__ cntA = nullptr,
                                                                  const unsigned char *__restrict__ cntB = nullptr,
-                                                                 const SymMeta *__restrict__ meta = nullptr) {
+                                                                 const SymMeta *__restrict__ meta = nullptr,
+                                                                 const double *__restrict__ sumA = nullptr,
+                                                                 const double *__restrict__ sumB = nullptr) {
     constexpr int SY_TI = 4 * SY_RI;      // rows per tile
     __shared__ __attribute__((aligned(16))) double A_s[SY_TI][CH_K];
     __shared__ __attribute__((aligned(16))) double B_s[CH_TJ][CH_BPITCH];
@@ -200,11 +219,12 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     constexpr int NH = (TSEL < 0) ? 8 : 2;
-    double acc[SY_RI][NH];
+    constexpr int NACC = RELAX ? NH / 2 : NH;      // relaxed: one sum per pairing (the twins coincide)
+    double acc[SY_RI][NACC];
 #pragma unroll
     for (int r = 0; r < SY_RI; ++r)
 #pragma unroll
-        for (int h = 0; h < NH; ++h) acc[r][h] = 0.0;
+        for (int h = 0; h < NACC; ++h) acc[r][h] = 0.0;
 
     unsigned int tabmask = 0;             // shells served from the table (uniform)
     if constexpr (TL > 0) {
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
                 const int ca = e / TL, cb = e - ca * TL;
                 const double a = (double)ca / totA, b = cb ? (double)cb / totB : CH_TINY;
                 const double df = a - b;
-                tab[e] = div_pos(df * df, a + b);
+                tab[e] = RELAX ? (a * b) * relaxed_recip(a + b) : div_pos(df * df, a + b);
             }
             __syncthreads();
         }
@@ -297,13 +317,20 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
                     __builtin_amdgcn_sched_barrier(0);
                     const int r = i / NT, t = (TSEL < 0) ? i % NT : TSEL;
                     const int hn = (TSEL < 0) ? t : 0, hr = (TSEL >= 0) ? 1 : (t == 0) ? 5 : (t == 1) ? 4 : (t == 2) ? 7 : 6;
-                    double sn = acc[r][hn], sr = acc[r][hr];
+                    if constexpr (RELAX) {
+                        double sn = acc[r][hn];
 #pragma unroll
-                    for (int p = 0; p < CH_K; ++p) sn = sn + Tc[p];
+                        for (int p = 0; p < CH_K; ++p) sn = sn + Tc[p];
+                        acc[r][hn] = sn;
+                    } else {
+                        double sn = acc[r][hn], sr = acc[r][hr];
 #pragma unroll
-                    for (int p = 0; p < CH_K; ++p) sr = sr + Tc[(p + 6) % 12];
-                    acc[r][hn] = sn;
-                    acc[r][hr] = sr;
+                        for (int p = 0; p < CH_K; ++p) sn = sn + Tc[p];
+#pragma unroll
+                        for (int p = 0; p < CH_K; ++p) sr = sr + Tc[(p + 6) % 12];
+                        acc[r][hn] = sn;
+                        acc[r][hr] = sr;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int p = 0; p < CH_K; ++p) Tc[p] = Tn[p];
@@ -343,6 +370,19 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
                 if (TSEL >= 0 && t != TSEL) continue;
                 // pairing t: B index for A index p; natural-order matrix, rolled-order matrix (widget numbering 0..7)
                 const int hn = (TSEL < 0) ? t : 0, hr = (TSEL >= 0) ? 1 : (t == 0) ? 5 : (t == 1) ? 4 : (t == 2) ? 7 : 6;
+                if constexpr (RELAX) {
+                    // two independent chains per (row, pairing) so that the reciprocals' latency overlaps
+                    double s0 = acc[r][hn], s1 = 0.0;
+#pragma unroll
+                    for (int p = 0; p < CH_K; p += 2) {
+                        const int q0 = (t == 0) ? p : (t == 1) ? (p + 6) % 12 : (t == 2) ? 11 - p : (17 - p) % 12;
+                        const int q1 = (t == 0) ? p + 1 : (t == 1) ? (p + 7) % 12 : (t == 2) ? 10 - p : (16 - p) % 12;
+                        s0 = __builtin_fma(a[p] * b[q0], relaxed_recip(a[p] + b[q0]), s0);
+                        s1 = __builtin_fma(a[p + 1] * b[q1], relaxed_recip(a[p + 1] + b[q1]), s1);
+                    }
+                    acc[r][hn] = s0 + s1;
+                    continue;
+                }
                 double T[CH_K];
 #pragma unroll
                 for (int p = 0; p < CH_K; ++p) {
@@ -366,11 +406,32 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
         for (int r = 0; r < SY_RI; ++r) {
             const int gi = i0 + wave * SY_RI + r;
             if (gi < nA) {
+                if constexpr (RELAX) {
+                    const double half = 0.5 * (sumA[gi] + sumB[gj]);
 #pragma unroll
-                for (int h = 0; h < NH; ++h) out[(size_t)h * mstride + (size_t)gi * ld + gj] = 0.5 * acc[r][h];
+                    for (int t = 0; t < NACC; ++t) {
+                        const double u = __builtin_fma(-2.0, acc[r][t], half);
+                        const int hr = (TSEL >= 0) ? 1 : (t == 0) ? 5 : (t == 1) ? 4 : (t == 2) ? 7 : 6;       // the twin: the same number
+                        out[(size_t)t * mstride + (size_t)gi * ld + gj] = u;
+                        out[(size_t)hr * mstride + (size_t)gi * ld + gj] = u;
+                    }
+                } else {
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) out[(size_t)h * mstride + (size_t)gi * ld + gj] = 0.5 * acc[r][h];
+                }
             }
         }
     }
+}
+
+// sum over a descriptor row's 360 bins, bin order (relaxed cost build: 0.5 (sum a + sum b) - 2 sum ab/(a+b))
+__global__ __launch_bounds__(256) void relaxed_rowsum_kernel(const double *__restrict__ sc, int n, double *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double *row = sc + (size_t)i * PM_NBINS;
+    double s = 0.0;
+    for (int k = 0; k < PM_NBINS; ++k) s += row[k];
+    out[i] = s;
 }
 
 // flag[0] |= 1 unless, bit for bit, sc2 = roll6(sc1), sc3 = reverse(sc1), sc4 = (5-q)(sc1) within every shell.
@@ -405,15 +466,17 @@ extern "C" int pm_chi2_symmetry_check(const double *sc_m1, const double *sc_m2, 
 }
 
 namespace pm {
-template <int RI, int MINW, int TSEL = -1, int TL = 0>
+template <int RI, int MINW, int TSEL = -1, int TL = 0, bool RELAX = false>
 int chi2_sym_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld, size_t mstride, hipStream_t s,
-                    const unsigned char *cntA = nullptr, const unsigned char *cntB = nullptr, const SymMeta *meta = nullptr) {
+                    const unsigned char *cntA = nullptr, const unsigned char *cntB = nullptr, const SymMeta *meta = nullptr,
+                    const double *sumA = nullptr, const double *sumB = nullptr) {
     const long nTi = ((long)nM + 4 * RI - 1) / (4 * RI), nTj = ((long)nF + CH_TJ - 1) / CH_TJ;
     const long nblocks = nTi * nTj;
     if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
     if (TL > 0 && (!cntA || !cntB || !meta)) return PM_ERR_INVALID_ARG;
-    chi2_sym_kernel<RI, MINW, TSEL, TL><<<(unsigned int)nblocks, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, mstride, (int)nTi,
-                                                                                    (unsigned int)nblocks, cntA, cntB, meta);
+    if (RELAX && (!sumA || !sumB)) return PM_ERR_INVALID_ARG;
+    chi2_sym_kernel<RI, MINW, TSEL, TL, RELAX><<<(unsigned int)nblocks, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, mstride, (int)nTi,
+                                                                                           (unsigned int)nblocks, cntA, cntB, meta, sumA, sumB);
     return launch_status();
 }
 
@@ -544,6 +607,38 @@ extern "C" int pm_chi2_sym_table_info(const void *ws, int32_t *tabled30, int32_t
         tabled30[g] = (m.bad == 0 && m.maxc[0][g] < pm::CH_TL && m.maxc[1][g] < pm::CH_TL) ? 1 : 0;
     *table_size = pm::CH_TL;
     return PM_OK;
+}
+
+// The relaxed build (opt-in experiment; see RELAX above).  Workspace: pm_chi2_relaxed_workspace_bytes = the term-table workspace +
+// the two row-sum vectors.  variant 0: every shell computed; 1: shells with small counts from a (relaxed) term table.
+extern "C" size_t pm_chi2_relaxed_workspace_bytes(int nM, int nF) {
+    if (nM <= 0 || nF <= 0) return 0;
+    return pm::align_up(pm_chi2_sym_workspace_bytes(nM, nF), 256) + pm::align_up((size_t)nM * 8, 256) + pm::align_up((size_t)nF * 8, 256);
+}
+
+extern "C" double pm_chi2_relaxed_delta(void) { return PM_CHI2_RELAX_DELTA; }
+
+extern "C" int pm_chi2_cost8_relaxed(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
+                                     size_t matrix_stride, void *ws, size_t ws_bytes, int variant, void *stream) {
+    if (!sc_m1 || !sc_f1 || !out || nM <= 0 || nF <= 0 || ld < (size_t)nF || matrix_stride < (size_t)nM * ld)
+        return PM_ERR_INVALID_ARG;
+    if (((uintptr_t)sc_f1 & 15) != 0 || ((uintptr_t)sc_m1 & 15) != 0) return PM_ERR_INVALID_ARG;
+    if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < pm_chi2_relaxed_workspace_bytes(nM, nF)) return PM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t tab_bytes = pm::align_up(pm_chi2_sym_workspace_bytes(nM, nF), 256);
+    double *sumA = (double *)((char *)ws + tab_bytes);
+    double *sumB = (double *)((char *)sumA + pm::align_up((size_t)nM * 8, 256));
+    pm::relaxed_rowsum_kernel<<<(nM + 255) / 256, 256, 0, s>>>(sc_m1, nM, sumA);
+    pm::relaxed_rowsum_kernel<<<(nF + 255) / 256, 256, 0, s>>>(sc_f1, nF, sumB);
+    if (variant == 0)
+        return pm::chi2_sym_launch<4, 2, -1, 0, true>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, nullptr, nullptr, nullptr, sumA, sumB);
+    if (variant != 1 && variant != 2) return PM_ERR_INVALID_ARG;
+    pm::SymWs w;
+    const int rc = pm::sym_prepare(sc_m1, nM, sc_f1, nF, ws, tab_bytes, s, w);
+    if (rc != PM_OK) return rc;
+    if (variant == 2)
+        return pm::chi2_sym_launch<4, 3, -1, 64, true>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta, sumA, sumB);
+    return pm::chi2_sym_launch<4, 2, -1, pm::CH_TL, true>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta, sumA, sumB);
 }
 
 extern "C" int pm_chi2_cost8_sym_ws(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,

@@ -251,12 +251,15 @@ class DeviceMatrix:
         return viol, loose, tight[:n_tight].cpu().numpy(), red[:n_tight].cpu().numpy(), bound
 
 
-def certify(M, u, v, col4row, info=None):
+def certify(M, u, v, col4row, info=None, min_eps=0.0):
     """Is (u, v, col4row) a certified UNIQUE optimum of the matrix M (nr <= nc)?  Dual feasibility and complementary
     slackness on every entry (pm_lsap_certificate), the free columns carrying the largest column dual (nr < nc), and no
     alternating cycle among the entries within eps of tight (pm_lsap_unique).  info["optimal"] tells the two failures apart:
     True = the assignment IS optimal (to the rounding bound) but another one lies within the margin, so which of them
-    SciPy's rounding would return cannot be told without running SciPy's algorithm."""
+    SciPy's rounding would return cannot be told without running SciPy's algorithm.
+    min_eps (absolute): a wider uniqueness margin demanded by the caller — the relaxed cost build (pm_chi2_cost8_relaxed) asks for
+    2 min(N, M) delta, delta its per-entry error bound: an optimum of the relaxed matrix that beats every alternative by more
+    than that is the exact matrix's unique optimum too."""
     lib = nat.load()
     nr, nc = M.shape
     scale = max(float(np.abs(u).max()), float(np.abs(v).max()), 1e-300)
@@ -268,7 +271,7 @@ def certify(M, u, v, col4row, info=None):
     # ~1e-17 per row: rounding).  If every alternative needs an entry with reduced cost > eps, eps > bound separates them —
     # taken EPS_SAFETY times wider, and never below REL_EPS_FLOOR (far above the rounding any exact solver, SciPy's included,
     # accumulates along a cycle).
-    eps = max(REL_EPS_FLOOR * scale, EPS_SAFETY * bound)
+    eps = max(REL_EPS_FLOOR * scale, EPS_SAFETY * bound, float(min_eps) + bound)
     if info is not None:
         info.update(violations=viol, loose=loose, tight=None if tight is None else len(tight), slack_bound=bound, delta=delta, eps=eps)
     if info is not None:
@@ -438,6 +441,8 @@ def solve_core(M, info=None):
             rounds += 1
             if info is not None:
                 info.setdefault("violated_per_round", []).append(violated)
+                info.setdefault("steps_after_solve", []).append(stats[1])
+                info.setdefault("augmentations_after_solve", []).append(stats[2])
             if violated == 0:
                 break
             if rounds >= MAX_PRICING_ROUNDS:
@@ -470,7 +475,7 @@ def solve_on_device(U, info=None, force=False):
 DENSE_FALLBACK_MAX_ENTRIES = 1 << 30      # matrices above this many entries are never handed to the dense host solver (hours)
 
 
-def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=True, accept_near_ties=False):
+def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=True, accept_near_ties=False, min_eps=0.0):
     """One hypothesis and its twin (the same terms summed in another order: U11/U22, U12/U21, U13/U24, U14/U23), both float64
     GPU matrices [N, M]: the hypothesis is solved on its sparse core and certified; the twin first tries its sibling's duals —
     accepted only if they are a certified unique optimum of the twin's OWN entries — and is solved on its own otherwise.
@@ -491,12 +496,12 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
     W = DeviceMatrix(U_h if n <= m else transposed(U_h))
     Wt = None
     sol = solve_core(W, info_h)
-    if sol is not None and certify(W, *sol, info=info_h):
+    if sol is not None and certify(W, *sol, info=info_h, min_eps=min_eps):
         info_h["route"] = "device"
         out[0] = _answer(sol[2], n, m)
         W = None                                        # (possibly a transposed copy: release it before the twin's is made)
         Wt = DeviceMatrix(U_twin if n <= m else transposed(U_twin))
-        if certify(Wt, *sol, info=info_twin):
+        if certify(Wt, *sol, info=info_twin, min_eps=min_eps):
             info_twin["route"] = "device (sibling's duals certified)"
             out[1] = out[0]
             return out
@@ -513,7 +518,7 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
     if Wt is None:
         Wt = DeviceMatrix(U_twin if n <= m else transposed(U_twin))
     sol_t = solve_core(Wt, info_twin)
-    if sol_t is not None and certify(Wt, *sol_t, info=info_twin):
+    if sol_t is not None and certify(Wt, *sol_t, info=info_twin, min_eps=min_eps):
         info_twin["route"] = "device"
         out[1] = _answer(sol_t[2], n, m)
     elif host_ok:
@@ -530,7 +535,7 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
 PIPELINED_PRIORITY = -1
 
 
-def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False, ready=None):
+def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False, ready=None, min_eps=0.0):
     """The widget's eight assignments (_dock_widget.py:604-611) for U8 [8, N, M] on the GPU: hypotheses 11, 12, 13, 14 are
     solved (four host threads drive their core solves and kernels concurrently), each together with its twin (22, 21, 24,
     23: solve_pair_on_device).  -> list of eight (row_ind, col_ind).
@@ -568,7 +573,7 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
         with torch.cuda.device(U8.device), torch.cuda.stream(stream):
             if ready is not None:
                 stream.wait_event(ready[h])
-            out[h], out[twin] = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], allow_host, accept_near_ties)
+            out[h], out[twin] = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], allow_host, accept_near_ties, min_eps)
             stream.synchronize()
 
     if ready is None:

@@ -109,7 +109,8 @@ def test_every_entry_point_rejects_bad_arguments_before_touching_the_device(lib_
     so this runs without a GPU); a non-NULL call with a missing workspace -> PM_ERR_WORKSPACE; size queries answer 0."""
     from platymatch_amd import _native
     lib = _native.load()
-    skipped = {"pm_version", "pm_last_hip_error", "pm_error_string", "pm_lsap_core_create", "pm_lsap_core_destroy"}
+    skipped = {"pm_version", "pm_last_hip_error", "pm_error_string", "pm_lsap_core_create", "pm_lsap_core_destroy",
+               "pm_chi2_relaxed_delta"}                 # (a constant, no arguments)
     for name, (restype, argtypes) in _native.SIGNATURES.items():
         if name in skipped:
             continue
@@ -131,6 +132,8 @@ def test_every_entry_point_rejects_bad_arguments_before_touching_the_device(lib_
     assert lib.pm_chi2_cost8_sym_ws(fake, 10, fake, 10, fake, 10, 100, None, 0, None) == -2
     assert lib.pm_chi2_cost_pair_sym_ws(fake, 10, fake, 10, 1, fake, 10, 100, fake, 64, None) == -2     # workspace too small
     assert lib.pm_chi2_sym_workspace_bytes(10, 20) == 512 + 3600 + 7200
+    assert lib.pm_chi2_cost8_relaxed(fake, 10, fake, 10, fake, 10, 100, None, 0, 1, None) == -2       # workspace missing
+    assert 0.0 < lib.pm_chi2_relaxed_delta() < 1e-11
     assert lib.pm_shape_context(fake, 10, 8, 5, fake, fake, fake, 4, fake, None, None, None) == -1     # row block outside the cloud
     assert lib.pm_shape_context(fake, 10, 0, 5, fake, fake, fake, 3, fake, None, None, None) == -1     # 3 frames do not exist
     assert lib.pm_shape_context_tiled(fake, 10, 0, 5, fake, fake, fake, 4, fake, None, None, None, None, 0, None) == -2   # workspace missing

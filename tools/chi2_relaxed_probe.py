@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""The relaxed-rounding cost build (pm_chi2_cost8_relaxed: opt-in experiment) beside the exact one:
+launch time (HIP events), the largest deviation from the exact entries against the stated bound, and whether the assignments
+read off the relaxed matrices are certified unique with the margin that bound demands (2 min(N, M) delta) — and equal the
+exact matrices' assignments.  Usage: python tools/chi2_relaxed_probe.py [N] [check_rows]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from conftest import synth_pair  # noqa: E402
+from platymatch_amd import _kernels as K, lsap as L, pipeline as P  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+check_rows = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+mv, fx, _ = synth_pair(n, 42)
+be = P.GpuBackend()
+mov, fix = be.cloud(mv), be.cloud(fx)
+sc_m, sc_f, _ = P.build_descriptors(be, mov, fix)
+a, b = sc_m[0].contiguous(), sc_f[0].contiguous()
+assert K.chi2_symmetric(sc_m, sc_f)
+delta = K.chi2_relaxed_delta()
+print("N = M = %d; per-entry bound delta = %.1e; margin a certificate must show: 2 N delta = %.2e" % (n, delta, 2 * n * delta), flush=True)
+
+
+def timed(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return min(ts), ts
+
+
+# --- accuracy on a row block (both results resident)
+rows = min(check_rows, n)
+blk = a[:rows].contiguous()
+exact = K.chi2_cost8_frame1(blk, b)
+for variant in (0, 1, 2):
+    rel = K.chi2_cost8_relaxed(blk, b, variant=variant)
+    diff = (rel - exact).abs()
+    twins = all(torch.equal(rel[h], rel[t]) for t, h in L.TWINS.items())
+    print("variant %d: max |relaxed - exact| over %d x %d x 8 entries = %.2e (bound %.1e: %s); twins identical: %s; row argmins equal: %s"
+          % (variant, rows, n, float(diff.max()), delta, "ok" if float(diff.max()) <= delta else "EXCEEDED", twins,
+             bool(torch.equal(K.row_argmin(rel), K.row_argmin(exact)))), flush=True)
+    del rel, diff
+del exact
+torch.cuda.empty_cache()
+
+# --- launch times at full size, one buffer
+out = torch.empty((8, n, n), dtype=torch.float64, device=mov.device)
+t_exact, all_exact = timed(lambda: K.chi2_cost8_frame1(a, b, out=out))
+print("exact (term table)       : %8.1f ms  %s" % (t_exact, ["%.1f" % t for t in all_exact]), flush=True)
+best = (None, 1e30)
+for variant, name in ((0, "relaxed, all computed    "), (1, "relaxed, 94 x 94 table   "), (2, "relaxed, 64 x 64 table x3")):
+    t, ts = timed(lambda: K.chi2_cost8_relaxed(a, b, out=out, variant=variant))
+    print("%s: %8.1f ms  %s   speed-up %.2fx" % (name, t, ["%.1f" % x for x in ts], t_exact / t), flush=True)
+    if t < best[1]:
+        best = (variant, t)
+
+# --- the assignments: exact matrices, then the fastest relaxed variant with the wider margin
+K.chi2_cost8_frame1(a, b, out=out)
+info_e = {}
+t0 = time.perf_counter()
+lsa_e = L.solve_eight_on_device(out, info=info_e, allow_host=False)
+print("exact matrices  : eight assignments in %.2f s, routes %s" % (time.perf_counter() - t0, sorted(set(info_e["routes"]))), flush=True)
+K.chi2_cost8_relaxed(a, b, out=out, variant=best[0])
+info_r = {}
+t0 = time.perf_counter()
+lsa_r = L.solve_eight_on_device(out, info=info_r, allow_host=False, min_eps=2.0 * n * delta)
+print("relaxed matrices: eight assignments in %.2f s with min_eps = %.2e, routes %s" % (time.perf_counter() - t0, 2.0 * n * delta, sorted(set(info_r["routes"]))), flush=True)
+for h in range(8):
+    d = info_r["details"][h]
+    same = lsa_r[h] is not None and lsa_e[h] is not None and np.array_equal(lsa_r[h][1], lsa_e[h][1])
+    print("  hypothesis %d: certified with the wider margin: %s (eps used %.2e, entries within it %s, unique %s); equals the exact matrix's assignment: %s"
+          % (h, lsa_r[h] is not None, d.get("eps", float("nan")), d.get("tight_within_eps"), d.get("unique"), same), flush=True)
