@@ -76,6 +76,7 @@ __global__ __launch_bounds__(192) void centroid_kernel(const double *__restrict_
 // sums of a full piece meet in a balanced tree.  The last, partial piece takes the general plan / leaf / combine route of
 // pm_pairwise.h.  Piece sums go to `partial[]`; a second launch adds them one after the other (staged through LDS) and divides.
 constexpr int MDX_WAVES = 4;
+constexpr int MDX_LEAF_PITCH = 136;       // doubles between the leaves of a block in LDS (128 + 8: see mean_distance_chunks)
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(MDX_WAVES * 64) void mean_distance_chunks(const dou
     __shared__ int s_off[MDX_WAVES][160];
     __shared__ int s_cf[MDX_WAVES][4];
     __shared__ double s_leaf[MDX_WAVES][160];
+    __shared__ double s_blk[MDX_WAVES][8 * MDX_LEAF_PITCH];          // a wave's block of 1 024 distances (eight leaves)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double *P0 = xyz, *P1 = xyz + (size_t)n, *P2 = xyz + 2 * (size_t)n;
     const long long waves_total = (long long)gridDim.x * MDX_WAVES;
@@ -127,34 +129,60 @@ __global__ __launch_bounds__(MDX_WAVES * 64) void mean_distance_chunks(const dou
         const int len = (int)((P - e0 < PM_PW_CHUNK) ? P - e0 : PM_PW_CHUNK);
         double chunk_sum;
         if (len == PM_PW_CHUNK) {
-            // Lanes in element order within a 16-lane row pair up as (q, parity): lane_in_row = 2 q + p, so that accumulator
-            // r[acc] (acc = 2 * row + p ... see elem_of) runs through q = 0..7 by shifts of TWO lanes inside the row: DPP moves
-            // (VALU), and a lane whose source lies outside the row keeps its own value — with the addend zeroed for q = 0 every
-            // step is an unconditional add (v <- shifted(v) + term): finished lanes recompute the value they already hold.
-            // (Tried: __shfl_up(v, 8) chains — LDS permutes, 5.7 ms per 50 000-point cloud; eight leaves side by side with one
-            // accumulator per lane and no cross-lane traffic — uncoalesced loads, 6.9 ms.)
-            const int row = lane >> 4, lir = lane & 15, q = lir >> 1, par = lir & 1;
-            const int acc_id = 2 * row + par;                        // which of NumPy's eight partial sums this lane feeds
-            int i, j;
-            md_locate(e0 + 8 * q + acc_id, n, i, j);                 // element 8 q + acc of the 64-element half leaf
+            // Round 4.  A piece is 64 leaves of 128 elements; NumPy runs eight interleaved partial sums through a leaf (r[k] takes
+            // elements k, k + 8, ..., k + 120, one after the other) and combines them ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)).
+            // The piece is taken in eight blocks of 1 024 elements (eight leaves).  Per block:
+            //   1. the 1 024 distances are computed with the lanes in ELEMENT order (coalesced loads of p_j) and written to this
+            //      wave's LDS block; a block that lies inside one row of the pair list — all but ~4 % at 50 000 points — has ONE p_i
+            //      (wave-uniform, scalar registers) and p_j = p[jb + 64 t + lane]: no per-lane index arithmetic at all;
+            //   2. lane (leaf l = lane / 8, partial sum k = lane % 8) adds its sixteen elements l * 128 + k + 8 t in order from LDS
+            //      (leaves 136 doubles apart: the 64 lanes of a read fall on all 32 bank pairs twice — the natural rate of 8-byte
+            //      reads) — no cross-lane chain (round 3 chained the partial sums through the lanes by DPP moves: ~25 vector
+            //      instructions per element; this is one write, one read and one add);
+            //   3. the eight partial sums of a leaf meet by three row-shift adds, in NumPy's bracketing.
+            // The 64 leaf sums of the piece are then added by the balanced tree below, as before.  Same operations on the same
+            // operands in the same order as round 3's kernel, hence the same bits (tests/test_gpu_parity.py::test_statistics*).
+            double *blk = s_blk[wave];
+            const int l = lane >> 3, kk = lane & 7;
             double keep = 0.0;
-            for (int leaf = 0; leaf < 64; ++leaf) {
-                const double a = md_dist(P0, P1, P2, i, j);
-                md_advance(i, j, 64, n);
-                const double b = md_dist(P0, P1, P2, i, j);
-                md_advance(i, j, 64, n);
-                const double a_eff = q == 0 ? 0.0 : a, b_eff = q == 0 ? 0.0 : b;
-                double v = a;
+            for (int it = 0; it < 8; ++it) {
+                const long long eb = e0 + (long long)it * 1024;
+                int ib, jb;
+                md_locate(eb, n, ib, jb);                            // (every lane computes the same pair: wave-uniform)
+                ib = __builtin_amdgcn_readfirstlane(ib);
+                jb = __builtin_amdgcn_readfirstlane(jb);
+                if (jb + 1024 <= n) {                                // the whole block pairs p_ib with p_jb .. p_jb+1023
+                    const double a0 = P0[ib], a1 = P1[ib], a2 = P2[ib];
+                    const double *q0 = P0 + jb + lane, *q1 = P1 + jb + lane, *q2 = P2 + jb + lane;
+#pragma unroll 4
+                    for (int t = 0; t < 16; ++t) {
+                        const double d0 = a0 - q0[64 * t], d1 = a1 - q1[64 * t], d2 = a2 - q2[64 * t];
+                        blk[(t >> 1) * MDX_LEAF_PITCH + (t & 1) * 64 + lane] = __builtin_sqrt(__builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0)));
+                    }
+                } else {                                             // the block crosses rows of the pair list: every lane follows its own pair
+                    int i, j;
+                    md_locate(eb + lane, n, i, j);
+                    for (int t = 0; t < 16; ++t) {
+                        blk[(t >> 1) * MDX_LEAF_PITCH + (t & 1) * 64 + lane] = md_dist(P0, P1, P2, i, j);
+                        md_advance(i, j, 64, n);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const double *lf = blk + l * MDX_LEAF_PITCH + kk;
+                double r = lf[0];
 #pragma unroll
-                for (int step = 1; step < 8; ++step) v = dpp_f64<0x112>(v) + a_eff;      // row_shr:2 — lane l reads lane l - 2
-                const double w = dpp_f64<0x10e>(v);                  // row_shl:14 — q = 0 reads q = 7 of its accumulator
-                v = q == 0 ? w + b : v;
+                for (int t = 1; t < 16; ++t) r = r + lf[8 * t];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();                     // (the next block's writes come after these reads)
+                const double s1 = r + dpp_f64<0x101>(r);             // row_shl:1 — lane k reads lane k + 1: r[k] + r[k + 1] (k even)
+                const double s2 = s1 + dpp_f64<0x102>(s1);           // (r0 + r1) + (r2 + r3) in k = 0, (r4 + r5) + (r6 + r7) in k = 4
+                const double s3 = s2 + dpp_f64<0x104>(s2);           // the leaf sum, in lane 8 l
 #pragma unroll
-                for (int step = 1; step < 8; ++step) v = dpp_f64<0x112>(v) + b_eff;
-                // r[acc] now sits in lanes (q = 7): lane_in_row 14 + p of row `row`: acc 0, 1 in row 0, ... 6, 7 in row 3
-                const double s01 = v + dpp_f64<0x101>(v);            // row_shl:1 — lane 14 reads lane 15: r[2 row] + r[2 row + 1]
-                const double ls = (readlane_f64(s01, 14) + readlane_f64(s01, 30)) + (readlane_f64(s01, 46) + readlane_f64(s01, 62));
-                if (lane == leaf) keep = ls;
+                for (int w = 0; w < 8; ++w) {
+                    const double ls = readlane_f64(s3, 8 * w);
+                    if (lane == it * 8 + w) keep = ls;
+                }
             }
 #pragma unroll
             for (int st = 1; st < 64; st <<= 1) keep = keep + __shfl_down(keep, st, 64);   // balanced tree: left + right
