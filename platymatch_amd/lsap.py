@@ -293,6 +293,7 @@ def certify(M, u, v, col4row, info=None, min_eps=0.0):
     tight = tight[keep]
     if info is not None:
         info["tight_within_eps"] = int(keep.sum())
+        info["_tight_edges"] = tight                   # (row, col) of the entries an alternative optimum would have to use: resolve_near_ties
     t = np.ascontiguousarray(tight, dtype=np.int32)
     c4r = np.ascontiguousarray(col4row, dtype=np.int32)
     vv = np.ascontiguousarray(v, dtype=np.float64)
@@ -302,6 +303,102 @@ def certify(M, u, v, col4row, info=None, min_eps=0.0):
     if info is not None:
         info["unique"] = rc == 1
     return rc == 1
+
+
+RESOLVE_MAX_BLOCK_ROWS = 4096      # largest set of rows (all near-tied groups together) settled by the dense algorithm on their block
+
+
+def _cyclic_groups(edges, owner):
+    """Rows that lie on an alternating cycle of the digraph i -> owner(col) over the near-tight entries (row, col): the strongly
+    connected components with more than one row (iterative Tarjan over the rows that appear at all) -> list of sorted row arrays."""
+    succ = {}
+    for i, j in edges:
+        o = int(owner[int(j)])
+        if o >= 0 and o != int(i):
+            succ.setdefault(int(i), []).append(o)
+    index, low, on, order, groups = {}, {}, set(), [], []
+    for root in list(succ):
+        if root in index:
+            continue
+        work = [(root, 0)]
+        while work:
+            node, k = work.pop()
+            if k == 0:
+                index[node] = low[node] = len(index)
+                order.append(node)
+                on.add(node)
+            nxt = succ.get(node, [])
+            if k < len(nxt):
+                work.append((node, k + 1))
+                w = nxt[k]
+                if w not in index:
+                    work.append((w, 0))
+                elif w in on:
+                    low[node] = min(low[node], index[w])
+                continue
+            for w in nxt:                                  # children are finished: fold their low links
+                if w in on:
+                    low[node] = min(low[node], low[w])
+            if low[node] == index[node]:
+                comp = []
+                while True:
+                    w = order.pop()
+                    on.discard(w)
+                    comp.append(w)
+                    if w == node:
+                        break
+                if len(comp) > 1:
+                    groups.append(np.array(sorted(comp), dtype=np.int64))
+    return groups
+
+
+def resolve_near_ties(M, sol, info):
+    """A certified OPTIMAL assignment whose uniqueness could not be proven (certify: info["optimal"], an alternative within eps):
+    every alternative optimum differs from it only by alternating cycles over the near-tight entries, i.e. by a permutation of
+    the columns WITHIN each group of rows such a cycle connects.  Each group's block (its rows x the columns they hold) is
+    fetched — a few rows, whatever the size of the matrix — and assigned by SciPy's own algorithm (pm_lsap_solve), the result
+    spliced in: the answer where the reference always answers (_dock_widget.py:604-611), optimal to the certificate's bound, with
+    the near-tie settled by the reference's solver on the entries that decide it.  (For an EXACT tie inside a block SciPy's pick on
+    the block need not be its pick on the whole matrix: its tie-breaking follows the order of its augmentations.)
+    -> col4row, or None if it does not apply (no edges kept, an alternative through a spare column of a rectangular problem, groups beyond
+    RESOLVE_MAX_BLOCK_ROWS rows in all, a block the dense solver refuses)."""
+    import math
+    nr, nc = M.shape
+    edges = info.get("_tight_edges")
+    if edges is None or len(edges) == 0 or not hasattr(M, "entries"):
+        return None
+    c4r = np.array(sol[2], dtype=np.int64, copy=True)
+    owner = np.full(nc, -1, dtype=np.int64)
+    owner[c4r] = np.arange(nr)
+    if nr < nc:
+        # spare columns: an alternative may also run through a column nobody holds (a near-tight entry into one, or a held column
+        # whose dual is within eps of the free columns' level: certify / pm_lsap_unique's node F) — those are not settled here
+        v = np.asarray(sol[1])
+        v_free = float(v[owner < 0].min())
+        into_free = bool((owner[np.asarray(edges)[:, 1]] < 0).any())                    # some row is near-tight on a column nobody holds
+        out_of_free = bool((v_free - v[owner >= 0] <= float(info.get("eps", 0.0))).any())   # some held column is priced like a free one
+        if into_free and out_of_free:                      # only then can a cycle pass through F
+            return None
+    groups = _cyclic_groups(np.asarray(edges), owner)
+    total = int(sum(len(g) for g in groups))
+    if not groups or total > RESOLVE_MAX_BLOCK_ROWS:
+        return None
+    changed = 0
+    for rows in groups:
+        cols = c4r[rows]
+        k = len(rows)
+        S = np.asarray(M.entries(np.repeat(rows, k), np.tile(cols, k)), dtype=np.float64).reshape(k, k)
+        try:
+            r, c = linear_sum_assignment(S)
+        except ValueError:
+            return None
+        if math.fsum(S[r, c]) > math.fsum(np.diag(S)) + abs(info.get("eps", 0.0)) * k:      # cannot happen for a certified optimum
+            return None
+        changed += int((c != np.arange(k)).sum())
+        c4r[rows[r]] = cols[c]
+    info["resolved_groups"] = [int(len(g)) for g in groups]
+    info["resolved_rows_moved"] = changed
+    return c4r.astype(np.int32)
 
 
 # Jacobi rounds of augmenting row reduction on the dense rows before the core is chosen (0 = off, the default).  Measured at
@@ -508,6 +605,8 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
     elif host_ok:
         info_h["route"] = "host"
         out[0] = linear_sum_assignment(U_h.cpu().numpy())
+    elif sol is not None and info_h.get("optimal") and _resolved(W, sol, info_h, out, 0, n, m):
+        pass
     elif accept_near_ties and sol is not None and info_h.get("optimal"):
         info_h["route"] = near_tie
         out[0] = _answer(sol[2], n, m)
@@ -524,12 +623,24 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
     elif host_ok:
         info_twin["route"] = "host"
         out[1] = linear_sum_assignment(U_twin.cpu().numpy())
+    elif sol_t is not None and info_twin.get("optimal") and _resolved(Wt, sol_t, info_twin, out, 1, n, m):
+        pass
     elif accept_near_ties and sol_t is not None and info_twin.get("optimal"):
         info_twin["route"] = near_tie
         out[1] = _answer(sol_t[2], n, m)
     else:
         info_twin["route"] = refused
     return out
+
+
+def _resolved(W, sol, info, out, slot, n, m):
+    """solve_pair_on_device: settle a certified optimum's near-ties on their blocks (resolve_near_ties) -> True if out[slot] was set."""
+    c4r = resolve_near_ties(W, sol, info)
+    if c4r is None:
+        return False
+    info["route"] = "device (optimal; near-tie settled by the dense algorithm on %d row(s) in %d block(s))" % (sum(info["resolved_groups"]), len(info["resolved_groups"]))
+    out[slot] = _answer(c4r, n, m)
+    return True
 
 
 PIPELINED_PRIORITY = -1

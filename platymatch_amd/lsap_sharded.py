@@ -300,6 +300,15 @@ def serve(locals_, wire):
         pass
 
 
+def _settle(M, sol, info, out, slot):
+    c4r = lsap.resolve_near_ties(M, sol, info)
+    if c4r is None:
+        return False
+    out[slot] = c4r
+    info["route"] = "sharded device (optimal; near-tie settled by the dense algorithm on %d row(s))" % sum(info["resolved_groups"])
+    return True
+
+
 def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=None, accept_near_ties=False):
     """One hypothesis and (optionally) its twin, rows sharded: the root solves the first on its sparse core and certifies the
     result on both matrices; a twin that does not accept its sibling's duals is solved on its own core.  -> (col4row of the
@@ -319,6 +328,8 @@ def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=No
             certified = sol is not None and lsap.certify(M, *sol, info=info)
             if certified:
                 out[0] = sol[2]
+            elif sol is not None and info.get("optimal") and _settle(M, sol, info, out, 0):
+                pass                                      # near-ties settled on their blocks (lsap.resolve_near_ties: a few entries travel)
             elif accept_near_ties and sol is not None and info.get("optimal"):
                 out[0] = sol[2]
                 near.append(0)
@@ -333,6 +344,8 @@ def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=No
                     sol_t = lsap.solve_core(Mt, tinfo)
                     if sol_t is not None and lsap.certify(Mt, *sol_t, info=tinfo):
                         out[1] = sol_t[2]
+                    elif sol_t is not None and tinfo.get("optimal") and _settle(Mt, sol_t, tinfo, out, 1):
+                        pass
                     elif accept_near_ties and sol_t is not None and tinfo.get("optimal"):
                         out[1] = sol_t[2]
                         near.append(1)

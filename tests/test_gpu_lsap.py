@@ -239,28 +239,42 @@ def test_streamed_hypotheses_give_the_same_registration(dev):
         assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
-def test_near_tie_beyond_the_dense_solvers_reach_raises_unless_accepted(dev, monkeypatch):
-    """Where SciPy's dense algorithm is no fallback (lsap.DENSE_FALLBACK_MAX_ENTRIES; lowered here), a hypothesis whose optimum
-    is certified but has an alternative inside the margin comes back None (the driver raises) — or, with
-    accept_near_ties=True, as the certified optimum, labelled as such.  The engineered matrix has one 2-cycle worth 1e-14."""
+def test_near_tie_beyond_the_dense_solvers_reach_is_settled_on_its_block(dev, monkeypatch):
+    """Where SciPy's dense algorithm is no fallback for the whole matrix (lsap.DENSE_FALLBACK_MAX_ENTRIES; lowered here), a
+    hypothesis whose optimum is certified but has an alternative inside the margin is SETTLED (round 4): the rows its near-tight
+    entries connect are assigned by SciPy's algorithm on their own block and spliced in — the reference never refuses
+    (_dock_widget.py:604-611).  The engineered matrix has one 2-cycle worth 1e-14; the answer equals SciPy's on the whole matrix.
+    Only when the block cannot be formed (here: RESOLVE_MAX_BLOCK_ROWS lowered) does the hypothesis come back None (the driver
+    raises) — or, with accept_near_ties=True, as the certified optimum, labelled as such."""
     from platymatch_amd import lsap as L
     rng = np.random.default_rng(21)
     n = 1100
     base = rng.random((n, n)) + 0.5
     u, v, c = L.solve_core(L.DeviceMatrix(dev(base)))
-    U = base.copy()
-    i1, i2 = 5, 900
-    U[i1, c[i2]] = (u[i1] + v[c[i2]]) + 0.5e-14
-    U[i2, c[i1]] = (u[i2] + v[c[i1]]) + 0.5e-14
-    Ud = dev(U)
+    rs, cs = None, None
+    for sign in (+1.0, -1.0):                        # the alternative 1e-14 dearer than the start's optimum, then 1e-14 cheaper
+        U = base.copy()
+        i1, i2 = 5, 900
+        U[i1, c[i2]] = (u[i1] + v[c[i2]]) + sign * 0.5e-14
+        U[i2, c[i1]] = (u[i2] + v[c[i1]]) + sign * 0.5e-14
+        Ud = dev(U)
+        rs, cs = scipy_lsa(U)
+        monkeypatch.setattr(L, "DENSE_FALLBACK_MAX_ENTRIES", 0)
+        ih, it = {}, {}
+        out = L.solve_pair_on_device(Ud, Ud, ih, it)
+        assert ih["optimal"] and "settled" in ih["route"] and ih["resolved_groups"] == [2], ih.get("route")
+        for r_, c_ in out:
+            assert np.array_equal(r_, rs) and np.array_equal(c_, cs), sign            # SciPy's own pick between the two
+        monkeypatch.undo()
+    # the block cannot be formed: refused by default, the certified optimum with accept_near_ties
     monkeypatch.setattr(L, "DENSE_FALLBACK_MAX_ENTRIES", 0)
+    monkeypatch.setattr(L, "RESOLVE_MAX_BLOCK_ROWS", 1)
     ih, it = {}, {}
     out = L.solve_pair_on_device(Ud, Ud, ih, it)
     assert out == [None, None] and ih["optimal"] and ih["route"].startswith("uncertified (too large")
     ih, it = {}, {}
     out = L.solve_pair_on_device(Ud, Ud, ih, it, accept_near_ties=True)
     assert "near-tie" in ih["route"] and "near-tie" in it["route"]
-    rs, cs = scipy_lsa(U)
     for r_, c_ in out:
         assert np.array_equal(r_, rs) and sorted(c_) == list(range(n))
         assert abs(U[r_, c_].sum() - U[rs, cs].sum()) <= 1e-12 * n                   # optimal; which of the two near-equal ones is open
@@ -272,6 +286,9 @@ def test_near_tie_beyond_the_dense_solvers_reach_raises_unless_accepted(dev, mon
         P.assign(U8, [0, n])
     lsa = P.assign(U8, [0, n], accept_near_ties=True)
     assert all(a is not None for a in lsa)
+    monkeypatch.setattr(L, "RESOLVE_MAX_BLOCK_ROWS", 4096)
+    lsa = P.assign(U8, [0, n])                                                        # settled: no flag needed
+    assert all(np.array_equal(a[1], cs) for a in lsa)
     # with the dense solver allowed again the same matrix takes SciPy's own algorithm: identical indices
     monkeypatch.undo()
     ih = {}

@@ -320,3 +320,41 @@ def test_fuzz_of_shapes_and_cost_distributions_against_scipy():
         r, c = scipy_lsa(U)
         assert np.array_equal(got[0], r) and np.array_equal(got[1], c), (it, n, m, kind, info)
     assert uncertified <= 3
+
+
+def test_near_ties_are_settled_on_their_blocks_by_the_dense_algorithm():
+    """lsap.resolve_near_ties (round 4): a certified optimum with alternatives inside the margin — here two engineered 2-cycles and
+    a 3-cycle, each worth +-1e-14 — is not refused: the rows each cycle connects are assigned by SciPy's algorithm on their own
+    block (2 x 2, 2 x 2, 3 x 3 entries fetched through M.entries) and spliced in.  The answer is SciPy's on the whole matrix."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(31)
+    n = 200
+    base = rng.random((n, n)) + 0.5
+    u, v, c = L.solve_core(HostMatrix(base))
+    for sign in (+1.0, -1.0):
+        U = base.copy()
+        for cyc in ((3, 77), (10, 150), (20, 60, 120)):
+            k = len(cyc)
+            for a in range(k):                               # row cyc[a] may take the column of cyc[a + 1]: an alternating cycle
+                i, j = cyc[a], c[cyc[(a + 1) % k]]
+                U[i, j] = (u[i] + v[j]) + sign * 1e-14 / k
+        M = HostMatrix(U)
+        info = {}
+        sol = L.solve_core(M, info)
+        assert not L.certify(M, *sol, info=info) and info["optimal"]
+        got = L.resolve_near_ties(M, sol, info)
+        assert got is not None and sorted(info["resolved_groups"]) == [2, 2, 3]
+        assert np.array_equal(got, scipy_lsa(U)[1]), sign
+    # spare columns (nr < nc): a 2-cycle among rows that hold columns is settled the same way — unless an alternative could also run
+    # through a column nobody holds (near-tight entries into one AND held columns priced like a free one), which is left alone
+    R = rng.random((40, 50)) + 0.5
+    u, v, c = L.solve_core(HostMatrix(R))
+    R2 = R.copy()
+    R2[7, c[21]] = (u[7] + v[c[21]]) - 0.5e-14
+    R2[21, c[7]] = (u[21] + v[c[7]]) - 0.5e-14
+    M = HostMatrix(R2)
+    info = {}
+    sol = L.solve_core(M, info)
+    assert not L.certify(M, *sol, info=info) and info["optimal"]
+    got = L.resolve_near_ties(M, sol, info)
+    assert got is None or (info["resolved_groups"] == [2] and np.array_equal(got, scipy_lsa(R2)[1]))
