@@ -274,8 +274,8 @@ def main():
 
     def step(marks=None):
         if marks: marks[0].record()
-        cm, mdm, x0m = P.cloud_statistics(be, mov, group)    # sharded: tile rows of the pair sum interleaved over ranks
-        cf, mdf, x0f = P.cloud_statistics(be, fix, group)
+        # one GPU: the two clouds' statistics on two streams; sharded: the pieces of the pair sum interleaved over the ranks
+        (cm, mdm, x0m), (cf, mdf, x0f) = P.statistics_of_both(be, mov, fix, group)
         if marks: marks[1].record()
         sc_m = be.shape_context(mov, cm, mdm, x0m, 2, r0, r1 - r0)
         sc_f = be.shape_context(fix, cf, mdf, x0f, 4, bm[rank], bm[rank + 1] - bm[rank])

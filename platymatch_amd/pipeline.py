@@ -322,6 +322,27 @@ def gather_fixed_descriptors(be, sc_m_loc, sc_f_loc, bounds, group=None):
 STATS_ON_TWO_STREAMS = True
 
 
+def statistics_of_both(be, mov, fix, group=None):
+    """cloud_statistics of the moving and of the fixed cloud -> ((centroid, mean distance, axis), (...)).  On one GPU the two
+    clouds' statistics — independent of each other — run on two streams: each cloud's serial pieces (the chain over the mean
+    distance's piece sums, ~0.8 ms at 50 000 points; the one-workgroup centroid and axis kernels) then run beside the other
+    cloud's wide launch instead of after it.  Sharded runs keep one stream (their collectives are ordered on it)."""
+    _, world = _world(group)
+    if world == 1 and getattr(mov, "is_cuda", False) and getattr(be, "device_sampler", False) and STATS_ON_TWO_STREAMS:
+        import torch
+        main = torch.cuda.current_stream(mov.device)
+        side = nat.side_stream(mov.device, ("statistics", main.cuda_stream))
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            sf = be.stats(fix)
+        sm = be.stats(mov)
+        main.wait_stream(side)
+        for t in sf:
+            t.record_stream(main)
+        return sm, sf
+    return cloud_statistics(be, mov, group), cloud_statistics(be, fix, group)
+
+
 def build_descriptors(be, mov, fix, group=None, guards=None):
     """Stages 526-545 of the widget: statistics and get_unary for both clouds.
     -> (sc_m [2, rows_g, 360], sc_f [4, M, 360] complete (or [1, M, 360], see gather_fixed_descriptors), moving row bounds).
@@ -330,23 +351,7 @@ def build_descriptors(be, mov, fix, group=None, guards=None):
     n, m = mov.shape[1], fix.shape[1]
     if world > min(n, m):        # every rank sees the same clouds: all raise, before the first collective
         raise ValueError("cannot shard %d x %d points over %d ranks: every rank needs at least one row of each cloud" % (n, m, world))
-    if world == 1 and getattr(mov, "is_cuda", False) and getattr(be, "device_sampler", False) and STATS_ON_TWO_STREAMS:
-        # the two clouds' statistics are independent: the fixed cloud's run on a side stream, so that each cloud's serial pieces
-        # (the chain over the mean distance's piece sums, ~0.8 ms at 50 000 points; the one-workgroup centroid and axis kernels)
-        # run beside the other cloud's wide launch instead of after it
-        import torch
-        main = torch.cuda.current_stream(mov.device)
-        side = nat.side_stream(mov.device, ("statistics", main.cuda_stream))
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            cf, mdf, x0f = be.stats(fix)
-        cm, mdm, x0m = be.stats(mov)
-        main.wait_stream(side)
-        for t in (cf, mdf, x0f):
-            t.record_stream(main)
-    else:
-        cm, mdm, x0m = cloud_statistics(be, mov, group)
-        cf, mdf, x0f = cloud_statistics(be, fix, group)
+    (cm, mdm, x0m), (cf, mdf, x0f) = statistics_of_both(be, mov, fix, group)
     bn, bm = shard_bounds(n, world), shard_bounds(m, world)
     if guards is not None and getattr(be, "device_sampler", False):       # (the GPU backend; test doubles have no guard)
         sc_m = be.shape_context(mov, cm, mdm, x0m, 2, bn[rank], bn[rank + 1] - bn[rank], guards=guards)
