@@ -347,6 +347,22 @@ def chi2_cost8_frame1_by_pairings(sc_m1, sc_f1, out=None):
     return out, events
 
 
+def chi2_cost_pair_into(sc_m1, sc_f1, pairing, out8):
+    """The exact matrices of pairing t (hypothesis PAIRINGS[t][0] and its twin) written INTO their places of an eight-matrix
+    buffer out8 [8, nM, nF] (pm_chi2_cost_pair_sym_ws with the twin's offset as matrix stride): what the relaxed mode falls back
+    to for a pairing whose relaxed matrices do not certify (lsap.solve_eight_on_device(exact_rebuild=...))."""
+    a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
+    nM, nF = a.shape[0], b.shape[0]
+    out8 = _out8(out8, nM, nF, a.device)
+    t = int(pairing)
+    h, twin = PAIRINGS[t]
+    lib = nat.load()
+    ws = _sym_workspace(lib, nM, nF, a.device)
+    check(lib.pm_chi2_cost_pair_sym_ws(ptr(a), nM, ptr(b), nF, t, ptr(out8[h]), out8.stride(1), (twin - h) * out8.stride(0), ptr(ws),
+                                       ws.numel(), nat.stream_ptr()))
+    return out8
+
+
 def chi2_cost_pair(sc_m, sc_f, pairing, symmetric, out=None):
     """The two cost matrices of pairing t (PAIRINGS[t]: U11/U22, U12/U21, U13/U24, U14/U23) alone -> [2, nM, nF]: what a cloud
     whose eight matrices do not fit in HBM together is assigned from, two at a time.  symmetric (the frame-permutation

@@ -51,6 +51,35 @@ def get_affine_transform(moving, fixed, with_ones=False):
     return nat.like_input(A, moving)
 
 
+def _quaternion_matrix(Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz):
+    """The symmetric 4 x 4 matrix N of Horn's method exactly as the reference writes it (find_transform.py:55-58), from scalars
+    or from arrays of T fits at once (rows as tuples: the caller stacks them)."""
+    return [[Sxx + Syy + Szz, Syz - Szy, -Sxz + Szx, Sxy - Syx],
+            [-Szy + Syz, Sxx - Szz - Syy, Sxy + Syx, Sxz + Szx],
+            [Szx - Sxz, Syx + Sxy, Syy - Szz - Sxx, Syz + Szy],
+            [-Syx + Sxy, Szx + Sxz, Szy + Syz, Szz - Syy - Sxx]]
+
+
+def _rotation_from_one_N(N):
+    """One 4 x 4 quaternion matrix -> R the reference's way (find_transform.py:60-84): np.linalg.eig, eigenvectors sorted by
+    decreasing eigenvalue, q = ROW 0 of that matrix (the reference's quirk), R = (Qbar^T Q)[1:, 1:] by np.matmul."""
+    w, V = np.linalg.eig(N)
+    V = V[:, w.argsort()[::-1]]
+    q0, q1, q2, q3 = V[0]                                      # row 0, as the reference has it
+    Qbar = [[q0, -q1, -q2, -q3], [q1, q0, q3, -q2], [q2, -q3, q0, q1], [q3, q2, -q1, q0]]
+    Q = [[q0, -q1, -q2, -q3], [q1, q0, -q3, q2], [q2, q3, q0, -q1], [q3, -q2, q1, q0]]
+    return np.matmul(np.transpose(Qbar), Q)[1:, 1:]
+
+
+def _similar_4x4(R, sc, cs, ct):
+    """[s R | ct - s R cs; 0 0 0 1] (find_transform.py:94-99); cs, ct 3 x 1."""
+    A = np.zeros((4, 4))
+    A[:3, :3] = sc * R
+    A[:3, 3:4] = ct - sc * np.matmul(R, cs)
+    A[3, 3] = 1
+    return A
+
+
 def _rotation_from_N(N):
     """[T, 4, 4] quaternion matrices -> [T, 3, 3] rotations the reference's way (:60-84): eigenvectors sorted by
     decreasing eigenvalue, q = ROW 0 of that matrix, R = (Qbar^T Q)[1:, 1:]."""
@@ -125,10 +154,8 @@ def similar_fit_batch(P, Y):
     Syx, Syy, Syz = S(Py * Yx), S(Py * Yy), S(Py * Yz)
     Szx, Szy, Szz = S(Pz * Yx), S(Pz * Yy), S(Pz * Yz)
     N = np.empty((T, 4, 4))
-    N[:, 0] = np.stack([Sxx + Syy + Szz, Syz - Szy, -Sxz + Szx, Sxy - Syx], axis=1)                 # :55-58
-    N[:, 1] = np.stack([-Szy + Syz, Sxx - Szz - Syy, Sxy + Syx, Sxz + Szx], axis=1)
-    N[:, 2] = np.stack([Szx - Sxz, Syx + Sxy, Syy - Szz - Sxx, Syz + Szy], axis=1)
-    N[:, 3] = np.stack([-Syx + Sxy, Szx + Sxz, Szy + Syz, Szz - Syy - Sxx], axis=1)
+    for row, entries in enumerate(_quaternion_matrix(Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz)):    # :55-58
+        N[:, row] = np.stack(entries, axis=1)
     R = _rotation_from_N(N)
     D = np.zeros(T)
     Sp = np.zeros(T)
@@ -164,27 +191,12 @@ def similar_transform_host(moving, fixed):
     Sxx, Sxy, Sxz = np.sum(Yx * Px), np.sum(Px * Yy), np.sum(Px * Yz)
     Syx, Syy, Syz = np.sum(Py * Yx), np.sum(Py * Yy), np.sum(Py * Yz)
     Szx, Szy, Szz = np.sum(Pz * Yx), np.sum(Pz * Yy), np.sum(Pz * Yz)
-    N = [[Sxx + Syy + Szz, Syz - Szy, -Sxz + Szx, Sxy - Syx],
-         [-Szy + Syz, Sxx - Szz - Syy, Sxy + Syx, Sxz + Szx],
-         [Szx - Sxz, Syx + Sxy, Syy - Szz - Sxx, Syz + Szy],
-         [-Syx + Sxy, Szx + Sxz, Szy + Syz, Szz - Syy - Sxx]]
-    w, V = np.linalg.eig(N)
-    V = V[:, w.argsort()[::-1]]
-    q0, q1, q2, q3 = V[0]                                      # row 0, as the reference has it
-    Qbar = [[q0, -q1, -q2, -q3], [q1, q0, q3, -q2], [q2, -q3, q0, q1], [q3, q2, -q1, q0]]
-    Q = [[q0, -q1, -q2, -q3], [q1, q0, -q3, q2], [q2, q3, q0, -q1], [q3, -q2, q1, q0]]
-    R = np.matmul(np.transpose(Qbar), Q)[1:, 1:]
+    R = _rotation_from_one_N(_quaternion_matrix(Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz))
     D = Sp = 0
     for i in range(Y.shape[1]):                                # :86-91
         D += np.matmul(np.transpose(Y[:, i]), Y[:, i])
         Sp += np.matmul(np.transpose(P[:, i]), P[:, i])
-    sc = np.sqrt(D / Sp)
-    t = ct[:3, :] - sc * np.matmul(R, cs[:3, :])
-    A = np.zeros((4, 4))
-    A[:3, :3] = sc * R
-    A[:3, 3:4] = t
-    A[3, 3] = 1
-    return A
+    return _similar_4x4(R, np.sqrt(D / Sp), cs[:3, :], ct[:3, :])
 
 
 def similar_from_moments(v):
@@ -194,34 +206,14 @@ def similar_from_moments(v):
     Only these lines of get_similar_transform run on the host (the eigenvector-row quirk forces LAPACK: DESIGN.md §2)."""
     v = np.asarray(v, dtype=np.float64)
     cs, ct = v[0:3].reshape(3, 1), v[3:6].reshape(3, 1)
-    Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz = (v[k] for k in range(6, 15))
-    N = [[Sxx + Syy + Szz, Syz - Szy, -Sxz + Szx, Sxy - Syx],
-         [-Szy + Syz, Sxx - Szz - Syy, Sxy + Syx, Sxz + Szx],
-         [Szx - Sxz, Syx + Sxy, Syy - Szz - Sxx, Syz + Szy],
-         [-Syx + Sxy, Szx + Sxz, Szy + Syz, Szz - Syy - Sxx]]
-    w, V = np.linalg.eig(N)
-    V = V[:, w.argsort()[::-1]]
-    q0, q1, q2, q3 = V[0]                                      # row 0, as the reference has it
-    Qbar = [[q0, -q1, -q2, -q3], [q1, q0, q3, -q2], [q2, -q3, q0, q1], [q3, q2, -q1, q0]]
-    Q = [[q0, -q1, -q2, -q3], [q1, q0, -q3, q2], [q2, q3, q0, -q1], [q3, -q2, q1, q0]]
-    R = np.matmul(np.transpose(Qbar), Q)[1:, 1:]
-    sc = np.sqrt(v[15] / v[16])
-    t = ct - sc * np.matmul(R, cs)
-    A = np.zeros((4, 4))
-    A[:3, :3] = sc * R
-    A[:3, 3:4] = t
-    A[3, 3] = 1
-    return A
+    R = _rotation_from_one_N(_quaternion_matrix(*(v[k] for k in range(6, 15))))
+    return _similar_4x4(R, np.sqrt(v[15] / v[16]), cs, ct)
 
 
 def quaternion_matrix_from_moments(v):
     """The 4 x 4 matrix N of find_transform.py:55-58 alone (tests compare it with the oracle's bit for bit)."""
     v = np.asarray(v, dtype=np.float64)
-    Sxx, Sxy, Sxz, Syx, Syy, Syz, Szx, Szy, Szz = (v[k] for k in range(6, 15))
-    return np.array([[Sxx + Syy + Szz, Syz - Szy, -Sxz + Szx, Sxy - Syx],
-                     [-Szy + Syz, Sxx - Szz - Syy, Sxy + Syx, Sxz + Szx],
-                     [Szx - Sxz, Syx + Sxy, Syy - Szz - Sxx, Syz + Szy],
-                     [-Syx + Sxy, Szx + Sxz, Szy + Syz, Szz - Syy - Sxx]])
+    return np.array(_quaternion_matrix(*(v[k] for k in range(6, 15))))
 
 
 def apply_affine_host(moving, A):

@@ -263,7 +263,7 @@ def certify(M, u, v, col4row, info=None, min_eps=0.0):
     lib = nat.load()
     nr, nc = M.shape
     scale = max(float(np.abs(u).max()), float(np.abs(v).max()), 1e-300)
-    delta, eps_collect = REL_DELTA * scale, REL_EPS_COLLECT * scale
+    delta, eps_collect = REL_DELTA * scale, max(REL_EPS_COLLECT * scale, 4.0 * float(min_eps))
     cap = 8 * nc + 1024
     viol, loose, tight, red, bound = M.certificate(u, v, col4row, delta, eps_collect, cap)
     # How wide must the margin be?  Any other assignment costs at least (the reduced costs of its new entries) - bound more than
@@ -646,7 +646,7 @@ def _resolved(W, sol, info, out, slot, n, m):
 PIPELINED_PRIORITY = -1
 
 
-def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False, ready=None, min_eps=0.0):
+def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False, ready=None, min_eps=0.0, exact_rebuild=None):
     """The widget's eight assignments (_dock_widget.py:604-611) for U8 [8, N, M] on the GPU: hypotheses 11, 12, 13, 14 are
     solved (four host threads drive their core solves and kernels concurrently), each together with its twin (22, 21, 24,
     23: solve_pair_on_device).  -> list of eight (row_ind, col_ind).
@@ -684,7 +684,26 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
         with torch.cuda.device(U8.device), torch.cuda.stream(stream):
             if ready is not None:
                 stream.wait_event(ready[h])
-            out[h], out[twin] = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], allow_host, accept_near_ties, min_eps)
+            if exact_rebuild is None:
+                out[h], out[twin] = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], allow_host, accept_near_ties, min_eps)
+            else:
+                # RELAXED matrices (pm_chi2_cost8_relaxed: every entry within delta of the exact cost, min_eps = 2 min(N, M) delta):
+                # an answer counts only if it is a certified UNIQUE optimum with that margin — then it is the exact matrix's too.
+                # Anything else (a near-tie inside the margin, ties, non-finite costs) has this pairing's two matrices rebuilt by
+                # the exact kernel, in place, and solved as usual.
+                got = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], False, False, min_eps)
+                ok = all(g is not None and i.get("route") in ("device", "device (sibling's duals certified)") for g, i in zip(got, (infos[h], infos[twin])))
+                if ok:
+                    for i in (infos[h], infos[twin]):
+                        i["cost_mode"] = "relaxed (certified with margin %.1e)" % min_eps
+                else:
+                    infos[h].clear()
+                    infos[twin].clear()
+                    exact_rebuild(h)
+                    got = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], allow_host, accept_near_ties)
+                    for i in (infos[h], infos[twin]):
+                        i["cost_mode"] = "exact (rebuilt: the relaxed matrices did not certify)"
+                out[h], out[twin] = got
             stream.synchronize()
 
     if ready is None:

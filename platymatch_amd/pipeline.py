@@ -94,6 +94,9 @@ def release_cost_buffers():
             del _COST_CACHE[key]
 
 
+RELAXED_VARIANT = 2            # pm_chi2_cost8_relaxed: 0 all computed, 1 94 x 94 term table, 2 64 x 64 table at three waves per SIMD (fastest at 50k)
+
+
 class EdgeGuardWarning(UserWarning):
     """estimate_transform met neighbours that sit on a bin boundary of the shape context within the reference's own rounding
     noise: the integer histograms are then not defined by the reference's source alone."""
@@ -140,6 +143,13 @@ class GpuBackend:
         if sc_f.shape[0] == 1:            # frame 1 only: gather_fixed_descriptors verified the permutation relation
             return self.K.chi2_cost8_frame1(sc_m[0], sc_f[0], out=out)
         return self.K.chi2_cost8(sc_m, sc_f, out=out)
+
+    def chi2_cost8_relaxed(self, sc_m, sc_f, out=None):
+        """Opt-in experiment: the eight matrices in relaxed float64 arithmetic (K.chi2_cost8_relaxed) — only where the
+        frame-permutation relation holds; -> (U, delta) or None if it does not (the caller builds exactly)."""
+        if sc_f.shape[0] != 1 and not self.K.chi2_symmetric(sc_m, sc_f):
+            return None
+        return self.K.chi2_cost8_relaxed(sc_m[0], sc_f[0], out=out, variant=RELAXED_VARIANT), self.K.chi2_relaxed_delta()
 
     def chi2_cost_pair(self, sc_m, sc_f, pairing, out=None):
         """The two matrices of one pairing (hypothesis + twin) only -> [2, rows, M]; symmetric iff sc_f holds frame 1 only or
@@ -320,6 +330,7 @@ def gather_fixed_descriptors(be, sc_m_loc, sc_f_loc, bounds, group=None):
 
 
 STATS_ON_TWO_STREAMS = True
+RELAXED_MIN_POINTS = 1024      # cost_mode='relaxed' below this: exact (the dense host solver takes such matrices, no certificate to lean on)
 
 
 def statistics_of_both(be, mov, fix, group=None):
@@ -766,7 +777,7 @@ def _shared_device_seed(group, device):
 def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
                        ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, group=None,
                        backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS, private_rng=False, stream_hypotheses=None,
-                       accept_near_ties=False, sampler='auto', icp_one_launch=None, keep_cost_buffer=True):
+                       accept_near_ties=False, sampler='auto', icp_one_launch=None, keep_cost_buffer=True, cost_mode='exact'):
     """Reproduces _dock_widget.py:526-718 -> (A_sc, A_icp, inliers[8]); final transform = A_icp @ A_sc (:428).
 
     moving, fixed   3 x N / 3 x M float64 (rows z, y, x), NumPy or torch
@@ -794,6 +805,12 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     keep_cost_buffer  large registrations (eight matrices >= 8 GiB) write their cost matrices into a buffer this module keeps per
                     (device, stream) between calls (see COST_CACHE_MIN_BYTES above; release_cost_buffers() frees it); False: a fresh
                     allocation per call, returned to torch's allocator afterwards
+    cost_mode       'exact' (default): the eight cost matrices bit-identical to the reference's scalar loop.  'relaxed' (opt-in
+                    experiment, one GPU, clouds of >= 1 024 points): built in relaxed float64 arithmetic (1.3-1.55x faster at
+                    50 000; every entry within 2e-13 of the exact cost) and used ONLY through a uniqueness certificate whose
+                    margin covers that error (2 min(N, M) delta): certified assignments are the exact matrices' by proof; a
+                    pairing that does not certify is rebuilt exactly and solved as usual — same assignment vectors either
+                    way, details['assignment']['details'][h]['cost_mode'] says which route each hypothesis took
     icp_one_launch  None: perform_icp.ONE_LAUNCH decides (default False: one launch per iteration); True: iterations 1 .. n-1 of the
                     Affine ICP loop in one launch of persistent workgroups (only for a device that does nothing else meanwhile;
                     estimate_transform_batch always passes False: its workers keep several streams busy) — identical results
@@ -820,6 +837,8 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     t0 = time.perf_counter()
     if sampler not in ('auto', 'numpy', 'device'):
         raise ValueError("sampler must be 'auto', 'numpy' or 'device'")
+    if cost_mode not in ('exact', 'relaxed'):
+        raise ValueError("cost_mode must be 'exact' or 'relaxed'")
     on_device = (sampler == 'device' or (sampler == 'auto' and seed is None)) and getattr(be, "device_sampler", False) \
         and int(ransac_samples) <= min(mov.shape[1], fix.shape[1])
     if mode == 'unsupervised':
@@ -828,7 +847,7 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         draws = _SampleDraws(be, min(mov.shape[1], fix.shape[1]), int(ransac_samples), 0 if on_device else int(ransac_trials),
                              seed, private_rng)
         a_info = None if details is None else details.setdefault("assignment", {})
-        lease = None
+        lease = relaxed = None
         try:
             guards = [] if getattr(be, "device_sampler", False) else None     # (the GPU backend: its descriptor launches count)
             sc_m, sc_f, bn = build_descriptors(be, mov, fix, group, guards=guards)
@@ -846,7 +865,13 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             else:
                 if keep_cost_buffer and mov.is_cuda and need >= COST_CACHE_MIN_BYTES and world == 1:
                     lease = cost_buffer(mov.device, (8, sc_m.shape[1], sc_f.shape[1]))     # None: another registration holds it
-                U = be.chi2_cost8(sc_m, sc_f, out=None if lease is None else lease.view)
+                if (cost_mode == 'relaxed' and world == 1 and mov.is_cuda and hasattr(be, "chi2_cost8_relaxed")
+                        and min(mov.shape[1], fix.shape[1]) >= RELAXED_MIN_POINTS):
+                    relaxed = be.chi2_cost8_relaxed(sc_m, sc_f, out=None if lease is None else lease.view)
+                if relaxed is not None:
+                    U, relaxed_delta = relaxed
+                else:
+                    U = be.chi2_cost8(sc_m, sc_f, out=None if lease is None else lease.view)
         except BaseException:
             draws.thread.join()
             if lease is not None:
@@ -857,6 +882,15 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             if streamed:
                 lsa = assign_streamed(be, sc_m, sc_f, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None),
                                       accept_near_ties=accept_near_ties)
+            elif relaxed is not None:
+                from .lsap import solve_eight_on_device
+                from ._kernels import PAIRINGS
+                sc_m1, sc_f1 = sc_m[0], sc_f[0]
+                lsa = solve_eight_on_device(U, info=a_info, accept_near_ties=accept_near_ties,
+                                            min_eps=2.0 * min(mov.shape[1], fix.shape[1]) * relaxed_delta,
+                                            exact_rebuild=lambda h: be.K.chi2_cost_pair_into(sc_m1, sc_f1, [p[0] for p in PAIRINGS].index(h), U))
+                if any(a is None for a in lsa):
+                    raise RuntimeError("a hypothesis could not be assigned (see accept_near_ties)")
             else:
                 lsa = assign(U, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None), accept_near_ties=accept_near_ties)
         finally:
