@@ -1024,7 +1024,7 @@ int icp_iteration(bool first, double *mov, int n, const double *fix, int m, cons
     // first iteration: nothing bounds the search, 32 lanes per point walk the rings; afterwards the previous match does
     // and 8 or 4 lanes per point (4 or 8 leaves per workgroup) are plenty for the few cells left
     if (first) icp_iter_kernel<GR_LANES, true><<<(n + 256 / GR_LANES - 1) / (256 / GR_LANES), 256, 0, s>>>(a);
-#ifdef PM_GR_TRY_LANES      // (tuning builds: tools/scripts)
+#ifdef PM_GR_TRY_LANES      // (tuning builds: PM_EXTRA_DEFINES, tools/icp_stamps.py)
     else if (n >= GR_ITER_FEW_LANES_FROM) icp_iter_kernel<PM_GR_TRY_LANES, false><<<(n + 256 / PM_GR_TRY_LANES - 1) / (256 / PM_GR_TRY_LANES), 256, 0, s>>>(a);
 #else
     else if (n >= GR_ITER_FEW_LANES_FROM) icp_iter_kernel<4, false><<<(n + 63) / 64, 256, 0, s>>>(a);

@@ -211,3 +211,24 @@ def test_similar_mode_and_small_sample_counts_draw_on_the_device_too(K):
     finally:
         sc.SAMPLER = "numpy"
     assert a[1] == b[1] == mv.shape[1] and np.array_equal(a[0], b[0])
+
+
+def test_a_caller_who_seeds_numpy_itself_gets_the_references_sets_with_sampler_numpy(K):
+    """the only way to seed the reference is np.random.seed(s) before its eight do_ransac calls (it draws from NumPy's
+    global generator, shape_context.py:122).  estimate_transform(seed=None) with the default sampler='auto' draws on the device and
+    does NOT follow that stream (documented: README, INTEGRATION); with sampler='numpy' it does — the same index sets, inlier counts
+    and A_sc as estimate_transform(seed=s), i.e. the reference's — and leaves the global generator where the reference would."""
+    from platymatch_amd import pipeline as P
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    mv, fx, _ = synth_pair(700, 31)
+    kw = dict(ransac_trials=150, icp_iterations=3)
+    want = P.estimate_transform(mv, fx, seed=1234, **kw)
+    state_after_seeded = np.random.get_state()[1].copy()
+    np.random.seed(1234)
+    got = P.estimate_transform(mv, fx, seed=None, sampler='numpy', **kw)
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(np.random.get_state()[1], state_after_seeded)         # consumed exactly like the seeded call
+    np.random.seed(1234)
+    auto = P.estimate_transform(mv, fx, seed=None, **kw)                        # 'auto' without a seed: the device sampler
+    assert auto[2].sum() > 0 and np.isfinite(np.asarray(auto[1])).all()
