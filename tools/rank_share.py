@@ -71,7 +71,9 @@ def bench_share(n, G, icp_iters=200):
             part = be.mean_distance_partials(x, 0, G)
             st[id(x)] = (c, be.mean_distance_finish(part, n), a)
     t_stats = timed(stats)
-    (cm, mdm, x0m), (cf, mdf, x0f) = st[id(mov)], st[id(fix)]
+    # (what was timed holds only this rank's pieces of the pair sums — the all-reduce is not executed here —, so the values the
+    # later stages work with are taken from the one-GPU kernels: identical to what the all-reduce + finish would deliver)
+    (cm, mdm, x0m), (cf, mdf, x0f) = be.stats(mov), be.stats(fix)
     sc = {}
 
     def desc():
@@ -104,7 +106,7 @@ def c4_share(n=200_000, G=8, slab=4096):
             c, a = be.centroid_and_axis(x)
             st[id(x)] = (c, be.mean_distance_finish(be.mean_distance_partials(x, 0, G), n), a)
     t_stats = timed(stats, reps=1)
-    (cm, mdm, x0m), (cf, mdf, x0f) = st[id(mov)], st[id(fix)]
+    (cm, mdm, x0m), (cf, mdf, x0f) = be.stats(mov), be.stats(fix)          # (the true values: see bench_share)
     sc = {}
 
     def desc():
