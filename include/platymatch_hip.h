@@ -299,6 +299,43 @@ int pm_lsap_core_solve(void *core);
 int pm_lsap_core_reprice(void *core, int k, const int32_t *cand_col, const double *cand_cost, double delta, int *n_violated);
 int pm_lsap_core_get(void *core, double *u, double *v, int32_t *col4row, long *stats4);
 
+/* DEVICE: out[r] = U[r][col0 + r] for r < min(nr, nc - col0): the diagonal entries of a row block that starts at matrix row col0
+ * (the safety edges of the core: with them it always holds a perfect matching). */
+int pm_lsap_diagonal(const double *U, int nr, int nc, size_t ld, int col0, double *out, void *stream);
+
+/* HOST + DEVICE (round 4): the whole scheme above for ONE resident matrix in one call — column reduction, core selection,
+ * eps-scaling auctions with pricing in between, shortest augmenting paths, pricing rounds until no entry of U violates dual
+ * feasibility (pm_lsap_solve_resident: platymatch_amd/lsap.py's solve_core), and the certificate with its uniqueness check
+ * (pm_lsap_certify_resident: lsap.certify) — as native host code around the kernels and the core solver declared here: one
+ * foreign call per hypothesis instead of ~60, no interpreter lock shared by the hypotheses' threads.  U: device, nr <= nc (the
+ * caller transposes otherwise); u [nr], v [nc], col4row [nr], tight_out: HOST; dev_ws: pm_lsap_resident_workspace bytes of device
+ * memory, 256-byte aligned; blocks until the result is on the host (it synchronises `stream` several times); staging goes
+ * through a pinned host buffer owned by the calling thread (grown on demand, freed with the thread).
+ * report.status: 0 solved (duals feasible on every entry of U), 2 pricing did not converge, 3 non-finite entries, 4 infeasible.
+ * certify: report.optimal / report.unique as lsap.certify's info; tight_out (may be NULL) receives the (row, col) pairs of the
+ * non-matching entries within eps of tight (report.n_tight of them; -1 if more than tight_capacity). */
+typedef struct pm_lsap_options {
+    int core_edges, price_edges, max_pricing_rounds, column_reduction;
+    double rel_delta, rel_eps_collect, rel_eps_floor, eps_safety;
+    int auction, a_rounds, a_bids_per_row, a_later_bids_per_row;
+    double a_eps0, a_eps_min, a_factor, a_later_eps0, a_stop_below, a_max_free_columns;
+    double min_eps;
+} pm_lsap_options;
+typedef struct pm_lsap_report {
+    int status, rounds, violations, loose, tight_within_eps, n_tight, optimal, unique, n_auction_violated, pad_;
+    long bids, steps, augmentations, edges;
+    double slack_bound, delta, eps, seconds_total, seconds_auction, seconds_core, seconds_device, seconds_certify;
+    int auction_violated[8];
+    int violated_per_round[32];
+} pm_lsap_report;
+void pm_lsap_default_options(pm_lsap_options *options);
+size_t pm_lsap_resident_workspace(int nr, int nc);
+int pm_lsap_solve_resident(const double *U, int nr, int nc, size_t ld, const pm_lsap_options *options, double *u, double *v,
+                           int32_t *col4row, pm_lsap_report *report, void *dev_ws, size_t dev_ws_bytes, void *stream);
+int pm_lsap_certify_resident(const double *U, int nr, int nc, size_t ld, const pm_lsap_options *options, const double *u,
+                             const double *v, const int32_t *col4row, int32_t *tight_out, int tight_capacity,
+                             pm_lsap_report *report, void *dev_ws, size_t dev_ws_bytes, void *stream);
+
 /* HOST: 1 if the entries listed by pm_lsap_certificate (tight [n_tight][2]) admit no alternating cycle — and, for
  * nr < nc, no alternating path between a free column and a column whose dual is within eps of v_free_level (the dual the
  * free columns carry) — i.e. the certified optimum is unique with margin eps; 0 if an alternative exists. */

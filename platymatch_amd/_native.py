@@ -52,6 +52,13 @@ SIGNATURES = {
     "pm_transpose_f64": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_size_t, _c_void_p]),
     "pm_lsap_core_auction": (_c_int, [_c_void_p, _c_double, _c_double, _c_double, ctypes.c_long, _c_void_p]),
     "pm_lsap_core_auction_resume": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_double, _c_double, _c_double, ctypes.c_long, _c_void_p]),
+    "pm_lsap_diagonal": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_int, _c_void_p, _c_void_p]),
+    "pm_lsap_default_options": (None, [_c_void_p]),
+    "pm_lsap_resident_workspace": (_c_size_t, [_c_int, _c_int]),
+    "pm_lsap_solve_resident": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                        _c_void_p, _c_size_t, _c_void_p]),
+    "pm_lsap_certify_resident": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                          _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_lsap_core_reprice": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_double, _c_void_p]),
     "pm_lsap_core_get": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "pm_lsap_unique": (_c_int, [_c_int, _c_int, _c_void_p, _c_void_p, _c_double, _c_double, _c_void_p, _c_int]),

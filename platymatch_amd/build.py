@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libplatymatch_hip.so")
 SOURCES = ["pm_api.hip", "pm_stats.hip", "pm_shape_context.hip", "pm_chi2.hip", "pm_transform.hip",
-           "pm_icp.hip", "pm_icp_grid.hip", "pm_similar.hip", "pm_ransac.hip", "pm_eval.hip", "pm_lsap_dev.hip", "pm_lsap.cpp", "pm_lsap_core.cpp",
+           "pm_icp.hip", "pm_icp_grid.hip", "pm_similar.hip", "pm_ransac.hip", "pm_eval.hip", "pm_lsap_dev.hip", "pm_lsap_resident.hip", "pm_lsap.cpp", "pm_lsap_core.cpp",
            "pm_host_rng.cpp"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-ffp-contract=off", "-fno-fast-math",

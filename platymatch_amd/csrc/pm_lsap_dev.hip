@@ -6,6 +6,7 @@
 //                       and, with the solver's column duals, the PRICING step (which entries violate dual feasibility);
 //   certificate_kernel  the optimality certificate of a finished solve against every entry of the matrix, plus the list of
 //                       entries within eps of tight that decides uniqueness (pm_lsap_unique).
+#include <algorithm>
 #include "pm_common.h"
 
 namespace pm {
@@ -216,6 +217,12 @@ __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *_
 }
 
 
+// out[r] = U[r][col0 + r]: the entries a block of rows starting at global row col0 contributes to the matrix's diagonal
+__global__ __launch_bounds__(256) void diagonal_kernel(const double *__restrict__ U, int n, size_t ld, int col0, double *__restrict__ out) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n) out[r] = U[(size_t)r * ld + col0 + r];
+}
+
 // dst[j][i] = src[i][j]: 64 x 64 tiles through LDS (pitch 65: the column-wise reads of the tile hit distinct banks), both
 // sides coalesced.  The solver wants the short side of a matrix as rows (SciPy transposes likewise); with more moving than
 // fixed nuclei that is the transpose of what the cost kernel writes.
@@ -284,6 +291,14 @@ int pm_lsap_certificate(const double *U, int nr, int nc, size_t ld, const double
     if (hipMemsetAsync(stats2, 0, 2 * sizeof(double), s) != hipSuccess) return pm::launch_status();
     pm::certificate_kernel<<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, u, v, col4row, delta, eps, summary4, (unsigned long long *)stats2,
                                                           tight, tight_red, cap, row_slack, row_neg);
+    return pm::launch_status();
+}
+
+int pm_lsap_diagonal(const double *U, int nr, int nc, size_t ld, int col0, double *out, void *stream) {
+    if (!U || !out || nr <= 0 || nc <= 0 || ld < (size_t)nc || col0 < 0) return PM_ERR_INVALID_ARG;
+    const int n = std::min(nr, nc - col0);
+    if (n <= 0) return PM_OK;
+    pm::diagonal_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(U, n, ld, col0, out);
     return pm::launch_status();
 }
 

@@ -5,6 +5,7 @@ keeps the GIL, so those solves cannot overlap.  pm_lsap_solve restates SciPy 1.1
 (identical indices, ties included — tests/test_lsap.py checks it against SciPy itself) and is called through ctypes,
 which releases the GIL: `solve_many` runs the eight solves on eight host threads.  Host code only; nothing here runs on
 the GPU."""
+import ctypes
 import os
 from concurrent.futures import ThreadPoolExecutor
 
@@ -260,6 +261,8 @@ def certify(M, u, v, col4row, info=None, min_eps=0.0):
     min_eps (absolute): a wider uniqueness margin demanded by the caller — the relaxed cost build (pm_chi2_cost8_relaxed) asks for
     2 min(N, M) delta, delta its per-entry error bound: an optimum of the relaxed matrix that beats every alternative by more
     than that is the exact matrix's unique optimum too."""
+    if _native_ok(M):
+        return certify_native(M, u, v, col4row, info, min_eps)
     lib = nat.load()
     nr, nc = M.shape
     scale = max(float(np.abs(u).max()), float(np.abs(v).max()), 1e-300)
@@ -458,9 +461,113 @@ def _row_reduction(M, v, rounds):
     return u, v, col4row
 
 
+# ---- the native driver (csrc/pm_lsap_resident.hip): the same sequence as solve_core / certify below in one foreign call each --------
+NATIVE_DRIVER = os.environ.get("PM_LSAP_NATIVE", "1") != "0"
+
+
+class _Options(ctypes.Structure):
+    _fields_ = [("core_edges", ctypes.c_int), ("price_edges", ctypes.c_int), ("max_pricing_rounds", ctypes.c_int), ("column_reduction", ctypes.c_int),
+                ("rel_delta", ctypes.c_double), ("rel_eps_collect", ctypes.c_double), ("rel_eps_floor", ctypes.c_double), ("eps_safety", ctypes.c_double),
+                ("auction", ctypes.c_int), ("a_rounds", ctypes.c_int), ("a_bids_per_row", ctypes.c_int), ("a_later_bids_per_row", ctypes.c_int),
+                ("a_eps0", ctypes.c_double), ("a_eps_min", ctypes.c_double), ("a_factor", ctypes.c_double), ("a_later_eps0", ctypes.c_double),
+                ("a_stop_below", ctypes.c_double), ("a_max_free_columns", ctypes.c_double), ("min_eps", ctypes.c_double)]
+
+
+class _Report(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int), ("rounds", ctypes.c_int), ("violations", ctypes.c_int), ("loose", ctypes.c_int),
+                ("tight_within_eps", ctypes.c_int), ("n_tight", ctypes.c_int), ("optimal", ctypes.c_int), ("unique", ctypes.c_int),
+                ("n_auction_violated", ctypes.c_int), ("pad_", ctypes.c_int),
+                ("bids", ctypes.c_long), ("steps", ctypes.c_long), ("augmentations", ctypes.c_long), ("edges", ctypes.c_long),
+                ("slack_bound", ctypes.c_double), ("delta", ctypes.c_double), ("eps", ctypes.c_double), ("seconds_total", ctypes.c_double),
+                ("seconds_auction", ctypes.c_double), ("seconds_core", ctypes.c_double), ("seconds_device", ctypes.c_double),
+                ("seconds_certify", ctypes.c_double), ("auction_violated", ctypes.c_int * 8), ("violated_per_round", ctypes.c_int * 32)]
+
+
+def _native_options(min_eps=0.0):
+    """This module's settings (CORE_EDGES_PER_ROW ... AUCTION) as the native driver's option record."""
+    o = _Options()
+    o.core_edges, o.price_edges, o.max_pricing_rounds = min(CORE_EDGES_PER_ROW, 256), min(PRICE_EDGES_PER_ROW, 256), MAX_PRICING_ROUNDS
+    o.column_reduction = int(bool(COLUMN_REDUCTION))
+    o.rel_delta, o.rel_eps_collect, o.rel_eps_floor, o.eps_safety = REL_DELTA, REL_EPS_COLLECT, REL_EPS_FLOOR, EPS_SAFETY
+    a = AUCTION
+    o.auction = int(a is not None)
+    if a is not None:
+        o.a_rounds, o.a_bids_per_row, o.a_later_bids_per_row = int(a["rounds"]), int(a["bids_per_row"]), int(a["later_bids_per_row"])
+        o.a_eps0, o.a_eps_min, o.a_factor, o.a_later_eps0 = a["eps0"], a["eps_min"], a["factor"], a["later_eps0"]
+        o.a_stop_below, o.a_max_free_columns = a["stop_below"], a["max_free_columns"]
+    o.min_eps = float(min_eps)
+    return o
+
+
+def _native_ok(M):
+    """The native driver takes a DeviceMatrix with this module's stock flow (no row-reduction warm start, <= 64 candidates per row)."""
+    return (NATIVE_DRIVER and isinstance(M, DeviceMatrix) and ROW_REDUCTION_ROUNDS == 0 and CORE_EDGES_PER_ROW <= 64
+            and PRICE_EDGES_PER_ROW <= 64)
+
+
+def _native_ws(M):
+    torch = nat.torch_mod()
+    nr, nc = M.shape
+    ws = getattr(M, "_resident_ws", None)
+    need = int(nat.load().pm_lsap_resident_workspace(nr, nc))
+    if ws is None or ws.numel() < need:
+        ws = M._resident_ws = torch.empty(need, dtype=torch.uint8, device=M.U.device)
+    return ws
+
+
+def solve_core_native(M, info=None):
+    """solve_core for a DeviceMatrix by ONE foreign call (pm_lsap_solve_resident: the interpreter lock is released for the whole
+    solve) -> (u, v, col4row) or None, as solve_core."""
+    nr, nc = M.shape
+    lib = nat.load()
+    ws = _native_ws(M)
+    u, v, c4r = np.empty(nr), np.empty(nc), np.empty(nr, dtype=np.int32)
+    opt, rep = _native_options(), _Report()
+    rc = lib.pm_lsap_solve_resident(nat.ptr(M.U), nr, nc, M.ld, ctypes.addressof(opt), u.ctypes.data, v.ctypes.data, c4r.ctypes.data,
+                                    ctypes.addressof(rep), nat.ptr(ws), ws.numel(), nat.stream_ptr(M.U))
+    nat.check(rc)
+    if info is not None:
+        info.update(driver="native", rounds=rep.rounds, edges=rep.edges, steps=rep.steps, augmentations=rep.augmentations,
+                    auction_bids=rep.bids, auction_seconds=rep.seconds_auction, core_seconds=rep.seconds_core,
+                    device_seconds=rep.seconds_device, solve_seconds=rep.seconds_total,
+                    violated_per_round=list(rep.violated_per_round[:min(rep.rounds, 32)]),
+                    auction_violated=list(rep.auction_violated[:rep.n_auction_violated]))
+    if rep.status == 4:
+        raise ValueError("cost matrix is infeasible")
+    if rep.status != 0:
+        return None
+    return u, v, c4r
+
+
+def certify_native(M, u, v, col4row, info=None, min_eps=0.0):
+    """certify for a DeviceMatrix by one foreign call (pm_lsap_certify_resident); same verdicts, same info keys."""
+    nr, nc = M.shape
+    lib = nat.load()
+    ws = _native_ws(M)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    c4r = np.ascontiguousarray(col4row, dtype=np.int32)
+    cap = 8 * nc + 1024
+    tight = np.empty((cap, 2), dtype=np.int32)
+    opt, rep = _native_options(min_eps), _Report()
+    nat.check(lib.pm_lsap_certify_resident(nat.ptr(M.U), nr, nc, M.ld, ctypes.addressof(opt), u.ctypes.data, v.ctypes.data, c4r.ctypes.data,
+                                           tight.ctypes.data, cap, ctypes.addressof(rep), nat.ptr(ws), ws.numel(), nat.stream_ptr(M.U)))
+    if info is not None:
+        info.update(violations=rep.violations, loose=rep.loose, tight=None if rep.tight_within_eps < 0 else rep.tight_within_eps,
+                    slack_bound=rep.slack_bound, delta=rep.delta, eps=rep.eps, optimal=bool(rep.optimal), certify_seconds=rep.seconds_certify)
+        if rep.tight_within_eps >= 0:
+            info["tight_within_eps"] = rep.tight_within_eps
+            info["unique"] = bool(rep.unique)
+            if rep.n_tight >= 0:
+                info["_tight_edges"] = tight[:rep.n_tight].copy()
+    return bool(rep.optimal and rep.unique)
+
+
 def solve_core(M, info=None):
     """The sparse-core solve of one matrix M [nr, nc], nr <= nc, finite entries -> (u, v, col4row) with no entry of M
     violating dual feasibility beyond delta, or None if M holds non-finite entries / pricing did not converge."""
+    if _native_ok(M):
+        return solve_core_native(M, info)
     nr, nc = M.shape
     k = min(CORE_EDGES_PER_ROW, 256)
     # square problems start from the column reduction (v = column minima, u = row minima of cost - v, rows matched to their

@@ -344,3 +344,36 @@ def test_rectangular_chi_square_assignments_at_a_few_thousand_nuclei(dev, n, m):
         for k, hyp in enumerate((h, twin)):
             rs, cs = scipy_lsa(U[hyp].cpu().numpy())
             assert np.array_equal(got[k][0], rs) and np.array_equal(got[k][1], cs), (hyp, ih)
+
+
+@pytest.mark.parametrize("shape", [(1200, 1200), (1100, 1300), (2500, 2500)])
+def test_native_driver_gives_the_python_drivers_answers(dev, shape, monkeypatch):
+    """csrc/pm_lsap_resident.hip (round 4): solve_core + certify as one foreign call each.  Same kernels, same core solver, same
+    sequence: the certified assignment is the Python driver's (and SciPy's), the duals are feasible to the same tolerance, the
+    certificate's verdict and counters agree."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(shape[0] + 3)
+    U = rng.random(shape) * rng.random((1, shape[1])) + 0.3 * rng.random((shape[0], 1))
+    Ud = dev(U)
+    res = {}
+    for native in (False, True):
+        monkeypatch.setattr(L, "NATIVE_DRIVER", native)
+        W = L.DeviceMatrix(Ud)
+        info = {}
+        sol = L.solve_core(W, info)
+        assert sol is not None and (info.get("driver") == "native") == native
+        ok = L.certify(W, *sol, info=info)
+        res[native] = (sol, ok, info)
+    (sp, okp, ip), (sn, okn, inn) = res[False], res[True]
+    assert okp and okn and np.array_equal(sp[2], sn[2]) and np.array_equal(sn[2], scipy_lsa(U)[1])
+    assert ip["violations"] == inn["violations"] == 0 and ip["loose"] == inn["loose"] == 0
+    assert inn["optimal"] and inn["unique"] and inn["tight_within_eps"] >= 0
+    # the native certificate rejects what the Python one rejects: shifted duals, a rotated matching
+    monkeypatch.setattr(L, "NATIVE_DRIVER", True)
+    W = L.DeviceMatrix(Ud)
+    u, v, c = sn
+    assert not L.certify(W, u + 1e-6, v, c) and not L.certify(W, u, v, np.roll(c, 1))
+    # non-finite entries: no solve (the caller takes SciPy's own path)
+    Un = U.copy()
+    Un[3, 4] = np.nan
+    assert L.solve_core(L.DeviceMatrix(dev(Un))) is None
