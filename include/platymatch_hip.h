@@ -323,7 +323,7 @@ typedef struct pm_lsap_options {
 } pm_lsap_options;
 typedef struct pm_lsap_report {
     int status, rounds, violations, loose, tight_within_eps, n_tight, optimal, unique, n_auction_violated, pad_;
-    long bids, steps, augmentations, edges;
+    long bids, steps, augmentations, edges, dummy_scans;
     double slack_bound, delta, eps, seconds_total, seconds_auction, seconds_core, seconds_device, seconds_certify;
     int auction_violated[8];
     int violated_per_round[32];

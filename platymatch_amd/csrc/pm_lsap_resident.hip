@@ -321,7 +321,7 @@ int pm_lsap_solve_resident(const double *U, int nr, int nc, size_t ld, const pm_
         if (rounds >= opt->max_pricing_rounds) { rep->rounds = rounds; return PM_OK; }
     }
     rep->rounds = rounds;
-    rep->edges = stats4[0]; rep->steps = stats4[1]; rep->augmentations = stats4[2];
+    rep->edges = stats4[0]; rep->steps = stats4[1]; rep->augmentations = stats4[2]; rep->dummy_scans = stats4[3];
     std::memcpy(u, uu.data(), (size_t)nr * 8);
     std::memcpy(v, vv.data(), (size_t)nc * 8);
     std::memcpy(col4row, c4r.data(), (size_t)nr * 4);

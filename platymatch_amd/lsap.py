@@ -477,7 +477,7 @@ class _Report(ctypes.Structure):
     _fields_ = [("status", ctypes.c_int), ("rounds", ctypes.c_int), ("violations", ctypes.c_int), ("loose", ctypes.c_int),
                 ("tight_within_eps", ctypes.c_int), ("n_tight", ctypes.c_int), ("optimal", ctypes.c_int), ("unique", ctypes.c_int),
                 ("n_auction_violated", ctypes.c_int), ("pad_", ctypes.c_int),
-                ("bids", ctypes.c_long), ("steps", ctypes.c_long), ("augmentations", ctypes.c_long), ("edges", ctypes.c_long),
+                ("bids", ctypes.c_long), ("steps", ctypes.c_long), ("augmentations", ctypes.c_long), ("edges", ctypes.c_long), ("dummy_scans", ctypes.c_long),
                 ("slack_bound", ctypes.c_double), ("delta", ctypes.c_double), ("eps", ctypes.c_double), ("seconds_total", ctypes.c_double),
                 ("seconds_auction", ctypes.c_double), ("seconds_core", ctypes.c_double), ("seconds_device", ctypes.c_double),
                 ("seconds_certify", ctypes.c_double), ("auction_violated", ctypes.c_int * 8), ("violated_per_round", ctypes.c_int * 32)]
@@ -527,7 +527,7 @@ def solve_core_native(M, info=None):
                                     ctypes.addressof(rep), nat.ptr(ws), ws.numel(), nat.stream_ptr(M.U))
     nat.check(rc)
     if info is not None:
-        info.update(driver="native", rounds=rep.rounds, edges=rep.edges, steps=rep.steps, augmentations=rep.augmentations,
+        info.update(driver="native", rounds=rep.rounds, edges=rep.edges, steps=rep.steps, augmentations=rep.augmentations, dummy_scans=rep.dummy_scans,
                     auction_bids=rep.bids, auction_seconds=rep.seconds_auction, core_seconds=rep.seconds_core,
                     device_seconds=rep.seconds_device, solve_seconds=rep.seconds_total,
                     violated_per_round=list(rep.violated_per_round[:min(rep.rounds, 32)]),
