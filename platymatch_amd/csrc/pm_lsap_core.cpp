@@ -371,6 +371,15 @@ struct Core {
             for (int i = 0; i < n; ++i)
                 for (const Edge &e : adj[i]) { crow[fill[e.col]] = i; ccost[fill[e.col]++] = e.cost; }
         }
+        // the core by rows as flat arrays (edges of a row contiguous, columns and costs apart): what the bid loop streams through
+        std::vector<int32_t> rstart(n + 1, 0);
+        for (int i = 0; i < n; ++i) rstart[i + 1] = rstart[i] + (int32_t)adj[i].size();
+        std::vector<int32_t> rcol(rstart[n]);
+        std::vector<double> rcost(rstart[n]);
+        for (int i = 0; i < n; ++i) {
+            int32_t t = rstart[i];
+            for (const Edge &e : adj[i]) { rcol[t] = e.col; rcost[t++] = e.cost; }
+        }
         std::vector<int32_t> stack;
         for (double eps = eps0;; eps = std::max(eps / factor, eps_min)) {
             size_t head = 0, count = 0;                    // ring buffer of the unassigned rows (first in, first out)
@@ -399,12 +408,26 @@ struct Core {
                 const int i = queue[head];
                 head = head + 1 == (size_t)n ? 0 : head + 1;
                 --count;
+                if (count > 0) {                            // the next bidder's edges: start their cache misses now
+                    const int32_t nx = rstart[queue[head]];
+                    __builtin_prefetch(&rcol[nx], 0, 3);
+                    __builtin_prefetch(&rcost[nx], 0, 3);
+                    __builtin_prefetch(&rcost[nx] + 8, 0, 3);
+                }
                 double best = std::numeric_limits<double>::infinity(), second = best, bc = 0.0;
                 int bj = -1;
-                for (const Edge &e : adj[i]) {
-                    const double val = e.cost + price[e.col];
-                    if (val < best) { second = best; best = val; bj = e.col; bc = e.cost; }
-                    else if (val < second) second = val;
+                // branch-free two-smallest scan (which edge wins is unpredictable: a mispredicted branch per edge cost more than
+                // the arithmetic); first minimum on ties, as before
+                for (int32_t t = rstart[i], te = rstart[i + 1]; t < te; ++t) {
+                    const int32_t cj = rcol[t];
+                    const double ct = rcost[t];
+                    const double val = ct + price[cj];
+                    const bool lt = val < best;
+                    const double s2 = val < second ? val : second;
+                    second = lt ? best : s2;
+                    bj = lt ? cj : bj;
+                    bc = lt ? ct : bc;
+                    best = lt ? val : best;
                 }
                 const double margin = second < std::numeric_limits<double>::infinity() ? second - best : lone;
                 price[bj] += margin + eps;

@@ -462,7 +462,12 @@ def _row_reduction(M, v, rounds):
 
 
 # ---- the native driver (csrc/pm_lsap_resident.hip): the same sequence as solve_core / certify below in one foreign call each --------
-NATIVE_DRIVER = os.environ.get("PM_LSAP_NATIVE", "1") != "0"
+# Measured, round 4 (profiles/r04_lsap_phases.txt, r04_batch64_native*.json): the native driver is NOT faster — 11.8 / 14.0 ms against
+# 9.1 / 15.5 ms per hypothesis at 5 000 nuclei, 79 / 87 against 73 / 84 at 20 000, the same for all eight on four threads and for
+# the 64-pair batch: the glue it removes was ~1 ms per hypothesis, the time is in the host core's auction and shortest paths either
+# way.  Kept as an option (PM_LSAP_NATIVE=1, lsap.NATIVE_DRIVER = True; identical answers: tests/test_gpu_lsap.py), not the default:
+# the Python driver is the one every kind of matrix (resident, sharded, the CPU tests' double) goes through.
+NATIVE_DRIVER = os.environ.get("PM_LSAP_NATIVE", "0") == "1"
 
 
 class _Options(ctypes.Structure):
