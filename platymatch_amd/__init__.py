@@ -36,3 +36,47 @@ def install_as_platymatch():
     for n in names:
         sys.modules.setdefault("platymatch." + n, importlib.import_module("platymatch_amd." + n))
     return sys.modules["platymatch"]
+
+
+class HostArithmeticWarning(UserWarning):
+    """self_check found that NumPy / BLAS on this host do not round the way the kernels restate them."""
+
+
+_SELF_CHECK = {}
+
+
+def self_check(force=False):
+    """Bit parity with the reference rests on three properties of the HOST's NumPy / BLAS that the kernels restate (DESIGN.md §4.4,
+    §4.6, §5): np.add.reduce sums a long vector in pieces of np.getbufsize() elements with pairwise leaves (the centroid, the mean
+    pairwise distance, the Similar-mode moments); BLAS ddot accumulates a 3-vector with fused multiply-adds (np.linalg.norm inside
+    get_mean_distance, utils/utils.py:66); np.matmul of a 4 x 4 with a cloud is dgemm's fused chain (apply_affine_transform,
+    apply_transform.py:13).  They hold for NumPy 1.2x / 2.x with OpenBLAS on x86-64; another BLAS or CPU may round differently, and
+    then the REFERENCE's own numbers differ on that host — from the fixtures and from this package alike.  This compares the three
+    on small inputs, host NumPy against the device kernels, once per process; a difference is reported as a HostArithmeticWarning
+    (results stay correct to rounding; what is lost is the guarantee of the reference's exact bits on this machine).
+    -> dict of the three verdicts.  Called by estimate_transform before its first registration; needs the GPU."""
+    import warnings
+    import numpy as np
+    if _SELF_CHECK and not force:
+        return dict(_SELF_CHECK)
+    from . import _kernels as K, _native as nat
+    rng = np.random.default_rng(20241)
+    x = np.ascontiguousarray(rng.normal(size=(3, 20011)) * 37.0 + 211.0)          # crosses two 8 192-element pieces and a ragged tail
+    xd = nat.to_dev(x)
+    ok = {}
+    ok["np.mean: buffer pieces + pairwise leaves"] = bool(np.array_equal(K.centroid(xd).cpu().numpy(), x.mean(1)))
+    small = np.ascontiguousarray(x[:, :45])
+    d = [np.linalg.norm(small[:, i] - small[:, j]) for i in range(45) for j in range(i + 1, 45)]     # get_mean_distance's own list
+    ok["BLAS ddot: fused multiply-adds"] = bool(K.mean_distance(nat.to_dev(small)).item() == np.average(d))
+    A = np.eye(4)
+    A[:3] = rng.normal(size=(3, 4))
+    want = np.matmul(A, np.vstack((x[:, :4099], np.ones((1, 4099)))))[:3]
+    got = K.apply_affine(nat.to_dev(A.reshape(16)), nat.to_dev(np.ascontiguousarray(x[:, :4099]))).cpu().numpy()
+    ok["np.matmul: dgemm's fused chain"] = bool(np.array_equal(got, want))
+    _SELF_CHECK.update(ok)
+    bad = [k for k, v in ok.items() if not v]
+    if bad:
+        warnings.warn("platymatch_amd.self_check: this host's NumPy / BLAS differ from the arithmetic the kernels restate (%s; numpy %s, "
+                      "np.getbufsize() = %d): results remain correct to rounding, but bit identity with the reference's output ON THIS "
+                      "HOST is not guaranteed" % ("; ".join(bad), np.__version__, np.getbufsize()), HostArithmeticWarning, stacklevel=2)
+    return dict(ok)

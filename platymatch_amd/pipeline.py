@@ -822,6 +822,9 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     import time
     import torch
     be = backend or GpuBackend()
+    if backend is None:
+        from . import self_check
+        self_check()                          # once per process: does this host's NumPy / BLAS round as the kernels restate it?
     mov, fix = be.cloud(moving), be.cloud(fixed)
     inliers = np.zeros(8, dtype=np.int64)
     rank, world = _world(group)

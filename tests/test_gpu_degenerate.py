@@ -137,3 +137,15 @@ def test_transform_and_get_Y_on_their_own(rk):
     t_in = _dev(rk["tf_neighbors"])
     t_out = sc.transform(rk["tf_detection"], rk["tf_x"], rk["tf_y"], rk["tf_z"], t_in)                # torch in -> torch out
     assert t_out.is_cuda and np.abs(t_out.cpu().numpy() - rk["tf_out"]).max() < 1e-10
+
+
+def test_host_arithmetic_self_check_passes_on_this_box():
+    """platymatch_amd.self_check: NumPy's buffered pairwise summation, BLAS ddot's and dgemm's fused multiply-adds —
+    the host properties the kernels restate — hold on the GPU box's host, so no HostArithmeticWarning is raised and the three
+    verdicts are True; estimate_transform runs the check once per process."""
+    import warnings
+    import platymatch_amd
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", platymatch_amd.HostArithmeticWarning)
+        verdicts = platymatch_amd.self_check(force=True)
+    assert len(verdicts) == 3 and all(verdicts.values()), verdicts

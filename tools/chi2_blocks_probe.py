@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Why does a rank's 6 250-row share of the 50k cost build take 85 ms when the whole build takes 1 144 ms (13.4x, not 8x:
-profiles/r04_rank_share.json)?  The same build as ONE launch and as B launches of N/B rows each, (a) into row slices of the one
+"""Is the 50k cost launch linear in its rows, or does its 160 GB footprint / its second-long duration cost something (TLB reach,
+clocks)?  (A first rank-share measurement suggested 13x for an eighth of the rows; it was an artefact of that tool — wrong ring
+radii, hence emptier shells and more of them tabled.)  The same build as ONE launch and as B launches of N/B rows each, (a) into row slices of the one
 [8, N, M] buffer (the big launch's footprint and matrix spacing, short launches) and (b) into a compact [8, N/B, M] buffer reused
 by every block (small footprint).  HIP events per launch.  Usage: python tools/chi2_blocks_probe.py [N]"""
 import os
