@@ -139,3 +139,41 @@ def test_config5_at_its_stated_size_64_pairs_of_2k_to_20k(pairs):
           "(device sampler) %.2f s = %.2f registrations/s; worst rel. error vs ground truth %.1e / %.1e; 512 of 512 assignments "
           "device-certified; primal - dual of the largest pair's winner %.1e"
           % (min(sizes), max(sizes), dt_seeded, 64 / dt_seeded, dt_unseeded, 64 / dt_unseeded, worst, worst_u, float(primal - dual)))
+
+
+def test_two_threads_on_one_stream_never_share_a_kept_cost_buffer(monkeypatch):
+    """the kept cost buffer of a (device, stream) is LEASED — a second registration arriving on the same
+    stream while the first still reads its matrices (host-driven assignment passes) gets a fresh allocation, never a view of the
+    same storage.  With the threshold lowered so that 1 500-point pairs take the kept-buffer path, three threads registering
+    different pairs on the default stream at once return exactly what the same calls return one after the other."""
+    import threading
+    import torch
+    from platymatch_amd import pipeline as P
+    from platymatch_amd.estimate_transform import perform_icp as pi
+    pi.VERBOSE = False
+    monkeypatch.setattr(P, "COST_CACHE_MIN_BYTES", 1 << 20)
+    P.release_cost_buffers()
+    pairs = []
+    for k, n in enumerate((1500, 1400, 1600)):
+        mv, fx, _ = synth_pair(n, 300 + k)
+        pairs.append((mv, fx))
+    kw = dict(ransac_trials=200, icp_iterations=4)
+    want = [P.estimate_transform(a, b, seed=9 + k, **kw) for k, (a, b) in enumerate(pairs)]
+    assert P.kept_cost_bytes(torch.device("cuda", torch.cuda.current_device())) > 0          # the path under test is the kept buffer's
+    for rep in range(3):
+        got, errors = [None] * 3, []
+
+        def run(k):
+            try:
+                got[k] = P.estimate_transform(pairs[k][0], pairs[k][1], seed=9 + k, private_rng=True, **kw)
+            except BaseException as e:
+                errors.append(e)
+        th = [threading.Thread(target=run, args=(k,)) for k in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errors, errors
+        for k in range(3):
+            assert np.array_equal(got[k][2], want[k][2]) and np.array_equal(got[k][0], want[k][0]) and np.array_equal(got[k][1], want[k][1]), (rep, k)
+    P.release_cost_buffers()
