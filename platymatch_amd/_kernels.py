@@ -428,7 +428,7 @@ def chi2_cost8(sc_m, sc_f, out=None, path="auto"):
     return out
 
 
-def _pairs(mov, fix, rows, cols):
+def _pairs(mov, fix, rows, cols, trusted=False):
     mov, fix = _cloud(mov, "moving"), _cloud(fix, "fixed")
     if (rows is None) != (cols is None):
         raise ValueError("rows and cols go together")
@@ -438,8 +438,8 @@ def _pairs(mov, fix, rows, cols):
         n = mov.shape[1]
     else:
         n = rows.numel()
-        rows = _idx(rows, n, mov.shape[1], "rows")
-        cols = _idx(cols, n, fix.shape[1], "cols")
+        rows = _idx(rows, n, mov.shape[1], "rows", trusted=trusted)
+        cols = _idx(cols, n, fix.shape[1], "cols", trusted=trusted)
     return mov, fix, rows, cols, n
 
 
@@ -475,11 +475,12 @@ def ransac_draw(n, k, trials, seed, run=0, device=None):
     return out
 
 
-def ransac_affine_draw(mov, fix, rows, cols, k, trials, seed, run, error):
+def ransac_affine_draw(mov, fix, rows, cols, k, trials, seed, run, error, trusted=False):
     """ransac_affine with each trial's index set drawn on the device in front of its fit (pm_ransac_affine_draw)
-    -> (samples [trials, k] int32, A [trials, 4, 4], inliers [trials] int32, degenerate [trials] int32)."""
+    -> (samples [trials, k] int32, A [trials, 4, 4], inliers [trials] int32, degenerate [trials] int32).
+    trusted: rows / cols were range-checked by the caller on the host (no read-back here: the launch does not wait for the stream)."""
     torch = _t()
-    mov, fix, rows, cols, n = _pairs(mov, fix, rows, cols)
+    mov, fix, rows, cols, n = _pairs(mov, fix, rows, cols, trusted=trusted)
     k, trials = int(k), int(trials)
     if k < 4:
         raise ValueError("k >= 4 (fewer pairs are rank deficient by construction: host pinv)")

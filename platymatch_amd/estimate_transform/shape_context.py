@@ -245,8 +245,24 @@ def refit_affine_winner(deferred):
     return torch.as_tensor(affine_pinv_host(h[:, :k], h[:, k:]), device=pts.device)
 
 
+def ransac_prelaunch(moving_all, fixed_all, rows, cols, min_samples, trials, error, device_seed, run):
+    """Enqueue do_ransac's fused draw + fit + score launch for one hypothesis WITHOUT waiting for it (Affine, device sampler,
+    min_samples >= 4) -> an opaque handle for do_ransac(prelaunched=...).  The driver enqueues all eight hypotheses' launches
+    back to back and only then starts reading results: the GPU runs them without the host's read-backs in between."""
+    torch = nat.torch_mod()
+    m, f = nat.to_dev(moving_all), nat.to_dev(fixed_all)
+    m, f = m[:3, :].contiguous(), f[:3, :].contiguous()
+    r_h, c_h = np.asarray(rows), np.asarray(cols)         # range-checked HERE, on the host: the launch must not wait for the stream
+    if r_h.size and (r_h.min() < 0 or r_h.max() >= m.shape[1] or c_h.min() < 0 or c_h.max() >= f.shape[1]):
+        raise IndexError("matched pair indices outside the clouds")
+    rows = nat.to_dev(r_h, dtype=torch.int32, dev=m.device)
+    cols = nat.to_dev(c_h, dtype=torch.int32, dev=m.device)
+    fused = K.ransac_affine_draw(m, f, rows, cols, int(min_samples), int(trials), device_seed, run, float(error), trusted=True)
+    return {"fused": fused, "rows": rows, "cols": cols, "key": (int(min_samples), int(trials), float(error), int(device_seed), int(run))}
+
+
 def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transform='Affine', rows=None, cols=None,
-              samples=None, device_seed=None, run=0, defer=None):
+              samples=None, device_seed=None, run=0, defer=None, prelaunched=None):
     """shape_context.py:103-139 -> (A_best 4 x 4, inliers_best).
 
     The host draws the index sets (same RNG calls as the reference); one kernel launch fits and
@@ -268,6 +284,10 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
     if m.shape[0] == 4 or f.shape[0] == 4:
         m, f = m[:3, :], f[:3, :]
     m, f = m.contiguous(), f.contiguous()
+    if prelaunched is not None:               # the launch is already in flight (ransac_prelaunch): same arguments, checked
+        if transform != 'Affine' or prelaunched["key"] != (int(min_samples), int(trials), float(error), int(device_seed), int(run)):
+            raise ValueError("prelaunched does not belong to this call")
+        rows, cols = prelaunched["rows"], prelaunched["cols"]
     if rows is not None:
         rows = nat.to_dev(rows, dtype=torch.int32, dev=m.device)
         cols = nat.to_dev(cols, dtype=torch.int32, dev=m.device)
@@ -291,7 +311,7 @@ def do_ransac(moving_all, fixed_all, min_samples=4, trials=500, error=5, transfo
         samples = draw_ransac_samples(n, int(min_samples), trials)
     elif transform == 'Affine' and int(min_samples) >= 4:
         # the draw is fused in front of each trial's fit; the sets stay on the device (fetched only for trials the host refits)
-        fused = K.ransac_affine_draw(m, f, rows, cols, int(min_samples), trials, device_seed, run, float(error))
+        fused = prelaunched["fused"] if prelaunched is not None else K.ransac_affine_draw(m, f, rows, cols, int(min_samples), trials, device_seed, run, float(error))
         samples = _DeviceSamples(fused[0])
     else:
         samples = K.ransac_draw(n, int(min_samples), trials, device_seed, run, device=m.device).cpu().numpy()

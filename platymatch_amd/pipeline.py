@@ -176,10 +176,15 @@ class GpuBackend:
         from .estimate_transform.shape_context import draw_ransac_samples
         return draw_ransac_samples(n, min_samples, trials, rng=rng)
 
-    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples, samples=None, device_seed=None, run=0, defer=None):
+    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples, samples=None, device_seed=None, run=0, defer=None,
+                  prelaunched=None):
         from .estimate_transform.shape_context import do_ransac
         return do_ransac(mov, fix, min_samples=min_samples, trials=trials, error=error, transform=transform,
-                         rows=rows, cols=cols, samples=samples, device_seed=device_seed, run=run, defer=defer)
+                         rows=rows, cols=cols, samples=samples, device_seed=device_seed, run=run, defer=defer, prelaunched=prelaunched)
+
+    def ransac_prelaunch(self, mov, fix, rows, cols, trials, error, min_samples, device_seed, run):
+        from .estimate_transform.shape_context import ransac_prelaunch
+        return ransac_prelaunch(mov, fix, rows, cols, min_samples, trials, error, device_seed, run)
 
     def refit_winner(self, deferred):
         """The chosen hypothesis's RANSAC model by the reference's own host expression (shape_context.refit_affine_winner)."""
@@ -915,8 +920,16 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         # details["ransac_A"], equal to the reference's to ~1e-12)
         can_defer = transform == 'Affine' and hasattr(be, "refit_winner")
         deferred = [dict() for _ in range(8)]
+        pre = [None] * 8
+        if (on_device and transform == 'Affine' and int(ransac_samples) >= 4 and int(ransac_trials) > 0 and hasattr(be, "ransac_prelaunch")
+                and all(len(r) >= int(ransac_samples) for r, _ in lsa)):
+            # all eight hypotheses' fused draw + fit + score launches go out back to back; results are read afterwards
+            pre = [be.ransac_prelaunch(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, ransac_samples, dseed, h)
+                   for h, (r, c) in enumerate(lsa)]
         for h, (r, c) in enumerate(lsa):
             extra = {"defer": deferred[h]} if can_defer else {}
+            if pre[h] is not None:
+                extra["prelaunched"] = pre[h]
             if on_device:                            # stream h of the registration's seed: the eight runs draw independent sets
                 A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
                                     ransac_samples, device_seed=dseed, run=h, **extra)
