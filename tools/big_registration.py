@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One complete unsupervised registration of two N-point clouds through the driver, with the stage split — for sizes
 at which the eight cost matrices (64 N M bytes) exceed HBM and the pipeline streams the hypotheses two matrices at a time
-(N > ~67 000 on one MI355X).  Usage: python tools/big_registration.py N [ransac_trials [icp_iterations]]"""
+(N > ~67 000 on one MI355X).  Since round 4 a hypothesis whose optimum has a near-tie is settled on its block (lsap.resolve_near_ties):
+the call passes NO accept_near_ties and must not raise.  Usage: python tools/big_registration.py N [ransac_trials [icp_iterations]]"""
 import os
 import sys
 import threading
@@ -36,8 +37,7 @@ mv, fx, A_gt = synth_pair(n, 42)
 P.estimate_transform(mv[:, :400], fx[:, :400], ransac_trials=50, icp_iterations=2)          # warm-up
 det = {"timing": True}
 t = time.perf_counter()
-A_sc, A_icp, inl = P.estimate_transform(mv, fx, ransac_trials=trials, ransac_error=16, icp_iterations=iters, seed=0, details=det,
-                                        accept_near_ties=True)
+A_sc, A_icp, inl = P.estimate_transform(mv, fx, ransac_trials=trials, ransac_error=16, icp_iterations=iters, seed=0, details=det)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t
 stop.set()
