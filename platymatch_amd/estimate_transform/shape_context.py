@@ -401,13 +401,54 @@ class _DeviceSamples:
         return self.dev[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=self.dev.device)].cpu().numpy()
 
 
+def pca_view(detections, transposed=False):
+    """The N x 3 array the reference hands to sklearn's PCA (shape_context.py:151-165), made from the CALLER'S OWN array by the
+    reference's own steps — transpose unless `transposed`, drop a 4th column — as views: the array's memory layout is part of what
+    BLAS sees and hence of the axis's last bits.  Torch tensors come over as host arrays; non-float64 input is converted
+    (sklearn itself would keep a float32 cloud in float32: not mirrored)."""
+    a = detections.detach().cpu().numpy() if nat.is_torch(detections) else np.asarray(detections)
+    if a.ndim != 2:
+        raise ValueError("detections must be 2-D")
+    if not transposed:
+        a = a.transpose()
+    if a.shape[1] == 4:
+        a = a[:, :3]
+    if a.shape[1] != 3:
+        raise ValueError("detections must be 3 x N (N x 3 with transposed=True)")
+    return a if a.dtype == np.float64 else a.astype(np.float64)
+
+
+def pca_axis_host(X):
+    """sklearn.decomposition.PCA(n_components=3).fit(X).components_[0] (shape_context.py:162-165) restated in NumPy, call for call
+    as scikit-learn 1.7 computes it (sklearn/decomposition/_pca.py: _fit_full; svd_solver='auto'): for n_samples >= 10 n_features
+    the eigen-decomposition of the Gram matrix X.T @ X minus n mean mean^T (solver 'covariance_eigh'), otherwise LAPACK's SVD of the
+    centred data ('full'); components flipped so that each one's largest-magnitude entry is positive (svd_flip,
+    u_based_decision=False).  HOST code on purpose (round 4): the result hangs on BLAS's accumulation order inside X.T @ X and on
+    LAPACK's eigh — only the same NumPy calls on the same array reproduce the reference's axis to the BIT (verified against
+    sklearn itself on 3 500 random clouds of 4 .. 3 000 points, both solver branches and both memory orders:
+    tests/golden/gen_pca_axis.py); a device kernel (pm_pca_axis) gets within 9e-14.  The work is O(N) on 24 N bytes."""
+    X = np.asarray(X)
+    n, f = X.shape
+    mean = np.mean(X, axis=0)
+    if f <= 1000 and n >= 10 * f:
+        C = X.T @ X
+        C -= n * np.reshape(mean, (-1, 1)) * np.reshape(mean, (1, -1))
+        C /= n - 1
+        w, V = np.linalg.eigh(C)
+        Vt = np.flip(np.asarray(V), axis=1).T              # rows by decreasing eigenvalue (eigh returns them ascending)
+    else:
+        _, _, Vt = np.linalg.svd(X - mean, full_matrices=False)
+    row = Vt[0]
+    return row * np.sign(row[np.argmax(np.abs(row))])
+
+
 def get_unary(centroid, mean_distance, detections, type, transposed=False, x0=None):
     """shape_context.py:144-188 -> (sc, sc2, sc3, sc4), each (N, 360) float64; sc3 and sc4 are empty
     (shape (0,)) unless type == 'fixed', as in the reference.
 
     centroid: 3 x 1 (or 1 x 3 with transposed=True); detections: 3 x N (or N x 3); a 4th
-    row/column is dropped (:156-157).  The first PCA axis the reference gets from sklearn
-    (:162-165) is computed on the device unless `x0` is given."""
+    row/column is dropped (:156-157).  The first PCA axis the reference gets from sklearn (:162-165) is sklearn's own sequence
+    of NumPy calls on the caller's array (pca_axis_host: the reference's bits) unless `x0` is given."""
     torch = nat.torch_mod()
     d = nat.to_dev(detections)
     if d.dim() != 2:
@@ -419,7 +460,7 @@ def get_unary(centroid, mean_distance, detections, type, transposed=False, x0=No
     xyz = d[:3, :].contiguous()
     c = nat.to_dev(centroid, dev=xyz.device).reshape(-1)[:3].contiguous()
     md = nat.to_dev(mean_distance, dev=xyz.device).reshape(1)
-    axis = K.pca_axis(xyz) if x0 is None else nat.to_dev(x0, dev=xyz.device).reshape(3).contiguous()
+    axis = nat.to_dev(pca_axis_host(pca_view(detections, transposed)) if x0 is None else x0, dev=xyz.device).reshape(3).contiguous()
     nf = 4 if type == 'fixed' else 2
     hist = K.shape_context(xyz, c, axis, md, nf)["hist"]
     if nat.is_torch(detections):

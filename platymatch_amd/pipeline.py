@@ -118,8 +118,17 @@ class GpuBackend:
             raise ValueError("clouds must be 3 x N (or 4 x N)")
         return t[:3, :].contiguous()
 
-    def stats(self, xyz):
-        return self.K.centroid(xyz), self.K.mean_distance(xyz), self.K.pca_axis(xyz)
+    def axis(self, xyz, view=None):
+        """First PCA axis of the cloud as the reference gets it from sklearn (shape_context.py:162-165): sklearn's own NumPy calls on
+        the host (shape_context.pca_axis_host: the reference's bits), on `view` — the N x 3 array the reference would pass, made
+        from the caller's own array (shape_context.pca_view) — or, without one, on a host copy of the device cloud."""
+        from .estimate_transform.shape_context import pca_axis_host
+        if view is None:
+            view = xyz.cpu().numpy().transpose()
+        return nat.to_dev(pca_axis_host(view), dev=xyz.device).reshape(3).contiguous()
+
+    def stats(self, xyz, view=None):
+        return self.K.centroid(xyz), self.K.mean_distance(xyz), self.axis(xyz, view)
 
     def mean_distance_partials(self, xyz, row_offset, row_stride):
         return self.K.mean_distance_partials(xyz, row_offset, row_stride)
@@ -127,8 +136,8 @@ class GpuBackend:
     def mean_distance_finish(self, partials, n):
         return self.K.mean_distance_finish(partials, n)
 
-    def centroid_and_axis(self, xyz):
-        return self.K.centroid(xyz), self.K.pca_axis(xyz)
+    def centroid_and_axis(self, xyz, view=None):
+        return self.K.centroid(xyz), self.axis(xyz, view)
 
     def shape_context(self, xyz, c, md, x0, nf, row0, nrows, guards=None):
         r = self.K.shape_context(xyz, c, x0, md, nf, row0=row0, nrows=nrows)
@@ -302,17 +311,18 @@ def all_gather_rows(local, bounds, dim, group):
     return out if dim == 1 else out[0]
 
 
-def cloud_statistics(be, xyz, group=None):
+def cloud_statistics(be, xyz, group=None, view=None):
     """(centroid [3], mean pairwise distance [1], first PCA axis [3]) of one cloud, identical on every rank.
     The O(N) parts are recomputed by every rank (same input, same reduction order, same bits).  The O(N^2) mean distance
     is shared out: rank g adds up the 256 x 256 tiles of the tile rows g, g + G, ..., the tile sums (every one non-zero
     on one rank only, so the element-wise all-reduce is exact) are combined, and every rank adds them in the fixed
     order of the one-device kernel — the same bits as on one GPU, at 1/G of the pair work."""
     rank, world = _world(group)
+    kw = {"view": view} if (view is not None and getattr(be, "device_sampler", False)) else {}      # (the GPU backend; test doubles take none)
     if world == 1:
-        return be.stats(xyz)
+        return be.stats(xyz, **kw)
     dist = _dist()
-    c, x0 = be.centroid_and_axis(xyz)
+    c, x0 = be.centroid_and_axis(xyz, **kw)
     part = be.mean_distance_partials(xyz, rank, world)
     dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
     return c, be.mean_distance_finish(part, xyz.shape[1]), x0
@@ -338,7 +348,7 @@ STATS_ON_TWO_STREAMS = True
 RELAXED_MIN_POINTS = 1024      # cost_mode='relaxed' below this: exact (the dense host solver takes such matrices, no certificate to lean on)
 
 
-def statistics_of_both(be, mov, fix, group=None):
+def statistics_of_both(be, mov, fix, group=None, views=(None, None)):
     """cloud_statistics of the moving and of the fixed cloud -> ((centroid, mean distance, axis), (...)).  On one GPU the two
     clouds' statistics — independent of each other — run on two streams: each cloud's serial pieces (the chain over the mean
     distance's piece sums, ~0.8 ms at 50 000 points; the one-workgroup centroid and axis kernels) then run beside the other
@@ -350,16 +360,16 @@ def statistics_of_both(be, mov, fix, group=None):
         side = nat.side_stream(mov.device, ("statistics", main.cuda_stream))
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            sf = be.stats(fix)
-        sm = be.stats(mov)
+            sf = be.stats(fix, views[1])
+        sm = be.stats(mov, views[0])
         main.wait_stream(side)
         for t in sf:
             t.record_stream(main)
         return sm, sf
-    return cloud_statistics(be, mov, group), cloud_statistics(be, fix, group)
+    return cloud_statistics(be, mov, group, views[0]), cloud_statistics(be, fix, group, views[1])
 
 
-def build_descriptors(be, mov, fix, group=None, guards=None):
+def build_descriptors(be, mov, fix, group=None, guards=None, views=(None, None)):
     """Stages 526-545 of the widget: statistics and get_unary for both clouds.
     -> (sc_m [2, rows_g, 360], sc_f [4, M, 360] complete (or [1, M, 360], see gather_fixed_descriptors), moving row bounds).
     guards (optional list): receives the edge-guard counters of the two launches (this rank's rows), moving first."""
@@ -367,7 +377,7 @@ def build_descriptors(be, mov, fix, group=None, guards=None):
     n, m = mov.shape[1], fix.shape[1]
     if world > min(n, m):        # every rank sees the same clouds: all raise, before the first collective
         raise ValueError("cannot shard %d x %d points over %d ranks: every rank needs at least one row of each cloud" % (n, m, world))
-    (cm, mdm, x0m), (cf, mdf, x0f) = statistics_of_both(be, mov, fix, group)
+    (cm, mdm, x0m), (cf, mdf, x0f) = statistics_of_both(be, mov, fix, group, views)
     bn, bm = shard_bounds(n, world), shard_bounds(m, world)
     if guards is not None and getattr(be, "device_sampler", False):       # (the GPU backend; test doubles have no guard)
         sc_m = be.shape_context(mov, cm, mdm, x0m, 2, bn[rank], bn[rank + 1] - bn[rank], guards=guards)
@@ -858,7 +868,11 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         lease = relaxed = None
         try:
             guards = [] if getattr(be, "device_sampler", False) else None     # (the GPU backend: its descriptor launches count)
-            sc_m, sc_f, bn = build_descriptors(be, mov, fix, group, guards=guards)
+            views = (None, None)
+            if getattr(be, "device_sampler", False):
+                from .estimate_transform.shape_context import pca_view
+                views = (pca_view(moving), pca_view(fixed))       # what the reference would hand to sklearn: the caller's own arrays
+            sc_m, sc_f, bn = build_descriptors(be, mov, fix, group, guards=guards, views=views)
             # all eight matrices at once when they fit (four assignments then run side by side); otherwise two at a time
             need = cost_bytes(sc_m.shape[1], mov.shape[1], sc_f.shape[1], world)
             if stream_hypotheses is not None:

@@ -53,8 +53,15 @@ def test_statistics(gpu, oracle, name):
         assert np.abs(x0.cpu().numpy() - oracle.pca_axis(d[key].T)).max() < 1e-12                # (observed: <= 9e-14; the edge guard assumes 1e-12)
     assert gpu.K.mean_distance(gpu.d(d["moving"])).item() == float(d["mean_dist_m"])          # vs the reference itself: identical
     assert gpu.K.mean_distance(gpu.d(d["fixed"])).item() == float(d["mean_dist_f"])
-    assert np.abs(gpu.K.pca_axis(gpu.d(d["fixed"])).cpu().numpy() - d["x0_f"]).max() < 1e-12
+    assert np.abs(gpu.K.pca_axis(gpu.d(d["fixed"])).cpu().numpy() - d["x0_f"]).max() < 1e-12          # the device kernel (C ABI entry)
     assert np.abs(gpu.K.pca_axis(gpu.d(d["moving"])).cpu().numpy() - d["x0_m"]).max() < 1e-12
+    # what the driver and the mirror USE since round 4: sklearn's own NumPy calls on the caller's array — the reference's bits
+    from platymatch_amd import pipeline as P
+    from platymatch_amd.estimate_transform import shape_context as sc
+    be = P.GpuBackend()
+    for key, want in (("moving", d["x0_m"]), ("fixed", d["x0_f"])):
+        assert np.array_equal(be.axis(gpu.d(d[key]), sc.pca_view(d[key])).cpu().numpy(), want)
+        assert np.array_equal(be.stats(gpu.d(d[key]))[2].cpu().numpy(), want)                           # (from the device copy: same layout)
 
 
 def test_mean_distance_shared_out_over_ranks_is_bit_identical(gpu):

@@ -60,8 +60,8 @@ def test_scenario_statistics(oracle, scenario):
     assert np.array_equal(oracle.get_centroid(mv, transposed=False), d["centroid_m"])
     assert oracle.get_mean_distance(mv, transposed=False) == d["mean_dist_m"]              # bit for bit (round 3)
     assert oracle.get_mean_distance(fx, transposed=False) == d["mean_dist_f"]
-    assert np.abs(oracle.pca_axis(mv.T) - d["x0_m"]).max() < 1e-12      # sklearn PCA axis incl. sign convention
-    assert np.abs(oracle.pca_axis(fx.T) - d["x0_f"]).max() < 1e-12
+    assert np.array_equal(oracle.pca_axis(mv.T), d["x0_m"])              # sklearn's PCA axis, bit for bit (round 4: its own NumPy calls restated)
+    assert np.array_equal(oracle.pca_axis(fx.T), d["x0_f"])
 
 
 def test_scenario_histograms_exact(oracle, scenario):
@@ -241,3 +241,27 @@ def test_oracle_against_the_reference_on_the_lopsided_lattice_pairs(oracle):
             if np.isfinite(d[p + "A_sc"]).all() and np.linalg.cond(d[p + "A_sc"]) < 1e8:
                 assert np.array_equal(got[0], d[p + "A_sc"]) and np.array_equal(np.asarray(det["nn"]), d[p + "icp_nn"]), seed
     assert tuple(equal) == LOPSIDED_ORACLE_EQUALS_REFERENCE, equal
+
+
+
+def _pca_views(d, k):
+    """The N x 3 array the reference would hand to sklearn for fixture case k of pca_axis.npz (gen_pca_axis.py)."""
+    cloud, kind = d["c%02d_cloud" % k], int(d["c%02d_kind" % k][0])
+    return cloud if kind == 2 else (cloud.transpose()[:, :3] if kind == 3 else cloud.transpose())
+
+
+def test_pca_axis_is_sklearns_bit_for_bit(oracle):
+    """tests/golden/pca_axis.npz (gen_pca_axis.py): sklearn.decomposition.PCA(3).fit(X).components_[0] for 40 clouds of 4 .. 1 500
+    points in the layouts the reference meets (transposed views, C-ordered N x 3, voxel coordinates, a sliced 4 x N array), both
+    solver branches.  The oracle's restatement and the PRODUCT's (shape_context.pca_axis_host, host NumPy by design: the axis hangs
+    on BLAS's accumulation order and LAPACK's eigh) both reproduce it bit for bit; pca_view builds the reference's view from the
+    caller's array."""
+    from platymatch_amd.estimate_transform import shape_context as sc
+    d = load_golden("pca_axis")
+    for k in range(int(d["cases"][0])):
+        X, want = _pca_views(d, k), d["c%02d_axis" % k]
+        assert np.array_equal(oracle.pca_axis(X), want), k
+        assert np.array_equal(sc.pca_axis_host(X), want), k
+        kind = int(d["c%02d_kind" % k][0])
+        view = sc.pca_view(d["c%02d_cloud" % k], transposed=(kind == 2))
+        assert np.array_equal(sc.pca_axis_host(view), want), k
