@@ -877,7 +877,8 @@ def test_tile_kernel_equals_the_general_kernel_on_generic_clouds(gpu, oracle, n,
         (tc, tt, th), (gc, gt, gh) = _both_paths(gpu, cloud, c, md, x0, nf)
         assert np.array_equal(tc, gc) and np.array_equal(tt, gt)
         assert np.array_equal(th.view(np.uint64), gh.view(np.uint64))
-        assert (tt == n - 1).all()                         # every other point is counted, in every frame
+        if n > 3:                                          # (three points and their centroid are coplanar: every neighbour sits ON a sector
+            assert (tt == n - 1).all()                     #  plane of every frame and is binned by rounding noise — the edge guard's case)
     # a row block that starts and ends inside tiles
     if n >= 257:
         c, md, x0 = oracle.get_centroid(fx, False), oracle.get_mean_distance(fx, False), oracle.pca_axis(fx.T)
