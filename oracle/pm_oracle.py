@@ -372,16 +372,21 @@ def estimate_transform(moving, fixed, *, transform="Affine", mode="unsupervised"
 
 # --------------------------------------------------------------------------- rows "next" 
 def pca_components(detections_nx3):
-    """sklearn.decomposition.PCA(3).fit(X).components_ (the widget's PCA-only alignment, _dock_widget.py:722-731):
-    eigenvectors of the sample covariance by decreasing eigenvalue, each row's largest-|.| entry positive."""
+    """sklearn.decomposition.PCA(3).fit(X).components_ (the widget's PCA-only alignment, _dock_widget.py:722-731) by scikit-learn
+    1.7's own sequence of NumPy calls (see pca_axis): bit-identical to sklearn (round 4)."""
     X = np.asarray(detections_nx3, dtype=np.float64)
-    Xc = X - X.mean(0)
-    w, V = np.linalg.eigh((Xc.T @ Xc) / (X.shape[0] - 1))
-    comps = V[:, np.argsort(w)[::-1]].T.copy()
-    for r in comps:
-        if r[np.argmax(np.abs(r))] < 0:
-            r *= -1
-    return comps
+    n, f = X.shape
+    mean = np.mean(X, axis=0)
+    if f <= 1000 and n >= 10 * f:
+        C = X.T @ X
+        C -= n * np.reshape(mean, (-1, 1)) * np.reshape(mean, (1, -1))
+        C /= n - 1
+        w, V = np.linalg.eigh(C)
+        Vt = np.flip(np.asarray(V), axis=1).T
+    else:
+        _, _, Vt = np.linalg.svd(X - mean, full_matrices=False)
+    signs = np.sign(Vt[np.arange(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])
+    return Vt * signs[:, None]
 
 
 def cdist(a, b):

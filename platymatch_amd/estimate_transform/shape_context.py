@@ -418,15 +418,16 @@ def pca_view(detections, transposed=False):
     return a if a.dtype == np.float64 else a.astype(np.float64)
 
 
-def pca_axis_host(X):
-    """sklearn.decomposition.PCA(n_components=3).fit(X).components_[0] (shape_context.py:162-165) restated in NumPy, call for call
-    as scikit-learn 1.7 computes it (sklearn/decomposition/_pca.py: _fit_full; svd_solver='auto'): for n_samples >= 10 n_features
-    the eigen-decomposition of the Gram matrix X.T @ X minus n mean mean^T (solver 'covariance_eigh'), otherwise LAPACK's SVD of the
-    centred data ('full'); components flipped so that each one's largest-magnitude entry is positive (svd_flip,
-    u_based_decision=False).  HOST code on purpose (round 4): the result hangs on BLAS's accumulation order inside X.T @ X and on
-    LAPACK's eigh — only the same NumPy calls on the same array reproduce the reference's axis to the BIT (verified against
-    sklearn itself on 3 500 random clouds of 4 .. 3 000 points, both solver branches and both memory orders:
-    tests/golden/gen_pca_axis.py); a device kernel (pm_pca_axis) gets within 9e-14.  The work is O(N) on 24 N bytes."""
+def pca_components_host(X):
+    """sklearn.decomposition.PCA(n_components=3).fit(X).components_ (3 x 3; shape_context.py:162-165 uses row 0, the widget's
+    PCA-only alignment, _dock_widget.py:722-731, all three) restated in NumPy, call for call as scikit-learn 1.7 computes it
+    (sklearn/decomposition/_pca.py: _fit_full; svd_solver='auto'): for n_samples >= 10 n_features the eigen-decomposition of the
+    Gram matrix X.T @ X minus n mean mean^T (solver 'covariance_eigh'), otherwise LAPACK's SVD of the centred data ('full');
+    every component flipped so that its largest-magnitude entry is positive (svd_flip, u_based_decision=False).  HOST code on
+    purpose (round 4): the result hangs on BLAS's accumulation order inside X.T @ X and on LAPACK's eigh — only the same NumPy
+    calls on the same array reproduce the reference's axes to the BIT (verified against sklearn itself on 3 500 random clouds of
+    4 .. 3 000 points, both solver branches and both memory orders: tests/golden/gen_pca_axis.py); the device kernels
+    (pm_pca_axis, pm_pca_components) get within 1e-13 .. 1e-11.  The work is O(N) on 24 N bytes."""
     X = np.asarray(X)
     n, f = X.shape
     mean = np.mean(X, axis=0)
@@ -438,8 +439,13 @@ def pca_axis_host(X):
         Vt = np.flip(np.asarray(V), axis=1).T              # rows by decreasing eigenvalue (eigh returns them ascending)
     else:
         _, _, Vt = np.linalg.svd(X - mean, full_matrices=False)
-    row = Vt[0]
-    return row * np.sign(row[np.argmax(np.abs(row))])
+    signs = np.sign(Vt[np.arange(Vt.shape[0]), np.argmax(np.abs(Vt), axis=1)])
+    return Vt * signs[:, None]
+
+
+def pca_axis_host(X):
+    """The first principal axis, PCA(n_components=3).fit(X).components_[0]: what get_unary orients every local frame by."""
+    return pca_components_host(X)[0]
 
 
 def get_unary(centroid, mean_distance, detections, type, transposed=False, x0=None):

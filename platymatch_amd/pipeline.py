@@ -719,14 +719,15 @@ def icp_sharded(be, moved, fix, iters, group=None):
 
 
 def pca_alignment(moving, fixed):
-    """The widget's PCA-only branch (_dock_widget.py:722-731): sklearn PCA(3).components_ of each (centred) cloud
-    -> (moving_transform 3 x 3, fixed_transform 3 x 3), exported by io.save_pca_transforms."""
-    be = GpuBackend()
-    mt = be.K.pca_components(be.cloud(moving))
-    ft = be.K.pca_components(be.cloud(fixed))
+    """The widget's PCA-only branch (_dock_widget.py:722-731): sklearn PCA(3).components_ of each cloud (the widget centres them
+    first; PCA centres again) -> (moving_transform 3 x 3, fixed_transform 3 x 3), exported by io.save_pca_transforms.  sklearn's
+    own NumPy calls on the caller's arrays (shape_context.pca_components_host: the reference's bits, O(N) host work); the device
+    kernel pm_pca_components (1e-11) remains a C-ABI entry."""
+    from .estimate_transform.shape_context import pca_components_host, pca_view
+    mt, ft = pca_components_host(pca_view(moving)), pca_components_host(pca_view(fixed))
     if nat.is_torch(moving):
-        return mt, ft
-    return mt.cpu().numpy(), ft.cpu().numpy()
+        return nat.to_dev(mt, dev=moving.device if moving.is_cuda else None), nat.to_dev(ft, dev=moving.device if moving.is_cuda else None)
+    return mt, ft
 
 
 class _SampleDraws:

@@ -20,7 +20,21 @@ def metrics_args(d):
 # ------------------------------------------------------------------------------------------------ oracle (CPU)
 def test_oracle_pca_components(oracle, nx):
     for t in ("02", "04"):
-        assert np.abs(oracle.pca_components(nx["pca_cloud_" + t].T) - nx["pca_components_" + t]).max() < 1e-12   # sklearn PCA
+        X = nx["pca_cloud_" + t]
+        centred = X - oracle.get_centroid(X, False)                       # the widget centres the clouds first (_dock_widget.py:723-724)
+        assert np.array_equal(oracle.pca_components(centred.transpose()), nx["pca_components_" + t])      # sklearn's bits (round 4)
+        assert np.abs(oracle.pca_components(X.T) - nx["pca_components_" + t]).max() < 1e-12
+
+
+def test_pca_alignment_is_sklearns_bit_for_bit(oracle, nx):
+    """pipeline.pca_alignment (the widget's PCA-only branch, _dock_widget.py:722-731): sklearn's own NumPy calls on the caller's
+    arrays, host code by design (the axes hang on BLAS / LAPACK rounding) — the reference's 3 x 3 matrices to the bit."""
+    from platymatch_amd.pipeline import pca_alignment
+    c02 = nx["pca_cloud_02"] - oracle.get_centroid(nx["pca_cloud_02"], False)
+    c04 = nx["pca_cloud_04"] - oracle.get_centroid(nx["pca_cloud_04"], False)
+    mt, ft = pca_alignment(c02, c04)
+    assert np.array_equal(mt, nx["pca_components_02"]) and np.array_equal(ft, nx["pca_components_04"])
+    assert mt.shape == (3, 3) and np.allclose(mt @ mt.T, np.eye(3), atol=1e-13)
 
 
 def test_oracle_metrics_and_cdist(oracle, nx):
@@ -39,11 +53,13 @@ def test_oracle_label_centroids(oracle, nx):
 
 # ------------------------------------------------------------------------------------------------ HIP path (GPU)
 @pytest.mark.gpu
-def test_gpu_pca_alignment(oracle, nx):
-    from platymatch_amd.pipeline import pca_alignment
-    mt, ft = pca_alignment(nx["pca_cloud_02"], nx["pca_cloud_04"])
-    assert np.abs(mt - nx["pca_components_02"]).max() < 1e-11 and np.abs(ft - nx["pca_components_04"]).max() < 1e-11
-    assert mt.shape == (3, 3) and np.allclose(mt @ mt.T, np.eye(3), atol=1e-13)
+def test_gpu_pca_components_kernel(oracle, nx):
+    """pm_pca_components (the C-ABI entry; the mirror itself takes the host route above): within 1e-11 of sklearn."""
+    from platymatch_amd import _kernels as K, _native as nat
+    for t in ("02", "04"):
+        got = K.pca_components(nat.to_dev(np.ascontiguousarray(nx["pca_cloud_" + t][:3]))).cpu().numpy()
+        assert np.abs(got - nx["pca_components_" + t]).max() < 1e-11
+        assert np.allclose(got @ got.T, np.eye(3), atol=1e-13)
 
 
 @pytest.mark.gpu
