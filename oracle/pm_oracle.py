@@ -191,7 +191,12 @@ def shape_context_counts(centroid, mean_distance, detections, type, transposed=F
     n = x.shape[1]
     c = _f64(np.asarray(centroid, dtype=np.float64).reshape(-1)[:3])
     if x0 is None:
-        x0 = pca_axis(x.T)
+        # the array the reference hands to sklearn (shape_context.py:151-165): the CALLER's array, transposed and cut as views —
+        # its memory layout reaches BLAS and decides the axis's last bits (a C- and an F-ordered copy of one cloud differ there)
+        view = np.asarray(detections)
+        view = view if transposed else view.transpose()
+        view = view[:, :3] if view.shape[1] == 4 else view
+        x0 = pca_axis(view)
     x0 = _f64(x0)
     nf = 4 if type == "fixed" else 2
     counts = np.zeros((nf, n, 360), dtype=np.int32)
