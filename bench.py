@@ -266,6 +266,8 @@ def main():
     mv_h, fx_h, start_h = synth(n)
     mov, fix, start = (nat.to_dev(x, dev=dev) for x in (mv_h, fx_h, start_h))
     be = P.GpuBackend(dev)
+    from platymatch_amd.estimate_transform.shape_context import pca_view
+    views = (pca_view(mv_h), pca_view(fx_h))
     bn, bm = P.shard_bounds(n, world), P.shard_bounds(m, world)
     r0, r1 = bn[rank], bn[rank + 1]
     U = torch.empty((8, r1 - r0, m), dtype=torch.float64, device=dev)     # this rank's cost rows, resident output
@@ -275,7 +277,9 @@ def main():
     def step(marks=None):
         if marks: marks[0].record()
         # one GPU: the two clouds' statistics on two streams; sharded: the pieces of the pair sum interleaved over the ranks
-        (cm, mdm, x0m), (cf, mdf, x0f) = P.statistics_of_both(be, mov, fix, group)
+        # (the PCA axis is sklearn's own NumPy calls on the host, run inside the step on the host arrays the clouds came from —
+        # what the boundary hands over; the O(N^2) statistics read the resident tensors)
+        (cm, mdm, x0m), (cf, mdf, x0f) = P.statistics_of_both(be, mov, fix, group, views)
         if marks: marks[1].record()
         sc_m = be.shape_context(mov, cm, mdm, x0m, 2, r0, r1 - r0)
         sc_f = be.shape_context(fix, cf, mdf, x0f, 4, bm[rank], bm[rank + 1] - bm[rank])
