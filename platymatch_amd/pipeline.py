@@ -125,7 +125,9 @@ class GpuBackend:
         from .estimate_transform.shape_context import pca_axis_host
         if view is None:
             view = xyz.cpu().numpy().transpose()
-        return nat.to_dev(pca_axis_host(view), dev=xyz.device).reshape(3).contiguous()
+        torch = nat.torch_mod()
+        host = torch.from_numpy(np.ascontiguousarray(pca_axis_host(view), dtype=np.float64).reshape(3)).pin_memory()
+        return host.to(xyz.device, non_blocking=True)     # queued behind this stream's launches: a pageable copy would make the host wait for them
 
     def stats(self, xyz, view=None):
         if view is None:
