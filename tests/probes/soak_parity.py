@@ -3,7 +3,7 @@
 run over a stream of fresh clouds for a time budget (a probe, not a test: it lives under tests/ because it calls the oracle).
 Per case (random sizes N != M, anisotropy, offset, scale, jitter; every fifth cloud on a half-integer lattice, which puts
 neighbours exactly on ring and sector edges and makes distances tie):
-  statistics    centroid and mean distance == oracle bits, PCA axis within 1e-12
+  statistics    centroid, mean distance and the product's PCA axis == oracle bits (the device's Jacobi axis kernel: within 1e-12, reported)
   descriptors   integer histograms (2 + 4 frames, tile path and general path) == oracle
   costs         the eight chi-square matrices == oracle float64 bit patterns
   registration  assignment vectors of all eight hypotheses, RANSAC inlier counts, every ICP correspondence == oracle;
@@ -22,7 +22,7 @@ import torch  # noqa: E402
 import oracle  # noqa: E402
 import platymatch_amd  # noqa: E402
 from platymatch_amd import _kernels as K, _native as nat  # noqa: E402
-from platymatch_amd.estimate_transform import perform_icp as pi  # noqa: E402
+from platymatch_amd.estimate_transform import perform_icp as pi, shape_context as SC  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 max_points = int(sys.argv[2]) if len(sys.argv) > 2 else 500
@@ -69,6 +69,9 @@ while time.perf_counter() < t_end:
             axis_err = float(min(np.abs(x0_g - x0_o).max(), np.abs(x0_g + x0_o).max()))
             if not same_stats:
                 fails.append(tag + ": statistics differ (%r vs %r)" % (md_g, md_o))
+            x0_p = SC.pca_axis_host(SC.pca_view(cloud))          # the product's axis (sklearn's computation on the caller's array)
+            if not (np.array_equal(x0_p, x0_o) or (np.isnan(x0_p).all() and np.isnan(x0_o).all())):
+                fails.append(tag + ": PCA axis of the product differs from the oracle's by %.1e" % float(np.abs(x0_p - x0_o).max()))
             # the axis of a (nearly) isotropic or degenerate cloud is ill-conditioned in any arithmetic: histograms are compared on
             # the ORACLE's axis, handed to both sides, so that a stage is judged on its own inputs
             counts["statistics"] += 1
