@@ -288,10 +288,11 @@ int pm_lsap_core_add(void *core, int k, const int32_t *cols, const double *costs
  * would any other feasible start.  May be called repeatedly (e.g. after pm_lsap_core_reprice added edges) as long as
  * pm_lsap_core_solve has not run.  max_bids > 0 bounds the work of this call; bids (may be NULL): bids placed so far. */
 int pm_lsap_core_auction(void *core, double eps0, double eps_min, double factor, long max_bids, long *bids);
-/* The same auction continued from a state produced elsewhere (round 4: the device's Jacobi rounds over the same core,
- * pm_lsap_auction_dev below): price[nc] (= -v) and assigned[nr] (-1 = unassigned; otherwise a column of that row's core edges,
+/* The same auction continued from a state produced elsewhere (any synchronous — Jacobi — rounds over the same core; the
+ * library ships none: a device form was simulated with this entry, tests/probes/auction_sim.py, and not built, DESIGN.md
+ * §4.5c): price[nc] (= -v) and assigned[nr] (-1 = unassigned; otherwise a column of that row's core edges,
  * no column twice — PM_ERR_INVALID_ARG if not).  The first phase (eps0) does not reset the assignment: only the unassigned rows
- * bid — the narrow, sequential tail of the device's last phase; further phases down to eps_min (if eps0 > eps_min) run as in
+ * bid — the narrow, sequential tail of the imported phase; further phases down to eps_min (if eps0 > eps_min) run as in
  * pm_lsap_core_auction.  Ends with the same tightening; pm_lsap_core_solve completes the rest. */
 int pm_lsap_core_auction_resume(void *core, const double *price, const int32_t *assigned, double eps0, double eps_min,
                                 double factor, long max_bids, long *bids);

@@ -327,10 +327,10 @@ struct Core {
     // max_bids (> 0) bounds the work: rows contesting near-equal columns raise prices by eps per bid (a "price war");
     // stopping early is harmless, the rows still unassigned simply stay free.  bids = work done.
     // RESUME (round 4; price_in / assigned_in not null): the auction continues from prices and a partial assignment produced
-    // elsewhere — the device's Jacobi rounds over the same core (pm_lsap_auction_dev.hip), which do the wide part of every
-    // eps phase (thousands of rows bidding at once) and leave the narrow, inherently sequential tails (eviction chains, price
-    // wars of a handful of rows) to this loop: the first phase here does NOT reset the assignment, only the rows still
-    // unassigned bid.  assigned_in[i] must be -1 or a column of row i's core edges, no column held twice (else INVALID_ARG).
+    // elsewhere — synchronous (Jacobi) rounds over the same core, which can do the wide part of an eps phase (thousands of
+    // rows bidding at once) and leave the narrow, inherently sequential tails (eviction chains, price wars of a handful of
+    // rows) to this loop; the library ships no such producer (a device form was simulated through this entry and not built,
+    // DESIGN.md §4.5c).  The first phase here does NOT reset the assignment, only the rows still unassigned bid.  assigned_in[i] must be -1 or a column of row i's core edges, no column held twice (else INVALID_ARG).
     long bids = 0;
     int auction(double eps0, double eps_min, double factor, long max_bids, const double *price_in = nullptr,
                 const int32_t *assigned_in = nullptr) {
