@@ -192,6 +192,16 @@ size_t pm_chi2_relaxed_workspace_bytes(int nM, int nF);
 double pm_chi2_relaxed_delta(void);
 int pm_chi2_cost8_relaxed(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
                           size_t matrix_stride, void *ws, size_t ws_bytes, int variant, void *stream);
+/* Listed entries of one pairing's two EXACT matrices (the bits of pm_chi2_cost_pair_sym's): out_natural[e], out_rolled[e] =
+ * entry (rows[e], cols[e]) of the natural-order matrix (U11, U12, U13, U14 for pairing 0..3) and of its rolled-order twin (U22,
+ * U21, U24, U23).  rows / cols / outputs: device, n_entries each; an index out of range yields NaN in both outputs.  What turns
+ * an assignment solved on the relaxed matrices into a certificate for the exact ones without building them: with duals (u, v)
+ * and assignment s optimal for the relaxed matrix R, |R - C| <= delta entrywise, the row duals retuned to u'_i = C[i][s(i)] -
+ * v[s(i)] keep every entry whose relaxed reduced cost exceeds 2 delta feasible for the exact matrix C; only the matched
+ * entries and the few below that threshold (+ the uniqueness margin) need their exact values (the Python mirror:
+ * lsap.certify_listed).  Same precondition as the pair build (symmetry flag 0). */
+int pm_chi2_entries_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, const int32_t *rows,
+                        const int32_t *cols, int n_entries, double *out_natural, double *out_rolled, void *stream);
 
 /* The same two calls with a caller-provided workspace (pm_chi2_sym_workspace_bytes, 16-byte aligned device memory), which lets
  * the kernel take most terms of the sparsely filled inner shells from a table: a descriptor value is count / total

@@ -6,6 +6,8 @@ torch, and launches on torch's current stream.  Clouds are float64 [3, N] contig
 """
 import os
 
+import numpy as np
+
 from . import _native as nat
 from ._native import NBINS, ICP_NSUMS, check, ptr
 
@@ -317,6 +319,26 @@ def chi2_cost8_relaxed(sc_m1, sc_f1, out=None, variant=1):
 def chi2_relaxed_delta():
     """Absolute per-entry error bound of chi2_cost8_relaxed against the exact cost (csrc/pm_chi2.hip: PM_CHI2_RELAX_DELTA)."""
     return float(nat.load().pm_chi2_relaxed_delta())
+
+
+def chi2_entries(sc_m1, sc_f1, pairing, rows, cols):
+    """Listed entries (rows[e], cols[e]) of pairing t's two EXACT matrices -> (natural-order values, rolled-order values), float64
+    GPU tensors [len(rows)] carrying the bits of chi2_cost_pair's matrices (pm_chi2_entries_sym).  rows / cols: integer arrays
+    (NumPy or torch) of equal length, every index in range (checked here: the kernel would answer NaN)."""
+    torch = _t()
+    a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
+    r = torch.as_tensor(np.ascontiguousarray(rows) if not nat.is_torch(rows) else rows).to(device=a.device, dtype=torch.int32).contiguous()
+    c = torch.as_tensor(np.ascontiguousarray(cols) if not nat.is_torch(cols) else cols).to(device=a.device, dtype=torch.int32).contiguous()
+    if r.dim() != 1 or r.shape != c.shape:
+        raise ValueError("rows and cols must be one-dimensional and of equal length")
+    k = int(r.numel())
+    out = torch.empty((2, k), dtype=torch.float64, device=a.device)
+    if k:
+        if int(r.min()) < 0 or int(r.max()) >= a.shape[0] or int(c.min()) < 0 or int(c.max()) >= b.shape[0]:
+            raise ValueError("entry index out of range")
+        check(nat.load().pm_chi2_entries_sym(ptr(a), a.shape[0], ptr(b), b.shape[0], int(pairing), ptr(r), ptr(c), k, ptr(out[0]), ptr(out[1]),
+                                             nat.stream_ptr()))
+    return out[0], out[1]
 
 
 def _sym_workspace(lib, nM, nF, device):

@@ -434,6 +434,42 @@ __global__ __launch_bounds__(256) void relaxed_rowsum_kernel(const double *__res
     out[i] = s;
 }
 
+// Listed entries of ONE pairing's two matrices, exact: entry e = (rows[e], cols[e]) of the natural-order matrix (U11, U12, U13,
+// U14 for pairing 0..3) and of its rolled-order twin (U22, U21, U24, U23) — the same operations in the same order as
+// chi2_sym_kernel's computed path (and hence its table path), so the values carry the exact build's bits.  One thread per
+// entry: what the relaxed mode's certificate evaluates the matched and the near-tight entries with (a few N of them).
+__global__ __launch_bounds__(256) void entries_sym_kernel(const double *__restrict__ scA, int nA, const double *__restrict__ scB, int nB,
+                                                          int t, const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
+                                                          int n_entries, double *__restrict__ out_nat, double *__restrict__ out_rol) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_entries) return;
+    const int i = rows[e], j = cols[e];
+    if ((unsigned int)i >= (unsigned int)nA || (unsigned int)j >= (unsigned int)nB) {
+        out_nat[e] = out_rol[e] = __builtin_nan("");
+        return;
+    }
+    const double *a = scA + (size_t)i * PM_NBINS, *b = scB + (size_t)j * PM_NBINS;
+    double sn = 0.0, sr = 0.0;
+    for (int g = 0; g < CH_STAGES; ++g) {
+        double T[CH_K];
+#pragma unroll
+        for (int p = 0; p < CH_K; ++p) {
+            const int q = (t == 0) ? p : (t == 1) ? (p + 6) % 12 : (t == 2) ? 11 - p : (17 - p) % 12;
+            double bq = b[g * CH_K + q];
+            bq = (bq == 0.0) ? CH_TINY : bq;
+            const double ap = a[g * CH_K + p];
+            const double df = ap - bq;
+            T[p] = div_pos(df * df, ap + bq);
+        }
+#pragma unroll
+        for (int p = 0; p < CH_K; ++p) sn = sn + T[p];
+#pragma unroll
+        for (int p = 0; p < CH_K; ++p) sr = sr + T[(p + 6) % 12];
+    }
+    out_nat[e] = 0.5 * sn;
+    out_rol[e] = 0.5 * sr;
+}
+
 // flag[0] |= 1 unless, bit for bit, sc2 = roll6(sc1), sc3 = reverse(sc1), sc4 = (5-q)(sc1) within every shell.
 // which: 0 = moving (frame 2 only), 1 = fixed (frames 2, 3, 4).  One thread per (row, bin).
 __global__ __launch_bounds__(256) void symmetry_check_kernel(const unsigned long long *__restrict__ s1,
@@ -639,6 +675,16 @@ extern "C" int pm_chi2_cost8_relaxed(const double *sc_m1, int nM, const double *
     if (variant == 2)
         return pm::chi2_sym_launch<4, 3, -1, 64, true>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta, sumA, sumB);
     return pm::chi2_sym_launch<4, 2, -1, pm::CH_TL, true>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta, sumA, sumB);
+}
+
+extern "C" int pm_chi2_entries_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, const int32_t *rows,
+                                   const int32_t *cols, int n_entries, double *out_natural, double *out_rolled, void *stream) {
+    if (!sc_m1 || !sc_f1 || nM <= 0 || nF <= 0 || pairing < 0 || pairing > 3 || n_entries < 0) return PM_ERR_INVALID_ARG;
+    if (n_entries == 0) return PM_OK;
+    if (!rows || !cols || !out_natural || !out_rolled) return PM_ERR_INVALID_ARG;
+    pm::entries_sym_kernel<<<(unsigned int)((n_entries + 255) / 256), 256, 0, (hipStream_t)stream>>>(sc_m1, nM, sc_f1, nF, pairing, rows, cols,
+                                                                                                 n_entries, out_natural, out_rolled);
+    return pm::launch_status();
 }
 
 extern "C" int pm_chi2_cost8_sym_ws(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,

@@ -308,6 +308,92 @@ def certify(M, u, v, col4row, info=None, min_eps=0.0):
     return rc == 1
 
 
+def certify_listed(M, u, v, col4row, exact_entries, cost_delta, infos=None):
+    """(u, v, col4row) solved on a RELAXED matrix M (nr <= nc; every entry within cost_delta of the exact matrix C's, e.g.
+    pm_chi2_cost8_relaxed's): is col4row the certified UNIQUE optimum of C — of each of the exact matrices exact_entries answers
+    for — without C ever being built?
+    exact_entries(rows, cols) -> tuple of float64 arrays: the listed entries of each exact matrix (hypothesis, twin).
+    With the row duals retuned to the exact matched entries, u'_i = C[i][s(i)] - v[s(i)] (tight to the bit), an unlisted entry's
+    exact reduced cost is at least its relaxed one minus 2 cost_delta.  So one pass over M (pm_lsap_certificate) that lists the
+    entries with relaxed reduced cost <= eps_collect + 2 cost_delta leaves every OTHER entry feasible for C and further than
+    eps_collect from tight; the matched and the listed entries (a few N) get their exact values, and feasibility, the slack
+    bound, the free columns' prices and the uniqueness check (pm_lsap_unique) are decided on those exactly as lsap.certify
+    decides them on an exact matrix — same margins, no 2 N delta anywhere.
+    -> list of verdicts, one per exact matrix; infos (optional list of dicts) receive certify's keys."""
+    lib = nat.load()
+    nr, nc = M.shape
+    u, v = np.asarray(u, dtype=np.float64), np.asarray(v, dtype=np.float64)
+    c4r = np.ascontiguousarray(col4row, dtype=np.int32)
+    scale = max(float(np.abs(u).max()), float(np.abs(v).max()), 1e-300)
+    delta, eps_collect = REL_DELTA * scale, REL_EPS_COLLECT * scale
+    widen = 2.0 * float(cost_delta)
+    cap = 8 * nc + 1024
+    viol, loose, tight, red, _ = M.certificate(u, v, c4r, delta, eps_collect + widen + delta, cap)
+    n_out = None
+
+    def verdicts(flag, **keys):
+        out = [flag] * (n_out or (len(infos) if infos else 1))
+        for i in (infos or []):
+            if i is not None:
+                i.update(optimal=False, **keys)
+        return out
+
+    if viol or loose or tight is None:
+        return verdicts(False, violations=viol, loose=loose, tight=None if tight is None else len(tight))
+    rows_all = np.concatenate([np.arange(nr, dtype=np.int32), tight[:, 0].astype(np.int32)])
+    cols_all = np.concatenate([c4r, tight[:, 1].astype(np.int32)])
+    exact = exact_entries(rows_all, cols_all)
+    n_out = len(exact)
+    v_free = 0.0
+    free_ok = True
+    if nc > nr:
+        free = np.ones(nc, dtype=bool)
+        free[c4r] = False
+        v_free = float(v[free].min())
+        free_ok = not (float(v.max()) - v_free > delta)     # a matched column priced above a free one: not optimal for nr < nc
+    out = []
+    for k, C in enumerate(exact):
+        info = infos[k] if infos and k < len(infos) and infos[k] is not None else {}
+        C = np.asarray(C, dtype=np.float64)
+        info.update(listed=int(len(tight)), delta=delta, optimal=False)
+        if C.shape != rows_all.shape or not np.isfinite(C).all():
+            out.append(False)
+            continue
+        u2 = C[:nr] - v[c4r]                                  # the exact matched entries are tight to the bit
+        if float(np.abs(u2 - u).max()) > widen + delta:       # the premise |M - C| <= cost_delta, checked where C is known
+            info["cost_delta_exceeded"] = float(np.abs(u2 - u).max())
+            out.append(False)
+            continue
+        redC = (C[nr:] - v[tight[:, 1]]) - u2[tight[:, 0]]
+        if len(redC) and float(np.abs(redC - red).max()) > 2.0 * widen + delta:      # the same premise on the listed entries
+            info["cost_delta_exceeded"] = float(np.abs(redC - red).max())
+            out.append(False)
+            continue
+        # Listed entries may come out (slightly) negative under the retuned duals — by at most 2 cost_delta.  As in certify, that
+        # goes into the bound: another assignment costs (the reduced costs of its new entries) more than this one, its negative
+        # entries can take back at most sum over rows of the row's worst one = bound, so an alternative that uses ANY entry
+        # above eps > bound is dearer, and one that stays within eps of tight is an alternating cycle pm_lsap_unique would find.
+        worst = np.zeros(nr)
+        np.minimum.at(worst, tight[:, 0], redC)
+        bound = float(-worst.sum())
+        eps = max(REL_EPS_FLOOR * scale, EPS_SAFETY * bound)
+        info.update(violations=int((redC < -delta).sum()), loose=0, slack_bound=bound, eps=eps)
+        if not free_ok or eps > eps_collect:
+            out.append(False)
+            continue
+        info["optimal"] = bound <= delta * nr                 # (to the rounding bound, as certify reports it; the verdict below does not need it)
+        keep = redC <= eps
+        t = np.ascontiguousarray(tight[keep], dtype=np.int32)
+        info["tight_within_eps"] = int(keep.sum())
+        info["_tight_edges"] = t
+        rc = lib.pm_lsap_unique(nr, nc, c4r.ctypes.data, np.ascontiguousarray(v).ctypes.data, v_free, eps, t.ctypes.data, int(len(t)))
+        if rc < 0:
+            nat.check(rc)
+        info["unique"] = rc == 1
+        out.append(rc == 1)
+    return out
+
+
 RESOLVE_MAX_BLOCK_ROWS = 4096      # largest set of rows (all near-tied groups together) settled by the dense algorithm on their block
 
 
@@ -684,20 +770,27 @@ def solve_on_device(U, info=None, force=False):
 DENSE_FALLBACK_MAX_ENTRIES = 1 << 30      # matrices above this many entries are never handed to the dense host solver (hours)
 
 
-def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=True, accept_near_ties=False, min_eps=0.0):
+def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=True, accept_near_ties=False, min_eps=0.0,
+                         exact_entries=None, cost_delta=0.0):
     """One hypothesis and its twin (the same terms summed in another order: U11/U22, U12/U21, U13/U24, U14/U23), both float64
     GPU matrices [N, M]: the hypothesis is solved on its sparse core and certified; the twin first tries its sibling's duals —
     accepted only if they are a certified unique optimum of the twin's OWN entries — and is solved on its own otherwise.
     -> [(row_ind, col_ind) or None, (row_ind, col_ind) or None]; None only with allow_host=False (or a matrix too large for
     the dense solver): the hypothesis could not be certified and the dense host solver was not allowed.
     accept_near_ties: where the dense solver is not an option, take an assignment that is certified OPTIMAL but not proven
-    unique (an alternative within ~1e-11 of the total cost exists; SciPy might return either) instead of None."""
+    unique (an alternative within ~1e-11 of the total cost exists; SciPy might return either) instead of None.
+    exact_entries / cost_delta: U_h is a relaxed matrix within cost_delta of the exact one; exact_entries(rows, cols) -> (exact
+    entries of the hypothesis's matrix, of the twin's) for index arrays into the n x m matrices.  The assignment solved on U_h
+    is then certified against the EXACT matrices on their listed entries (certify_listed); an answer that does not certify
+    comes back as None (the caller rebuilds that pairing exactly); U_twin is not read."""
     n, m = U_h.shape
     info_h = {} if info_h is None else info_h
     info_twin = {} if info_twin is None else info_twin
     host_ok = allow_host and n * m <= DENSE_FALLBACK_MAX_ENTRIES
     refused = "uncertified (dense solver not allowed)" if not allow_host else "uncertified (too large for the dense solver)"
     if min(n, m) < DEVICE_MIN_ROWS:
+        if exact_entries is not None:
+            return [None, None]                              # (a relaxed matrix is never handed to the dense solver)
         info_h["route"] = info_twin["route"] = "host"
         return [linear_sum_assignment(U_h.cpu().numpy()), linear_sum_assignment(U_twin.cpu().numpy())]
     out = [None, None]
@@ -705,6 +798,20 @@ def solve_pair_on_device(U_h, U_twin, info_h=None, info_twin=None, allow_host=Tr
     W = DeviceMatrix(U_h if n <= m else transposed(U_h))
     Wt = None
     sol = solve_core(W, info_h)
+    if exact_entries is not None:
+        # U_h is a RELAXED matrix (its twin's relaxed matrix is the same numbers): one solve, then the exact matrices' certificate
+        # on the listed entries (certify_listed) for the hypothesis and for the twin; whatever does not certify stays None
+        if sol is None:
+            return out
+        fetch = exact_entries if n <= m else (lambda rows, cols: exact_entries(cols, rows))      # (the solve ran on the transpose)
+        ok = certify_listed(W, *sol, exact_entries=fetch, cost_delta=cost_delta, infos=[info_h, info_twin])
+        if ok[0]:
+            info_h["route"] = "device"
+            out[0] = _answer(sol[2], n, m)
+        if len(ok) > 1 and ok[1]:
+            info_twin["route"] = "device (sibling's duals certified)"
+            out[1] = _answer(sol[2], n, m)
+        return out
     if sol is not None and certify(W, *sol, info=info_h, min_eps=min_eps):
         info_h["route"] = "device"
         out[0] = _answer(sol[2], n, m)
@@ -758,7 +865,8 @@ def _resolved(W, sol, info, out, slot, n, m):
 PIPELINED_PRIORITY = -1
 
 
-def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False, ready=None, min_eps=0.0, exact_rebuild=None):
+def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False, ready=None, min_eps=0.0, exact_rebuild=None,
+                          exact_entries=None, cost_delta=0.0):
     """The widget's eight assignments (_dock_widget.py:604-611) for U8 [8, N, M] on the GPU: hypotheses 11, 12, 13, 14 are
     solved (four host threads drive their core solves and kernels concurrently), each together with its twin (22, 21, 24,
     23: solve_pair_on_device).  -> list of eight (row_ind, col_ind).
@@ -799,15 +907,24 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
             if exact_rebuild is None:
                 out[h], out[twin] = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], allow_host, accept_near_ties, min_eps)
             else:
-                # RELAXED matrices (pm_chi2_cost8_relaxed: every entry within delta of the exact cost, min_eps = 2 min(N, M) delta):
-                # an answer counts only if it is a certified UNIQUE optimum with that margin — then it is the exact matrix's too.
+                # RELAXED matrices (pm_chi2_cost8_relaxed: every entry within cost_delta of the exact cost).  An answer counts only
+                # if it is proven to be the EXACT matrix's unique optimum: with exact_entries(h) (-> the function that answers the
+                # listed entries of hypothesis h's and its twin's exact matrices) by the certificate on the exact matrix's listed
+                # entries (certify_listed: the exact mode's own margins); without it by a uniqueness margin of min_eps = 2 min(N,
+                # M) delta on the relaxed matrix (the round-4 first form: at 50 000 nuclei that margin is rarely there).
                 # Anything else (a near-tie inside the margin, ties, non-finite costs) has this pairing's two matrices rebuilt by
                 # the exact kernel, in place, and solved as usual.
-                got = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], False, False, min_eps)
+                if exact_entries is not None:
+                    got = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], False, False, exact_entries=exact_entries(h),
+                                               cost_delta=cost_delta)
+                    how = "relaxed (solved on the relaxed matrix, certified on the exact matrix's listed entries)"
+                else:
+                    got = solve_pair_on_device(U8[h], U8[twin], infos[h], infos[twin], False, False, min_eps)
+                    how = "relaxed (certified with margin %.1e)" % min_eps
                 ok = all(g is not None and i.get("route") in ("device", "device (sibling's duals certified)") for g, i in zip(got, (infos[h], infos[twin])))
                 if ok:
                     for i in (infos[h], infos[twin]):
-                        i["cost_mode"] = "relaxed (certified with margin %.1e)" % min_eps
+                        i["cost_mode"] = how
                 else:
                     infos[h].clear()
                     infos[twin].clear()

@@ -352,6 +352,7 @@ def gather_fixed_descriptors(be, sc_m_loc, sc_f_loc, bounds, group=None):
 
 
 STATS_ON_TWO_STREAMS = True
+RELAXED_CERTIFY_ON_EXACT_ENTRIES = True     # cost_mode='relaxed': certify on the exact matrix's listed entries (lsap.certify_listed); False: a 2 N delta margin on the relaxed one
 RELAXED_MIN_POINTS = 1024      # cost_mode='relaxed' below this: exact (the dense host solver takes such matrices, no certificate to lean on)
 
 
@@ -916,9 +917,17 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                 from .lsap import solve_eight_on_device
                 from ._kernels import PAIRINGS
                 sc_m1, sc_f1 = sc_m[0], sc_f[0]
+                pairing_of = {p[0]: t for t, p in enumerate(PAIRINGS)}
+
+                def exact_entries(h):
+                    # (rows, cols) -> the listed entries of hypothesis h's exact matrix and of its twin's (pm_chi2_entries_sym)
+                    def fetch(rows, cols):
+                        return tuple(x.cpu().numpy() for x in be.K.chi2_entries(sc_m1, sc_f1, pairing_of[h], rows, cols))
+                    return fetch
                 lsa = solve_eight_on_device(U, info=a_info, accept_near_ties=accept_near_ties,
+                                            exact_entries=exact_entries if RELAXED_CERTIFY_ON_EXACT_ENTRIES else None, cost_delta=relaxed_delta,
                                             min_eps=2.0 * min(mov.shape[1], fix.shape[1]) * relaxed_delta,
-                                            exact_rebuild=lambda h: be.K.chi2_cost_pair_into(sc_m1, sc_f1, [p[0] for p in PAIRINGS].index(h), U))
+                                            exact_rebuild=lambda h: be.K.chi2_cost_pair_into(sc_m1, sc_f1, pairing_of[h], U))
                 if any(a is None for a in lsa):
                     raise RuntimeError("a hypothesis could not be assigned (see accept_near_ties)")
             else:

@@ -358,3 +358,71 @@ def test_near_ties_are_settled_on_their_blocks_by_the_dense_algorithm():
     assert not L.certify(M, *sol, info=info) and info["optimal"]
     got = L.resolve_near_ties(M, sol, info)
     assert got is None or (info["resolved_groups"] == [2] and np.array_equal(got, scipy_lsa(R2)[1]))
+
+
+@pytest.mark.parametrize("shape", [(300, 300), (257, 300), (300, 257), (900, 900)])
+def test_a_solve_on_a_perturbed_matrix_is_certified_against_the_exact_matrix_on_its_listed_entries(shape):
+    """lsap.certify_listed — what cost_mode='relaxed' rests on: the assignment is solved on R (every entry within cost_delta
+    of the exact matrix C), then proven to be C's unique optimum from C's values at the matched and the near-tight entries
+    alone (C is never read elsewhere: the entry function counts what it is asked for).  The verdict must be SciPy's
+    answer on C whenever it is given."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(shape[0] * 3 + shape[1])
+    n, m = shape
+    C = rng.random(shape) * rng.random((1, m)) + 0.3 * rng.random((n, 1)) + 0.05 * rng.random(shape)
+    cost_delta = 1e-11                                             # (a hundred times the solver's own tolerance)
+    R = C + rng.uniform(-cost_delta, cost_delta, size=shape)
+    T = (lambda X: X if n <= m else X.T)
+    M = HostMatrix(T(R))
+    sol = L.solve_core(M)
+    assert sol is not None
+    asked = []
+
+    def entries(rows, cols):
+        asked.append(len(rows))
+        return (T(C)[rows, cols], T(C)[rows, cols] + 0.0)
+
+    infos = [{}, {}]
+    ok = L.certify_listed(M, *sol, exact_entries=entries, cost_delta=cost_delta, infos=infos)
+    assert ok == [True, True], infos
+    assert asked and asked[0] < 12 * max(n, m)                     # a few entries per row, not the matrix
+    got = L._answer(sol[2], n, m)
+    r, c = scipy_lsa(C)
+    assert np.array_equal(got[0], r) and np.array_equal(got[1], c)
+    # the premise is checked where C is known: an entry function that contradicts cost_delta is refused
+    bad = L.certify_listed(M, *sol, exact_entries=lambda rows, cols: (T(C)[rows, cols] + 1e-9 * (np.arange(len(rows)) == 5),),
+                           cost_delta=cost_delta, infos=[{}])
+    assert bad == [False]
+
+
+def test_listed_certificate_refuses_what_the_perturbation_decided():
+    """C has two optima `gap` apart (a 2-cycle, engineered from the optimal duals as above).  The perturbed matrix R breaks the
+    tie one way or the other and its own certificate would call the result unique; certified against C's listed entries the
+    answer is refused when gap is inside the exact mode's margin, refused when R picked C's loser, and accepted — and SciPy's —
+    when the gap is well above the margin and R picked the winner."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(21)
+    n = 150
+    base = rng.random((n, n)) + 0.5
+    u, v, c = L.solve_core(HostMatrix(base))
+    i1, i2 = 5, 90
+    cost_delta = 1e-9
+    for gap, push in ((0.0, +1), (1e-14, -1), (4e-10, -1), (4e-10, +1), (1e-6, +1)):
+        C = base.copy()
+        C[i1, c[i2]] = (u[i1] + v[c[i2]]) + gap / 2
+        C[i2, c[i1]] = (u[i2] + v[c[i1]]) + gap / 2
+        R = C.copy()
+        R[i1, c[i2]] += push * 0.9 * cost_delta          # push = -1: the perturbation makes C's loser (the swap) the cheaper one in R
+        R[i2, c[i1]] += push * 0.9 * cost_delta
+        M = HostMatrix(R)
+        sol = L.solve_core(M)
+        info = {}
+        ok = L.certify_listed(M, *sol, exact_entries=lambda rows, cols: (C[rows, cols],), cost_delta=cost_delta, infos=[info])[0]
+        rs, cs = scipy_lsa(C)
+        swapped = not np.array_equal(sol[2], c)
+        if gap <= 1e-14:
+            assert not ok, (gap, push, info)                          # a tie of the exact matrix: never certified
+        elif push < 0:
+            assert swapped and not ok, (gap, push, info)              # R chose the assignment that is NOT C's optimum
+        else:
+            assert ok and np.array_equal(sol[2], cs), (gap, push, info)

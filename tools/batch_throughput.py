@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--icp", type=int, default=50)
     ap.add_argument("--json", default=None)
     ap.add_argument("--sequential-too", action="store_true", help="also time workers=1 (one GPU only)")
+    ap.add_argument("--cost-mode", default="exact", choices=("exact", "relaxed"), help="estimate_transform(cost_mode=...)")
     ap.add_argument("--unseeded", action="store_true", help="no RANSAC seeds: index sets drawn on the device (the default for callers who do not seed)")
     args = ap.parse_args()
     pi.VERBOSE = False
@@ -70,7 +71,7 @@ def main():
         timings = {}
         t = time.perf_counter()
         out = P.estimate_transform_batch(pairs, workers=w, seeds=None if args.unseeded else list(range(len(pairs))), group=group, timings=timings,
-                                         ransac_trials=args.trials, ransac_error=16, icp_iterations=args.icp)
+                                         ransac_trials=args.trials, ransac_error=16, icp_iterations=args.icp, cost_mode=args.cost_mode)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
         err = max(np.linalg.norm(np.asarray(o[1]) @ np.asarray(o[0]) - A) / np.linalg.norm(A) for o, A in zip(out, truth))
@@ -85,7 +86,7 @@ def main():
             ref = flat.clone()
             dist.broadcast(ref, src=0)
             assert torch.equal(flat, ref), "ranks disagree on the batch results"
-        run = {"workers_per_gpu": w, "n_gpus": world, "ransac_index_sets": "device sampler (unseeded)" if args.unseeded else "NumPy stream (seeded)", "pairs": len(pairs), "seconds": dt, "registrations_per_s": len(pairs) / dt,
+        run = {"cost_mode": args.cost_mode, "workers_per_gpu": w, "n_gpus": world, "ransac_index_sets": "device sampler (unseeded)" if args.unseeded else "NumPy stream (seeded)", "pairs": len(pairs), "seconds": dt, "registrations_per_s": len(pairs) / dt,
                "worst_rel_error_vs_ground_truth": err,
                "stage_seconds_summed_over_this_ranks_pairs": split,
                "per_pair": [{"pair": k, "n": sizes[k], **{a: round(b, 4) for a, b in timings[k].items()}} for k in sorted(timings)]}
