@@ -403,7 +403,7 @@ def main():
 
     # Second extra, OUTSIDE the timed region and never the headline: the relaxed-rounding cost build (opt-in experiment,
     # pm_chi2_cost8_relaxed / estimate_transform(cost_mode='relaxed'): no bit identity, every entry within delta of the exact one,
-    # used only behind a uniqueness certificate of margin 2 N delta).  Launch time by HIP events on the launching stream.
+    # used only behind a certificate against the exact matrix's listed entries).  Launch time by HIP events on the launching stream.
     relaxed_extra = None
     if world == 1 and symmetric[0] and not args.no_assignment:
         ts = []
@@ -414,12 +414,30 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
+        # the eight assignments solved on the relaxed matrices and certified against the EXACT matrices on their matched and
+        # near-tight entries (pm_chi2_entries_sym, lsap.certify_listed): bounded like the leg above, nothing is rebuilt here
+        pairing_of = {p[0]: t for t, p in enumerate(K.PAIRINGS)}
+        a1, b1 = sc_m_last[0][0], sc_f_last[0][0]
+
+        def exact_entries(h):
+            return lambda rows, cols: tuple(x.cpu().numpy() for x in K.chi2_entries(a1, b1, pairing_of[h], rows, cols))
+        r_info = {}
+        torch.cuda.synchronize()
+        t_rs = time.perf_counter()
+        lsa_r = L.solve_eight_on_device(U, info=r_info, allow_host=False, exact_entries=exact_entries, cost_delta=K.chi2_relaxed_delta(),
+                                        exact_rebuild=lambda h: None)
+        t_rs = time.perf_counter() - t_rs
+        on_relaxed = [str(d.get("cost_mode", "")).startswith("relaxed") for d in r_info.get("details", [])]
         relaxed_extra = {"kernel": "pm::chi2_sym_kernel<4,3,-1,64,RELAX>", "launch_ms": min(ts), "exact_launch_ms": chi2_ms, "speedup": chi2_ms / min(ts),
-                         "per_entry_error_bound": K.chi2_relaxed_delta(), "certificate_margin_needed": 2.0 * min(n, m) * K.chi2_relaxed_delta(),
+                         "per_entry_error_bound": K.chi2_relaxed_delta(),
+                         "assignment_seconds": t_rs, "hypotheses_certified_on_exact_entries": int(sum(on_relaxed)),
+                         "equal_to_exact_matrices_assignments": [bool(ok and x is not None and y is not None and np.array_equal(x[1], y[1]))
+                                                                 for ok, x, y in zip(on_relaxed, lsa_r, lsa)],
                          "note": "opt-in experiment, NOT the product default and NOT in `value`: U = 0.5 (sum a + sum b) - 2 sum ab/(a+b), "
-                                 "v_rcp_f64 + one Newton step, four running sums per row (the twins coincide); an assignment from these "
-                                 "matrices counts only if certified unique with the margin above, else that pairing is rebuilt exactly "
-                                 "(profiles/r04_chi2_relaxed.txt)"}
+                                 "v_rcp_f64 + one Newton step, four running sums per row (the twins coincide); an assignment solved on "
+                                 "these matrices counts only once it is proven to be the exact matrix's unique optimum from the exact "
+                                 "values of its matched and near-tight entries (a few N of them, evaluated by a small kernel), else that "
+                                 "pairing is rebuilt exactly (profiles/r04_chi2_relaxed.txt)"}
         K.chi2_cost8_frame1(sc_m_last[0][0], sc_f_last[0][0], out=U)          # leave the exact matrices behind
 
     if rank == 0:

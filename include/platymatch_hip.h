@@ -185,8 +185,9 @@ int pm_chi2_cost_pair_sym(const double *sc_m1, int nM, const double *sc_f1, int 
  * the reference's scalar loop (shape_context.py:88-99), every entry within pm_chi2_relaxed_delta() (absolute) of it.
  * U = 0.5 (sum a + sum b) - 2 sum_k a_k b_k / (a_k + b_k): four running sums per row instead of eight (the twins U11/U22,
  * U12/U21, U13/U24, U14/U23 coincide once the order of summation is free and are written twice), v_rcp_f64 + one Newton step
- * instead of a correctly rounded division.  An assignment read off these matrices is the exact matrices' only if its
- * uniqueness margin exceeds 2 min(N, M) delta (the Python mirror: lsap.certify(min_eps=...)).  variant 0: every term computed;
+ * instead of a correctly rounded division.  An assignment solved on these matrices counts only once it is proven to be the
+ * exact matrices': by pm_chi2_entries_sym below (the Python mirror: lsap.certify_listed), or by a uniqueness margin above
+ * 2 min(N, M) delta on the relaxed matrix itself (lsap.certify(min_eps=...)).  variant 0: every term computed;
  * 1 / 2: sparsely filled shells from a 94 x 94 / 64 x 64 table of relaxed terms. */
 size_t pm_chi2_relaxed_workspace_bytes(int nM, int nF);
 double pm_chi2_relaxed_delta(void);

@@ -1109,7 +1109,8 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
         if timings is not None:
             timings[k] = det["timing"]
         if reports is not None:
-            reports[k] = {"routes": det.get("assignment", {}).get("routes"), "mode": det.get("assignment", {}).get("mode")}
+            reports[k] = {"routes": det.get("assignment", {}).get("routes"), "mode": det.get("assignment", {}).get("mode"),
+                          "cost_modes": [d.get("cost_mode") for d in det.get("assignment", {}).get("details", [])]}
         return out
 
     if on_gpu and workers > 1 and len(ks) > 1 and "icp_one_launch" not in kwargs:
@@ -1142,7 +1143,8 @@ def estimate_transform_batch(pairs, workers=8, seeds=None, group=None, timings=N
     give); unseeded pairs draw from NumPy's global generator one after the other.
     pairs: iterable of (moving, fixed); seeds: optional per-pair RANSAC seeds; timings: optional dict, filled with
     {pair index: wall-clock split of its stages} for the pairs this process registered (adds stream synchronisations);
-    reports: optional dict, filled with {pair index: {"routes": how each of its eight assignments was obtained}}.
+    reports: optional dict, filled with {pair index: {"routes": how each of its eight assignments was obtained, "cost_modes": with
+    cost_mode='relaxed', whether each was certified on the relaxed build or after an exact rebuild}}.
     -> list of (A_sc, A_icp, inliers) in input order, each identical to a stand-alone estimate_transform call."""
     import torch
     pairs = list(pairs)
