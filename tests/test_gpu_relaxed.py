@@ -143,3 +143,26 @@ def test_listed_certificate_at_a_size_where_the_wide_margin_fails(g):
     g.L.solve_eight_on_device(U, info=info2, allow_host=False, min_eps=2.0 * n * delta, exact_rebuild=lambda h: None)
     print("listed certificate: 8 of 8; 2 N delta margin: %d of 8 (margin %.1e); exact entries evaluated per pairing: %s"
           % (sum(d["cost_mode"].startswith("relaxed") for d in info2["details"]), 2.0 * n * delta, asked))
+
+
+def test_tied_clouds_fall_back_to_the_exact_build_and_give_the_exact_modes_answer(g):
+    """Duplicate nuclei make whole cost rows equal: every hypothesis has tied optima, nothing can be certified unique on the relaxed
+    build, so each pairing is rebuilt exactly and goes the exact mode's way (SciPy's algorithm on the host settles the ties) —
+    the two modes must return the same assignment vectors, inlier counts and transforms."""
+    n = 1400
+    mv, fx, _ = synth_pair(n, 23)
+    mv, fx = mv.copy(), fx.copy()
+    mv[:, 100:112] = mv[:, 200:212]                     # twelve duplicated nuclei in the moving cloud
+    fx[:, 300:306] = fx[:, 900:906]                     # six in the fixed one
+    kw = dict(ransac_trials=300, icp_iterations=4, seed=3)
+    de, dr = {}, {}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", g.P.EdgeGuardWarning)
+        a = g.P.estimate_transform(mv, fx, details=de, **kw)
+        b = g.P.estimate_transform(mv, fx, details=dr, cost_mode='relaxed', **kw)
+    for h in range(8):
+        assert np.array_equal(de["lsa"][h][0], dr["lsa"][h][0]) and np.array_equal(de["lsa"][h][1], dr["lsa"][h][1]), h
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    modes = [d.get("cost_mode", "") for d in dr["assignment"]["details"]]
+    assert all(x.startswith("exact (rebuilt") for x in modes), modes
