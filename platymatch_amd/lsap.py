@@ -252,6 +252,88 @@ class DeviceMatrix:
         return viol, loose, tight[:n_tight].cpu().numpy(), red[:n_tight].cpu().numpy(), bound
 
 
+class FilteredMatrix:
+    """An APPROXIMATE dense matrix as a filter in front of exact evaluation: `approx` (a DeviceMatrix, or the
+    tests' NumPy double) holds a matrix whose every entry is within cost_delta of the exact one, which is never built;
+    exact_entries(rows, cols) -> tuple of float64 arrays answers listed entries of the exact matrix (first array: the hypothesis
+    this matrix is solved for; further arrays: its twin(s), used by certify_listed).  The solver's queries all ask WHICH entries
+    have a small reduced cost: the approximate matrix selects them, every cost that reaches the sparse core or a verdict is exact.
+      row_select        the k entries the approximate matrix ranks first, with their exact costs, re-sorted by exact reduced cost
+      diagonal/entries  exact
+      col_min           approximate (a starting price, nothing rests on it)
+      threshold_select  ALL non-matched entries whose approximate reduced cost is below eps_collect + 2 cost_delta (so: every entry
+                        whose exact reduced cost is below eps_collect), per row, with exact costs — what solve_core's last pricing
+                        rounds and the certificate work on
+      certificate       the listing pass of certify_listed (negative reduced costs are listed, not counted as violations)."""
+
+    LIST_CAPACITY_PER_COLUMN = 64
+
+    def __init__(self, approx, exact_entries, cost_delta):
+        self.A = approx
+        self.shape = tuple(approx.shape)
+        self.exact_entries = exact_entries
+        self.cost_delta = float(cost_delta)
+        self.exact_evaluated = 0
+
+    def _exact(self, rows, cols):
+        self.exact_evaluated += int(len(rows))
+        return np.asarray(self.exact_entries(np.ascontiguousarray(rows, dtype=np.int32), np.ascontiguousarray(cols, dtype=np.int32))[0],
+                          dtype=np.float64)
+
+    def col_min(self):
+        return self.A.col_min()
+
+    def diagonal(self, n):
+        i = np.arange(n, dtype=np.int32)
+        return self._exact(i, i)
+
+    def entries(self, rows, cols):
+        return self._exact(rows, cols)
+
+    def row_select(self, v, k):
+        cols, costs, bad = self.A.row_select(v, k)
+        if bad:
+            return cols, costs, bad
+        valid = cols >= 0
+        rows = np.broadcast_to(np.arange(cols.shape[0], dtype=np.int32)[:, None], cols.shape)
+        exact = self._exact(rows[valid], cols[valid])
+        if not np.isfinite(exact).all():
+            return cols, costs, 1
+        costs = np.where(valid, 0.0, np.inf)
+        costs[valid] = exact
+        red = costs - (0.0 if v is None else np.asarray(v)[np.maximum(cols, 0)])
+        order = np.argsort(np.where(valid, red, np.inf), axis=1, kind="stable")
+        return np.take_along_axis(cols, order, axis=1), np.take_along_axis(costs, order, axis=1), 0
+
+    def certificate(self, u, v, col4row, delta, eps, cap):
+        cap = max(int(cap), self.LIST_CAPACITY_PER_COLUMN * self.shape[1])
+        _, _, tight, red, _ = self.A.certificate(u, v, col4row, 1.0, eps, cap)      # (delta = 1: nothing is set aside as a violation)
+        return 0, 0, tight, red, 0.0
+
+    def threshold_select(self, u, v, col4row):
+        """-> (cols [nr, kmax] int32, -1 padded; exact costs [nr, kmax], inf padded) of every non-matched entry whose EXACT reduced
+        cost can be below REL_EPS_COLLECT x scale, or None if the list overflowed."""
+        nr, nc = self.shape
+        scale = max(float(np.abs(u).max()), float(np.abs(v).max()), 1e-300)
+        tau = REL_EPS_COLLECT * scale + 2.0 * self.cost_delta + REL_DELTA * scale
+        _, _, tight, _, _ = self.certificate(u, v, col4row, 1.0, tau, 0)
+        if tight is None:
+            return None
+        if len(tight) == 0:
+            return np.full((nr, 1), -1, dtype=np.int32), np.full((nr, 1), np.inf)
+        order = np.argsort(tight[:, 0], kind="stable")
+        r, c = tight[order, 0].astype(np.int64), tight[order, 1].astype(np.int32)
+        exact = self._exact(r, c)
+        counts = np.bincount(r, minlength=nr)
+        start = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        slot = np.arange(len(r)) - start[r]
+        kmax = int(counts.max())
+        cols = np.full((nr, kmax), -1, dtype=np.int32)
+        costs = np.full((nr, kmax), np.inf)
+        cols[r, slot], costs[r, slot] = c, exact
+        return cols, costs
+
+
 def certify(M, u, v, col4row, info=None, min_eps=0.0):
     """Is (u, v, col4row) a certified UNIQUE optimum of the matrix M (nr <= nc)?  Dual feasibility and complementary
     slackness on every entry (pm_lsap_certificate), the free columns carrying the largest column dual (nr < nc), and no
@@ -742,6 +824,27 @@ def solve_core(M, info=None):
                 break
             if rounds >= MAX_PRICING_ROUNDS:
                 return None
+        if hasattr(M, "threshold_select"):
+            # A FilteredMatrix: the rounds above priced the entries its approximate matrix ranks first.  Now EVERY entry whose exact
+            # reduced cost can lie below the collection margin is listed and priced with its exact cost, until none violates: the duals
+            # are then feasible on all of them to the bit and every unlisted entry is further than the margin from tight.
+            polish = 0
+            while True:
+                lst = M.threshold_select(u, v, c4r)
+                if lst is None or not np.isfinite(lst[1][lst[0] >= 0]).all():
+                    return None
+                violated = core.reprice(lst[0], lst[1], delta)
+                polish += 1
+                if info is not None:
+                    info.setdefault("polish_violated", []).append(violated)
+                if violated == 0:
+                    break
+                if polish >= MAX_PRICING_ROUNDS:
+                    return None
+                t_s = time.perf_counter()
+                core.solve()
+                t_core += time.perf_counter() - t_s
+                u, v, c4r, stats = core.get()
         if info is not None:
             info.update(rounds=rounds, edges=stats[0], steps=stats[1], augmentations=stats[2], dummy_scans=stats[3], core_seconds=t_core)
     return u, v, c4r

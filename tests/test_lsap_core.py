@@ -426,3 +426,68 @@ def test_listed_certificate_refuses_what_the_perturbation_decided():
             assert swapped and not ok, (gap, push, info)              # R chose the assignment that is NOT C's optimum
         else:
             assert ok and np.array_equal(sol[2], cs), (gap, push, info)
+
+
+@pytest.mark.parametrize("shape", [(300, 300), (257, 300), (300, 257), (1000, 1000)])
+def test_an_approximate_matrix_as_a_filter_gives_the_exact_matrices_certified_answer(shape):
+    """lsap.FilteredMatrix: the dense matrix the solver queries is only within cost_delta = 1e-6 of the exact one (what a float32
+    cost build delivers); every cost that reaches the sparse core or the certificate is evaluated exactly on request.  The
+    certified answer must be SciPy's on the EXACT matrix although the approximate matrix's own optimum is usually another
+    assignment; the exact matrix is only ever read at listed entries (a few dozen per row)."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(shape[0] * 5 + shape[1])
+    n, m = shape
+    C = rng.random(shape) * rng.random((1, m)) + 0.3 * rng.random((n, 1)) + 0.05 * rng.random(shape)
+    Ct = C + rng.uniform(-4e-14, 4e-14, size=shape)              # the twin: the same terms in another order
+    cost_delta = 1e-6
+    A = C + rng.uniform(-cost_delta, cost_delta, size=shape)
+    T = (lambda X: X if n <= m else X.T)
+    asked = []
+
+    def entries(rows, cols):
+        asked.append(len(rows))
+        return T(C)[rows, cols], T(Ct)[rows, cols]
+
+    M = L.FilteredMatrix(HostMatrix(T(A)), entries, cost_delta)
+    info = {}
+    sol = L.solve_core(M, info)
+    assert sol is not None, info
+    infos = [{}, {}]
+    ok = L.certify_listed(M, *sol, exact_entries=entries, cost_delta=cost_delta, infos=infos)
+    assert ok == [True, True], (info, infos)
+    got = L._answer(sol[2], n, m)
+    r, c = scipy_lsa(C)
+    assert np.array_equal(got[0], r) and np.array_equal(got[1], c)
+    assert np.array_equal(scipy_lsa(Ct)[1], c)
+    ra, ca = scipy_lsa(A)
+    print("%s: approximate matrix's own optimum differs from the exact one's in %d rows; exact entries evaluated: %d of %d; polishing rounds %s"
+          % (shape, int((ca != c).sum()), sum(asked), n * m, info.get("polish_violated")))
+    assert sum(asked) < 0.5 * n * m
+
+
+def test_filter_settles_what_lies_below_its_own_accuracy_and_refuses_exact_ties():
+    """Two optima of the exact matrix `gap` apart with gap far BELOW the filter's accuracy (1e-9 against 1e-6): the approximate
+    matrix cannot tell them apart, the exact costs on the listed entries do — the certified answer is SciPy's; gap = 0 (an
+    exact tie) is refused."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(33)
+    n = 200
+    base = rng.random((n, n)) + 0.5
+    u, v, c = L.solve_core(HostMatrix(base))
+    i1, i2 = 7, 120
+    cost_delta = 1e-6
+    for gap in (1e-9, 0.0):
+        C = base.copy()
+        C[i1, c[i2]] = (u[i1] + v[c[i2]]) + gap / 2
+        C[i2, c[i1]] = (u[i2] + v[c[i1]]) + gap / 2
+        A = C + rng.uniform(-cost_delta, cost_delta, size=C.shape)
+        M = L.FilteredMatrix(HostMatrix(A), lambda rows, cols: (C[rows, cols],), cost_delta)
+        info = {}
+        sol = L.solve_core(M, info)
+        assert sol is not None
+        ci = {}
+        ok = L.certify_listed(M, *sol, exact_entries=M.exact_entries, cost_delta=cost_delta, infos=[ci])[0]
+        if gap > 0:
+            assert ok and np.array_equal(sol[2], scipy_lsa(C)[1]), (gap, info, ci)
+        else:
+            assert not ok and ci.get("unique") is False, (gap, ci)
