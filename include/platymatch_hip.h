@@ -193,6 +193,17 @@ size_t pm_chi2_relaxed_workspace_bytes(int nM, int nF);
 double pm_chi2_relaxed_delta(void);
 int pm_chi2_cost8_relaxed(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
                           size_t matrix_stride, void *ws, size_t ws_bytes, int variant, void *stream);
+/* OPT-IN (round 4): the FILTER build — the four pairings' matrices (out4 + t * matrix_stride, t = 0..3: U11/U22, U12/U21, U13/U24,
+ * U14/U23, each pair one matrix) in packed float32 arithmetic, written as float64; every entry within pm_chi2_filter_delta()
+ * (absolute, 1e-6) of the exact cost.  3.2x faster than the exact eight-matrix launch, half its output.  Not the reference's
+ * values and never handed out as such: the matrices only tell the assignment solver WHICH entries can matter, every cost it uses
+ * is evaluated exactly by pm_chi2_entries_sym (the Python mirror: lsap.FilteredMatrix, estimate_transform(cost_mode='filter')).
+ * ws: pm_chi2_filter_workspace_bytes of 16-byte aligned device memory.  Same precondition as pm_chi2_cost8_sym (symmetry flag 0). */
+size_t pm_chi2_filter_workspace_bytes(int nM, int nF);
+double pm_chi2_filter_delta(void);
+int pm_chi2_filter4(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out4, size_t ld, size_t matrix_stride,
+                    void *ws, size_t ws_bytes, void *stream);
+
 /* Listed entries of one pairing's two EXACT matrices (the bits of pm_chi2_cost_pair_sym's): out_natural[e], out_rolled[e] =
  * entry (rows[e], cols[e]) of the natural-order matrix (U11, U12, U13, U14 for pairing 0..3) and of its rolled-order twin (U22,
  * U21, U24, U23).  rows / cols / outputs: device, n_entries each; an index out of range yields NaN in both outputs.  What turns

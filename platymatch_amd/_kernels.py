@@ -321,6 +321,29 @@ def chi2_relaxed_delta():
     return float(nat.load().pm_chi2_relaxed_delta())
 
 
+def chi2_filter4(sc_m1, sc_f1, out=None):
+    """OPT-IN: the four pairings' cost matrices in packed float32 arithmetic -> [4, nM, nF] float64, every entry within
+    chi2_filter_delta() of the exact cost (pm_chi2_filter4).  A FILTER for the assignment solver (lsap.FilteredMatrix), never a
+    result: matrix t stands for hypothesis PAIRINGS[t][0] and for its twin."""
+    torch = _t()
+    a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
+    nM, nF = a.shape[0], b.shape[0]
+    if out is None:
+        out = torch.empty((4, nM, nF), dtype=torch.float64, device=a.device)
+    if (tuple(out.shape) != (4, nM, nF) or out.dtype != torch.float64 or out.device != a.device or out.stride(2) != 1
+            or out.stride(1) < nF or out.stride(0) < nM * out.stride(1)):
+        raise ValueError("out must be a float64 tensor [4, nM, nF] on the descriptors' device with unit column stride")
+    lib = nat.load()
+    ws = torch.empty(int(lib.pm_chi2_filter_workspace_bytes(nM, nF)), dtype=torch.uint8, device=a.device)
+    check(lib.pm_chi2_filter4(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(), nat.stream_ptr()))
+    return out
+
+
+def chi2_filter_delta():
+    """Absolute per-entry error bound of chi2_filter4 against the exact cost (csrc/pm_chi2.hip: PM_CHI2_FILTER_DELTA)."""
+    return float(nat.load().pm_chi2_filter_delta())
+
+
 def chi2_entries(sc_m1, sc_f1, pairing, rows, cols):
     """Listed entries (rows[e], cols[e]) of pairing t's two EXACT matrices -> (natural-order values, rolled-order values), float64
     GPU tensors [len(rows)] carrying the bits of chi2_cost_pair's matrices (pm_chi2_entries_sym).  rows / cols: integer arrays

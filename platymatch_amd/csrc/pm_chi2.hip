@@ -470,6 +470,93 @@ __global__ __launch_bounds__(256) void entries_sym_kernel(const double *__restri
     out_rol[e] = 0.5 * sr;
 }
 
+// ---- FILTER build (round 4, opt-in): the four pairings' matrices in packed FLOAT32 arithmetic, written as float64 -------------
+// U~ = 0.5 (sum a + sum b) - 2 sum_k a_k b_k / (a_k + b_k) with the terms in float32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on two
+// bins at a time, v_rcp_f32 per bin: 5.5 issue slots per term against the exact build's ~18), every shell computed, a shell's two
+// float32 chains added into a float64 sum per (row, pairing).  NOT the reference's values: every entry is within PM_CHI2_FILTER_DELTA of
+// the exact cost — per term 8 x 2^-24 relative (a, b rounded to float32: 2 each; a + b, a b: 1 each; v_rcp_f32: 2), i.e. <= 2.4e-7 on
+// the sum (<= 0.5); the six fused adds and the final add of a shell's chains 7 x 2^-24 of that shell's sum, <= 2.1e-7 over all shells;
+// doubled by the factor 2: < 1e-6.  It serves as a FILTER only (lsap.FilteredMatrix): it says which entries can matter, their exact
+// costs come from entries_sym_kernel.  out4 + t * mstride = the matrix of pairing t (both U11/U22-type twins: one matrix).
+#define PM_CHI2_FILTER_DELTA 1e-6
+typedef float pm_f2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__restrict__ scA, int nA, const double *__restrict__ scB, int nB,
+                                                                double *__restrict__ out, size_t ld, size_t mstride, int nTi,
+                                                                unsigned int nblocks, const double *__restrict__ sumA,
+                                                                const double *__restrict__ sumB) {
+    constexpr int RI = 4, TI = 4 * RI;
+    __shared__ __attribute__((aligned(16))) float A_s[TI][CH_K];
+    __shared__ __attribute__((aligned(16))) float B_s[CH_TJ][CH_K + 2];
+    unsigned int bid = blockIdx.x;
+    const unsigned int full = nblocks / 8u * 8u;
+    if (bid < full) bid = (bid % 8u) * (full / 8u) + bid / 8u;
+    int ti, tj;
+    tile_of(bid, nTi, nblocks, ti, tj);
+    const int i0 = ti * TI, j0 = tj * CH_TJ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double acc[RI][4];
+#pragma unroll
+    for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[r][t] = 0.0;
+    for (int g = 0; g < CH_STAGES; ++g) {
+        __syncthreads();
+        if (tid < TI * CH_K) {
+            const int r = tid / CH_K, k = tid - r * CH_K;
+            A_s[r][k] = (float)scA[(size_t)min(i0 + r, nA - 1) * PM_NBINS + g * CH_K + k];
+        }
+        for (int e = tid; e < CH_TJ * CH_K; e += CH_THREADS) {
+            const int j = e / CH_K, k = e - j * CH_K;
+            const float v = (float)scB[(size_t)min(j0 + j, nB - 1) * PM_NBINS + g * CH_K + k];
+            B_s[j][k] = (v == 0.f) ? 1e-30f : v;
+        }
+        __syncthreads();
+        pm_f2 b[6], br[6];                            // the lane's twelve fixed bins as pairs, and the same pairs swapped
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            b[k] = *reinterpret_cast<const pm_f2 *>(&B_s[lane][2 * k]);
+            br[k] = (pm_f2){b[k].y, b[k].x};
+        }
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            pm_f2 a[6], s4[4];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) a[k] = *reinterpret_cast<const pm_f2 *>(&A_s[wave * RI + r][2 * k]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s4[t] = (pm_f2){0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                // moving bins (2k, 2k+1) meet fixed bins: pairing 0 the same; 1: +6; 2: (11-2k, 10-2k) = pair 5-k swapped;
+                // 3: (17-2k, 16-2k) mod 12 = pair (8-k) mod 6 swapped
+                const pm_f2 q[4] = {b[k], b[(k + 3) % 6], br[5 - k], br[(8 - k) % 6]};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const pm_f2 sm = a[k] + q[t];
+                    const pm_f2 pr = a[k] * q[t];
+                    const pm_f2 rc = (pm_f2){__builtin_amdgcn_rcpf(sm.x), __builtin_amdgcn_rcpf(sm.y)};
+                    s4[t] = __builtin_elementwise_fma(pr, rc, s4[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[r][t] += (double)(s4[t].x + s4[t].y);
+        }
+    }
+    const int gj = j0 + lane;
+    if (gj < nB) {
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int gi = i0 + wave * RI + r;
+            if (gi < nA) {
+                const double half = 0.5 * (sumA[gi] + sumB[gj]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) out[(size_t)t * mstride + (size_t)gi * ld + gj] = __builtin_fma(-2.0, acc[r][t], half);
+            }
+        }
+    }
+}
+
 // flag[0] |= 1 unless, bit for bit, sc2 = roll6(sc1), sc3 = reverse(sc1), sc4 = (5-q)(sc1) within every shell.
 // which: 0 = moving (frame 2 only), 1 = fixed (frames 2, 3, 4).  One thread per (row, bin).
 __global__ __launch_bounds__(256) void symmetry_check_kernel(const unsigned long long *__restrict__ s1,
@@ -675,6 +762,32 @@ extern "C" int pm_chi2_cost8_relaxed(const double *sc_m1, int nM, const double *
     if (variant == 2)
         return pm::chi2_sym_launch<4, 3, -1, 64, true>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta, sumA, sumB);
     return pm::chi2_sym_launch<4, 2, -1, pm::CH_TL, true>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta, sumA, sumB);
+}
+
+// The filter build (see filter4_kernel).  Workspace: pm_chi2_filter_workspace_bytes = the two row-sum vectors.
+extern "C" size_t pm_chi2_filter_workspace_bytes(int nM, int nF) {
+    if (nM <= 0 || nF <= 0) return 0;
+    return pm::align_up((size_t)nM * 8, 256) + pm::align_up((size_t)nF * 8, 256);
+}
+
+extern "C" double pm_chi2_filter_delta(void) { return PM_CHI2_FILTER_DELTA; }
+
+extern "C" int pm_chi2_filter4(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out4, size_t ld, size_t matrix_stride,
+                               void *ws, size_t ws_bytes, void *stream) {
+    if (!sc_m1 || !sc_f1 || !out4 || nM <= 0 || nF <= 0 || ld < (size_t)nF || matrix_stride < (size_t)nM * ld)
+        return PM_ERR_INVALID_ARG;
+    if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < pm_chi2_filter_workspace_bytes(nM, nF)) return PM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    double *sumA = (double *)ws;
+    double *sumB = (double *)((char *)ws + pm::align_up((size_t)nM * 8, 256));
+    pm::relaxed_rowsum_kernel<<<(nM + 255) / 256, 256, 0, s>>>(sc_m1, nM, sumA);
+    pm::relaxed_rowsum_kernel<<<(nF + 255) / 256, 256, 0, s>>>(sc_f1, nF, sumB);
+    const long nTi = ((long)nM + 15) / 16, nTj = ((long)nF + pm::CH_TJ - 1) / pm::CH_TJ;
+    const long nblocks = nTi * nTj;
+    if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
+    pm::filter4_kernel<<<(unsigned int)nblocks, pm::CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out4, ld, matrix_stride, (int)nTi,
+                                                                       (unsigned int)nblocks, sumA, sumB);
+    return pm::launch_status();
 }
 
 extern "C" int pm_chi2_entries_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, const int32_t *rows,

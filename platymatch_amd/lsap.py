@@ -231,6 +231,13 @@ class DeviceMatrix:
     def certificate(self, u, v, col4row, delta, eps, cap):
         """-> (violations, loose matched entries, tight edges [t, 2] int32 and their reduced costs [t] — None if more than
         cap —, sum over rows of (|reduced cost| of the matched entry + the row's worst negative reduced cost))."""
+        viol, loose, tight, red, bound = self.certificate_t(u, v, col4row, delta, eps, cap)
+        if tight is None:
+            return viol, loose, None, None, bound
+        return viol, loose, tight.cpu().numpy(), red.cpu().numpy(), bound
+
+    def certificate_t(self, u, v, col4row, delta, eps, cap):
+        """certificate with the list left on the device: tight [t, 2] int32 and red [t] float64 GPU tensors (or None, None)."""
         torch = nat.torch_mod()
         U = self.U
         nr, nc = U.shape
@@ -249,7 +256,7 @@ class DeviceMatrix:
         bound = float(rows_h[0].sum() + rows_h[1].sum())         # what the observed imperfections can cost any alternative, in total
         if n_tight > cap:
             return viol, loose, None, None, bound
-        return viol, loose, tight[:n_tight].cpu().numpy(), red[:n_tight].cpu().numpy(), bound
+        return viol, loose, tight[:n_tight], red[:n_tight], bound
 
 
 class FilteredMatrix:
@@ -268,12 +275,16 @@ class FilteredMatrix:
 
     LIST_CAPACITY_PER_COLUMN = 64
 
-    def __init__(self, approx, exact_entries, cost_delta):
+    def __init__(self, approx, exact_entries, cost_delta, exact_entries_t=None):
+        """exact_entries_t (optional, with a DeviceMatrix as `approx`): the same question asked and answered with GPU tensors
+        (rows, cols int32 [t] -> tuple of float64 [t]); the per-row lists of threshold_select are then assembled on the device."""
         self.A = approx
         self.shape = tuple(approx.shape)
         self.exact_entries = exact_entries
+        self.exact_entries_t = exact_entries_t
         self.cost_delta = float(cost_delta)
         self.exact_evaluated = 0
+        self._listed = None             # the last complete listing: (u, v, col4row, eps, tight, red)
 
     def _exact(self, rows, cols):
         self.exact_evaluated += int(len(rows))
@@ -306,16 +317,52 @@ class FilteredMatrix:
         return np.take_along_axis(cols, order, axis=1), np.take_along_axis(costs, order, axis=1), 0
 
     def certificate(self, u, v, col4row, delta, eps, cap):
+        L = self._listed
+        if (L is not None and eps <= L[3] and np.array_equal(L[0], u) and np.array_equal(L[1], v) and np.array_equal(L[2], col4row)):
+            keep = L[5] <= eps                               # the same duals were listed (with a margin at least as wide): reuse
+            return 0, 0, L[4][keep], L[5][keep], 0.0
         cap = max(int(cap), self.LIST_CAPACITY_PER_COLUMN * self.shape[1])
         _, _, tight, red, _ = self.A.certificate(u, v, col4row, 1.0, eps, cap)      # (delta = 1: nothing is set aside as a violation)
+        if tight is not None:
+            self._listed = (np.array(u, copy=True), np.array(v, copy=True), np.array(col4row, copy=True), float(eps), tight, red)
         return 0, 0, tight, red, 0.0
+
+    def _tau(self, u, v):
+        scale = max(float(np.abs(u).max()), float(np.abs(v).max()), 1e-300)
+        return REL_EPS_COLLECT * scale + 2.0 * self.cost_delta + 2.0 * REL_DELTA * scale
+
+    def _threshold_select_t(self, u, v, col4row):
+        """threshold_select with the list sorted, evaluated and laid out per row on the device."""
+        torch = nat.torch_mod()
+        nr, nc = self.shape
+        tau = self._tau(u, v)
+        _, _, tight, red, _ = self.A.certificate_t(u, v, col4row, 1.0, tau, self.LIST_CAPACITY_PER_COLUMN * nc)
+        if tight is None:
+            return None
+        self._listed = (np.array(u, copy=True), np.array(v, copy=True), np.array(col4row, copy=True), tau, tight.cpu().numpy(), red.cpu().numpy())
+        if tight.shape[0] == 0:
+            return np.full((nr, 1), -1, dtype=np.int32), np.full((nr, 1), np.inf)
+        r = tight[:, 0].long()
+        order = torch.argsort(r, stable=True)
+        r, c = r[order], tight[order, 1].contiguous()
+        exact = self.exact_entries_t(r.to(torch.int32), c)[0]
+        self.exact_evaluated += int(r.numel())
+        counts = torch.bincount(r, minlength=nr)
+        start = torch.cumsum(counts, 0) - counts
+        slot = torch.arange(r.numel(), device=r.device) - start[r]
+        kmax = int(counts.max())
+        cols = torch.full((nr, kmax), -1, dtype=torch.int32, device=r.device)
+        costs = torch.full((nr, kmax), float("inf"), dtype=torch.float64, device=r.device)
+        cols[r, slot], costs[r, slot] = c, exact
+        return cols.cpu().numpy(), costs.cpu().numpy()
 
     def threshold_select(self, u, v, col4row):
         """-> (cols [nr, kmax] int32, -1 padded; exact costs [nr, kmax], inf padded) of every non-matched entry whose EXACT reduced
         cost can be below REL_EPS_COLLECT x scale, or None if the list overflowed."""
+        if self.exact_entries_t is not None and hasattr(self.A, "certificate_t"):
+            return self._threshold_select_t(u, v, col4row)
         nr, nc = self.shape
-        scale = max(float(np.abs(u).max()), float(np.abs(v).max()), 1e-300)
-        tau = REL_EPS_COLLECT * scale + 2.0 * self.cost_delta + REL_DELTA * scale
+        tau = self._tau(u, v)
         _, _, tight, _, _ = self.certificate(u, v, col4row, 1.0, tau, 0)
         if tight is None:
             return None
@@ -456,7 +503,8 @@ def certify_listed(M, u, v, col4row, exact_entries, cost_delta, infos=None):
         # entries can take back at most sum over rows of the row's worst one = bound, so an alternative that uses ANY entry
         # above eps > bound is dearer, and one that stays within eps of tight is an alternating cycle pm_lsap_unique would find.
         worst = np.zeros(nr)
-        np.minimum.at(worst, tight[:, 0], redC)
+        neg = redC < 0.0
+        np.minimum.at(worst, tight[neg, 0], redC[neg])        # (only negative entries can lower a row's worst below 0)
         bound = float(-worst.sum())
         eps = max(REL_EPS_FLOOR * scale, EPS_SAFETY * bound)
         info.update(violations=int((redC < -delta).sum()), loose=0, slack_bound=bound, eps=eps)
@@ -1040,6 +1088,62 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
 
     if ready is None:
         torch.cuda.current_stream(U8.device).synchronize()  # U8 was produced on the caller's stream
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(pair, range(4)))
+    if info is not None:
+        info["routes"] = [i.get("route") for i in infos]
+        info["details"] = infos
+    return out
+
+
+def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pair, info=None, allow_host=True, accept_near_ties=False):
+    """The widget's eight assignments from FOUR approximate matrices F4 [4, N, M] (pm_chi2_filter4: matrix t within cost_delta of
+    hypothesis PAIRINGS[t][0]'s exact matrix and of its twin's), none of the exact matrices built: per pairing (four host threads)
+    the sparse-core solve runs on a FilteredMatrix — the approximate matrix selects entries, every cost comes from
+    exact_entries(t)(rows, cols) -> (hypothesis's exact values, twin's) [exact_entries_t: the same with GPU tensors] — and the
+    result is certified against both exact matrices on their listed entries (certify_listed).  A pairing that cannot be certified
+    (ties, near-ties, non-finite costs) gets its two exact matrices from exact_pair(t) -> [2, N, M] and goes the exact mode's
+    way (solve_pair_on_device).  -> list of eight (row_ind, col_ind)."""
+    torch = nat.torch_mod()
+    n, m = F4.shape[1], F4.shape[2]
+    out = [None] * 8
+    infos = [dict() for _ in range(8)]
+    pairs = [(h, [t for t, s_ in TWINS.items() if s_ == h][0]) for h in range(4)]
+    caller = torch.cuda.current_stream(F4.device).cuda_stream
+
+    def pair(t):
+        h, twin = pairs[t]
+        stream = nat.side_stream(F4.device, ("pair", caller, h))
+        with torch.cuda.device(F4.device), torch.cuda.stream(stream):
+            got = [None, None]
+            if min(n, m) >= DEVICE_MIN_ROWS:
+                fetch, fetch_t = exact_entries(t), exact_entries_t(t)
+                if n > m:                                       # the solve runs on the transpose: rows are fixed nuclei
+                    f0, f0_t = fetch, fetch_t
+                    fetch, fetch_t = (lambda rows, cols: f0(cols, rows)), (lambda rows, cols: f0_t(cols, rows))
+                W = DeviceMatrix(F4[t] if n <= m else transposed(F4[t]))
+                M = FilteredMatrix(W, fetch, cost_delta, fetch_t)
+                sol = solve_core(M, infos[h])
+                if sol is not None:
+                    ok = certify_listed(M, *sol, exact_entries=fetch, cost_delta=cost_delta, infos=[infos[h], infos[twin]])
+                    if len(ok) == 2 and all(ok):
+                        got = [_answer(sol[2], n, m)] * 2
+                        infos[h]["route"], infos[twin]["route"] = "device", "device (sibling's duals certified)"
+                        for i in (infos[h], infos[twin]):
+                            i["cost_mode"] = "filter (approximate matrix as selector, exact costs on %d listed entries)" % M.exact_evaluated
+                del W, M
+            if got[0] is None or got[1] is None:
+                infos[h].clear()
+                infos[twin].clear()
+                U2 = exact_pair(t)
+                got = solve_pair_on_device(U2[0], U2[1], infos[h], infos[twin], allow_host, accept_near_ties)
+                for i in (infos[h], infos[twin]):
+                    i["cost_mode"] = "exact (built: the filtered solve did not certify)"
+                del U2
+            out[h], out[twin] = got
+            stream.synchronize()
+
+    torch.cuda.current_stream(F4.device).synchronize()       # F4 was produced on the caller's stream
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(pair, range(4)))
     if info is not None:

@@ -864,8 +864,8 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     t0 = time.perf_counter()
     if sampler not in ('auto', 'numpy', 'device'):
         raise ValueError("sampler must be 'auto', 'numpy' or 'device'")
-    if cost_mode not in ('exact', 'relaxed'):
-        raise ValueError("cost_mode must be 'exact' or 'relaxed'")
+    if cost_mode not in ('exact', 'relaxed', 'filter'):
+        raise ValueError("cost_mode must be 'exact', 'relaxed' or 'filter'")
     on_device = (sampler == 'device' or (sampler == 'auto' and seed is None)) and getattr(be, "device_sampler", False) \
         and int(ransac_samples) <= min(mov.shape[1], fix.shape[1])
     if mode == 'unsupervised':
@@ -875,6 +875,7 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                              seed, private_rng)
         a_info = None if details is None else details.setdefault("assignment", {})
         lease = relaxed = None
+        filtered = False
         try:
             guards = [] if getattr(be, "device_sampler", False) else None     # (the GPU backend: its descriptor launches count)
             views = (None, None)
@@ -899,7 +900,11 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                 if (cost_mode == 'relaxed' and world == 1 and mov.is_cuda and hasattr(be, "chi2_cost8_relaxed")
                         and min(mov.shape[1], fix.shape[1]) >= RELAXED_MIN_POINTS):
                     relaxed = be.chi2_cost8_relaxed(sc_m, sc_f, out=None if lease is None else lease.view)
-                if relaxed is not None:
+                if (cost_mode == 'filter' and world == 1 and mov.is_cuda and getattr(be, "device_sampler", False)
+                        and min(mov.shape[1], fix.shape[1]) >= RELAXED_MIN_POINTS and (sc_f.shape[0] == 1 or be.K.chi2_symmetric(sc_m, sc_f))):
+                    filtered = True
+                    U = be.K.chi2_filter4(sc_m[0], sc_f[0], out=None if lease is None else lease.view[:4])
+                elif relaxed is not None:
                     U, relaxed_delta = relaxed
                 else:
                     U = be.chi2_cost8(sc_m, sc_f, out=None if lease is None else lease.view)
@@ -913,6 +918,20 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             if streamed:
                 lsa = assign_streamed(be, sc_m, sc_f, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None),
                                       accept_near_ties=accept_near_ties)
+            elif filtered:
+                from .lsap import solve_four_filtered
+                sc_m1, sc_f1 = sc_m[0], sc_f[0]
+
+                def entries_np(t):
+                    return lambda rows, cols: tuple(x.cpu().numpy() for x in be.K.chi2_entries(sc_m1, sc_f1, t, rows, cols))
+
+                def entries_t(t):
+                    return lambda rows, cols: be.K.chi2_entries(sc_m1, sc_f1, t, rows, cols)
+                lsa = solve_four_filtered(U, entries_np, entries_t, be.K.chi2_filter_delta() + 1e-13,
+                                          lambda t: be.K.chi2_cost_pair(sc_m, sc_f, t, sc_f.shape[0] == 1 or be.K.chi2_symmetric(sc_m, sc_f)),
+                                          info=a_info, accept_near_ties=accept_near_ties)
+                if any(a is None for a in lsa):
+                    raise RuntimeError("a hypothesis could not be assigned (see accept_near_ties)")
             elif relaxed is not None:
                 from .lsap import solve_eight_on_device
                 from ._kernels import PAIRINGS

@@ -110,7 +110,7 @@ def test_every_entry_point_rejects_bad_arguments_before_touching_the_device(lib_
     from platymatch_amd import _native
     lib = _native.load()
     skipped = {"pm_version", "pm_last_hip_error", "pm_error_string", "pm_lsap_core_create", "pm_lsap_core_destroy",
-               "pm_chi2_relaxed_delta", "pm_lsap_default_options"}      # (a constant; a void function: NULL is ignored)
+               "pm_chi2_relaxed_delta", "pm_chi2_filter_delta", "pm_lsap_default_options"}      # (a constant; a void function: NULL is ignored)
     for name, (restype, argtypes) in _native.SIGNATURES.items():
         if name in skipped:
             continue

@@ -166,3 +166,61 @@ def test_tied_clouds_fall_back_to_the_exact_build_and_give_the_exact_modes_answe
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     modes = [d.get("cost_mode", "") for d in dr["assignment"]["details"]]
     assert all(x.startswith("exact (rebuilt") for x in modes), modes
+
+
+@pytest.mark.parametrize("n,m", [(1500, 2100), (2100, 1500), (3000, 3000)])
+def test_filter_build_is_within_its_bound_of_both_orders_of_every_pairing(g, n, m):
+    """pm_chi2_filter4 (packed float32 terms): matrix t against the exact natural-order matrix AND its rolled-order twin."""
+    mv, fx, _ = synth_pair(max(n, m), 31 + n)
+    be = g.P.GpuBackend()
+    sc_m, sc_f, _ = g.P.build_descriptors(be, be.cloud(np.ascontiguousarray(mv[:, :n])), be.cloud(np.ascontiguousarray(fx[:, :m])))
+    assert g.K.chi2_symmetric(sc_m, sc_f)
+    exact = g.K.chi2_cost8(sc_m, sc_f)
+    F = g.K.chi2_filter4(sc_m[0], sc_f[0])
+    delta = g.K.chi2_filter_delta()
+    worst = 0.0
+    for t, (h, twin) in enumerate(g.K.PAIRINGS):
+        for k in (h, twin):
+            worst = max(worst, float((F[t] - exact[k]).abs().max()))
+    print("%d x %d: largest |filter - exact| = %.2e (bound %.1e)" % (n, m, worst, delta))
+    assert worst <= delta
+
+
+@pytest.mark.parametrize("n,m,seed", [(3000, 2900, 77), (5000, 5000, 42), (2400, 2600, 3), (1200, 1200, 9), (600, 650, 1)])
+def test_filter_mode_returns_the_exact_modes_registration(g, n, m, seed):
+    """estimate_transform(cost_mode='filter'): no exact matrix is built, the assignment is solved with exact costs on the entries a
+    float32 build selects and certified against both exact matrices of every pairing — the same assignment vectors, inlier counts
+    and transforms as the exact mode, bit for bit."""
+    mv, fx, _ = synth_pair(max(n, m), seed)
+    mv, fx = np.ascontiguousarray(mv[:, :n]), np.ascontiguousarray(fx[:, :m])
+    kw = dict(ransac_trials=400, icp_iterations=6, seed=5)
+    de, dr = {}, {}
+    a = g.P.estimate_transform(mv, fx, details=de, **kw)
+    b = g.P.estimate_transform(mv, fx, details=dr, cost_mode='filter', **kw)
+    for h in range(8):
+        assert np.array_equal(de["lsa"][h][0], dr["lsa"][h][0]) and np.array_equal(de["lsa"][h][1], dr["lsa"][h][1]), h
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    if min(n, m) >= g.P.RELAXED_MIN_POINTS:
+        modes = [d.get("cost_mode", "") for d in dr["assignment"]["details"]]
+        assert all(x.startswith("filter") for x in modes), modes
+        print("%d x %d: %s; polishing rounds %s" % (n, m, modes[0], [d.get("polish_violated") for d in dr["assignment"]["details"][:4]]))
+
+
+def test_filter_mode_on_tied_clouds_builds_the_pairings_exactly(g):
+    n = 1400
+    mv, fx, _ = synth_pair(n, 23)
+    mv, fx = mv.copy(), fx.copy()
+    mv[:, 100:112] = mv[:, 200:212]
+    fx[:, 300:306] = fx[:, 900:906]
+    kw = dict(ransac_trials=300, icp_iterations=4, seed=3)
+    de, dr = {}, {}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", g.P.EdgeGuardWarning)
+        a = g.P.estimate_transform(mv, fx, details=de, **kw)
+        b = g.P.estimate_transform(mv, fx, details=dr, cost_mode='filter', **kw)
+    for h in range(8):
+        assert np.array_equal(de["lsa"][h][0], dr["lsa"][h][0]) and np.array_equal(de["lsa"][h][1], dr["lsa"][h][1]), h
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    modes = [d.get("cost_mode", "") for d in dr["assignment"]["details"]]
+    assert all(x.startswith("exact (built") for x in modes), modes
