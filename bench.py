@@ -404,7 +404,7 @@ def main():
     # Second extra, OUTSIDE the timed region and never the headline: the relaxed-rounding cost build (opt-in experiment,
     # pm_chi2_cost8_relaxed / estimate_transform(cost_mode='relaxed'): no bit identity, every entry within delta of the exact one,
     # used only behind a certificate against the exact matrix's listed entries).  Launch time by HIP events on the launching stream.
-    relaxed_extra = None
+    relaxed_extra = filter_extra = None
     if world == 1 and symmetric[0] and not args.no_assignment:
         ts = []
         for _ in range(3):
@@ -438,6 +438,32 @@ def main():
                                  "these matrices counts only once it is proven to be the exact matrix's unique optimum from the exact "
                                  "values of its matched and near-tight entries (a few N of them, evaluated by a small kernel), else that "
                                  "pairing is rebuilt exactly (profiles/r04_chi2_relaxed.txt)"}
+        # third extra: the float32 FILTER build (cost_mode='filter') and the eight assignments solved through it — four approximate
+        # matrices select entries, every cost is exact; nothing exact is built
+        ts = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            K.chi2_filter4(a1, b1, out=U[:4])
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        f_info = {}
+        t_fs = time.perf_counter()
+        lsa_f = L.solve_four_filtered(U[:4], lambda t: (lambda rows, cols: tuple(x.cpu().numpy() for x in K.chi2_entries(a1, b1, t, rows, cols))),
+                                      lambda t: (lambda rows, cols: K.chi2_entries(a1, b1, t, rows, cols, trusted=True)),
+                                      K.chi2_filter_delta() + 1e-13, lambda t: K.chi2_cost_pair(sc_m_last[0], sc_f_last[0], t, True),
+                                      info=f_info, allow_host=False)
+        t_fs = time.perf_counter() - t_fs
+        through = [str(d.get("cost_mode", "")).startswith("filter") for d in f_info.get("details", [])]
+        filter_extra = {"kernel": "pm::filter4_kernel", "launch_ms": min(ts), "exact_launch_ms": chi2_ms, "speedup": chi2_ms / min(ts),
+                        "per_entry_error_bound": K.chi2_filter_delta(), "assignment_seconds": t_fs,
+                        "hypotheses_settled_without_an_exact_matrix": int(sum(through)),
+                        "equal_to_exact_matrices_assignments": [bool(x is not None and y is not None and np.array_equal(x[1], y[1]))
+                                                                for x, y in zip(lsa_f, lsa)],
+                        "note": "opt-in, NOT the product default and NOT in `value`: four matrices in packed float32 arithmetic only select "
+                                "entries for the assignment solver, whose costs and certificate are evaluated exactly "
+                                "(lsap.FilteredMatrix; profiles/r04_e2e.txt)"}
         K.chi2_cost8_frame1(sc_m_last[0][0], sc_f_last[0][0], out=U)          # leave the exact matrices behind
 
     if rank == 0:
@@ -486,6 +512,7 @@ def main():
             "icp_affine_finite": bool(np.isfinite(final).all()),
             "assignment_extra": assignment,
             "relaxed_cost_build_extra": relaxed_extra,
+            "filter_cost_build_extra": filter_extra,
         }
         if world == 1 and not args.no_cpu_baseline:
             # the chi-square leg of the CPU baseline runs on the real clouds' descriptors (the GPU's, verified equal to the oracle's

@@ -344,10 +344,11 @@ def chi2_filter_delta():
     return float(nat.load().pm_chi2_filter_delta())
 
 
-def chi2_entries(sc_m1, sc_f1, pairing, rows, cols):
+def chi2_entries(sc_m1, sc_f1, pairing, rows, cols, trusted=False):
     """Listed entries (rows[e], cols[e]) of pairing t's two EXACT matrices -> (natural-order values, rolled-order values), float64
     GPU tensors [len(rows)] carrying the bits of chi2_cost_pair's matrices (pm_chi2_entries_sym).  rows / cols: integer arrays
-    (NumPy or torch) of equal length, every index in range (checked here: the kernel would answer NaN)."""
+    (NumPy or torch) of equal length, every index in range (checked here: the kernel would answer NaN; trusted=True skips the
+    check and its two read-backs — for index lists that come from the library's own kernels)."""
     torch = _t()
     a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
     r = torch.as_tensor(np.ascontiguousarray(rows) if not nat.is_torch(rows) else rows).to(device=a.device, dtype=torch.int32).contiguous()
@@ -357,7 +358,7 @@ def chi2_entries(sc_m1, sc_f1, pairing, rows, cols):
     k = int(r.numel())
     out = torch.empty((2, k), dtype=torch.float64, device=a.device)
     if k:
-        if int(r.min()) < 0 or int(r.max()) >= a.shape[0] or int(c.min()) < 0 or int(c.max()) >= b.shape[0]:
+        if not trusted and (int(r.min()) < 0 or int(r.max()) >= a.shape[0] or int(c.min()) < 0 or int(c.max()) >= b.shape[0]):
             raise ValueError("entry index out of range")
         check(nat.load().pm_chi2_entries_sym(ptr(a), a.shape[0], ptr(b), b.shape[0], int(pairing), ptr(r), ptr(c), k, ptr(out[0]), ptr(out[1]),
                                              nat.stream_ptr()))

@@ -301,7 +301,29 @@ class FilteredMatrix:
     def entries(self, rows, cols):
         return self._exact(rows, cols)
 
+    def _row_select_t(self, v, k):
+        """row_select with selection, exact evaluation and re-sorting on the device: one read-back."""
+        torch = nat.torch_mod()
+        cols, costs_a, flag = self.A.row_select_t(v, k)
+        valid = cols >= 0
+        rows = torch.arange(cols.shape[0], dtype=torch.int32, device=cols.device)[:, None].expand_as(cols)
+        exact = self.exact_entries_t(rows[valid].contiguous(), cols[valid].contiguous())[0]
+        self.exact_evaluated += int(exact.numel())
+        costs = torch.full(cols.shape, float("inf"), dtype=torch.float64, device=cols.device)
+        costs[valid] = exact
+        red = costs
+        if v is not None:
+            v_d = nat.to_dev(v, dev=cols.device)
+            red = costs - v_d[cols.clamp(min=0).long()]
+        order = torch.argsort(torch.where(valid, red, torch.full_like(red, float("inf"))), dim=1, stable=True)
+        cols_s, costs_s = torch.gather(cols, 1, order), torch.gather(costs, 1, order)
+        bad = torch.stack([flag.reshape(-1)[0].to(torch.int32), (~torch.isfinite(exact)).any().to(torch.int32)])
+        cols_h, costs_h, bad_h = cols_s.cpu().numpy(), costs_s.cpu().numpy(), bad.cpu().numpy()
+        return cols_h, costs_h, int(bad_h.max())
+
     def row_select(self, v, k):
+        if self.exact_entries_t is not None and hasattr(self.A, "row_select_t"):
+            return self._row_select_t(v, k)
         cols, costs, bad = self.A.row_select(v, k)
         if bad:
             return cols, costs, bad

@@ -353,6 +353,7 @@ def gather_fixed_descriptors(be, sc_m_loc, sc_f_loc, bounds, group=None):
 
 STATS_ON_TWO_STREAMS = True
 RELAXED_CERTIFY_ON_EXACT_ENTRIES = True     # cost_mode='relaxed': certify on the exact matrix's listed entries (lsap.certify_listed); False: a 2 N delta margin on the relaxed one
+FILTER_MIN_POINTS = 8192       # cost_mode='filter' below this: the relaxed mode (the filter's extra round trips cost more than its build saves: measured 36 / 30 ms at 5k, 72 / 78 at 10k, 178 / 212 at 20k, 0.99 / 1.24 s at 50k)
 RELAXED_MIN_POINTS = 1024      # cost_mode='relaxed' below this: exact (the dense host solver takes such matrices, no certificate to lean on)
 
 
@@ -829,12 +830,15 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     keep_cost_buffer  large registrations (eight matrices >= 8 GiB) write their cost matrices into a buffer this module keeps per
                     (device, stream) between calls (see COST_CACHE_MIN_BYTES above; release_cost_buffers() frees it); False: a fresh
                     allocation per call, returned to torch's allocator afterwards
-    cost_mode       'exact' (default): the eight cost matrices bit-identical to the reference's scalar loop.  'relaxed' (opt-in
-                    experiment, one GPU, clouds of >= 1 024 points): built in relaxed float64 arithmetic (1.3-1.55x faster at
-                    50 000; every entry within 2e-13 of the exact cost) and used ONLY through a uniqueness certificate whose
-                    margin covers that error (2 min(N, M) delta): certified assignments are the exact matrices' by proof; a
-                    pairing that does not certify is rebuilt exactly and solved as usual — same assignment vectors either
-                    way, details['assignment']['details'][h]['cost_mode'] says which route each hypothesis took
+    cost_mode       'exact' (default): the eight cost matrices bit-identical to the reference's scalar loop.  Two opt-in modes (one
+                    GPU, clouds of >= 1 024 points) return the SAME assignment vectors by proof without those matrices:
+                    'relaxed': built in relaxed float64 arithmetic (1.55x faster at 50 000; every entry within 2e-13 of the exact
+                    cost), solved, and the result certified against the exact matrices on their matched and near-tight entries
+                    (lsap.certify_listed); 'filter' (>= 8 192 points, below that: 'relaxed'): four matrices in packed float32
+                    arithmetic (3.2x faster, within 1e-6) only SELECT entries, every cost the solver and the certificate use is
+                    evaluated exactly (lsap.FilteredMatrix).  A pairing that cannot be certified (ties, near-ties) gets its exact
+                    matrices built and goes the exact mode's way; details['assignment']['details'][h]['cost_mode'] says which
+                    route each hypothesis took
     icp_one_launch  None: perform_icp.ONE_LAUNCH decides (default False: one launch per iteration); True: iterations 1 .. n-1 of the
                     Affine ICP loop in one launch of persistent workgroups (only for a device that does nothing else meanwhile;
                     estimate_transform_batch always passes False: its workers keep several streams busy) — identical results
@@ -897,11 +901,12 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             else:
                 if keep_cost_buffer and mov.is_cuda and need >= COST_CACHE_MIN_BYTES and world == 1:
                     lease = cost_buffer(mov.device, (8, sc_m.shape[1], sc_f.shape[1]))     # None: another registration holds it
-                if (cost_mode == 'relaxed' and world == 1 and mov.is_cuda and hasattr(be, "chi2_cost8_relaxed")
+                use_filter = cost_mode == 'filter' and min(mov.shape[1], fix.shape[1]) >= FILTER_MIN_POINTS
+                if (cost_mode in ('relaxed', 'filter') and not use_filter and world == 1 and mov.is_cuda and hasattr(be, "chi2_cost8_relaxed")
                         and min(mov.shape[1], fix.shape[1]) >= RELAXED_MIN_POINTS):
                     relaxed = be.chi2_cost8_relaxed(sc_m, sc_f, out=None if lease is None else lease.view)
-                if (cost_mode == 'filter' and world == 1 and mov.is_cuda and getattr(be, "device_sampler", False)
-                        and min(mov.shape[1], fix.shape[1]) >= RELAXED_MIN_POINTS and (sc_f.shape[0] == 1 or be.K.chi2_symmetric(sc_m, sc_f))):
+                if (use_filter and world == 1 and mov.is_cuda and getattr(be, "device_sampler", False)
+                        and (sc_f.shape[0] == 1 or be.K.chi2_symmetric(sc_m, sc_f))):
                     filtered = True
                     U = be.K.chi2_filter4(sc_m[0], sc_f[0], out=None if lease is None else lease.view[:4])
                 elif relaxed is not None:
@@ -925,8 +930,8 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                 def entries_np(t):
                     return lambda rows, cols: tuple(x.cpu().numpy() for x in be.K.chi2_entries(sc_m1, sc_f1, t, rows, cols))
 
-                def entries_t(t):
-                    return lambda rows, cols: be.K.chi2_entries(sc_m1, sc_f1, t, rows, cols)
+                def entries_t(t):              # (index lists from the library's own kernels: no range check, no read-back)
+                    return lambda rows, cols: be.K.chi2_entries(sc_m1, sc_f1, t, rows, cols, trusted=True)
                 lsa = solve_four_filtered(U, entries_np, entries_t, be.K.chi2_filter_delta() + 1e-13,
                                           lambda t: be.K.chi2_cost_pair(sc_m, sc_f, t, sc_f.shape[0] == 1 or be.K.chi2_symmetric(sc_m, sc_f)),
                                           info=a_info, accept_near_ties=accept_near_ties)

@@ -186,11 +186,14 @@ def test_filter_build_is_within_its_bound_of_both_orders_of_every_pairing(g, n, 
     assert worst <= delta
 
 
-@pytest.mark.parametrize("n,m,seed", [(3000, 2900, 77), (5000, 5000, 42), (2400, 2600, 3), (1200, 1200, 9), (600, 650, 1)])
-def test_filter_mode_returns_the_exact_modes_registration(g, n, m, seed):
+@pytest.mark.parametrize("n,m,seed", [(3000, 2900, 77), (5000, 5000, 42), (2400, 2600, 3), (1200, 1200, 9), (600, 650, 1), (9000, 8400, 4)])
+def test_filter_mode_returns_the_exact_modes_registration(g, n, m, seed, monkeypatch):
     """estimate_transform(cost_mode='filter'): no exact matrix is built, the assignment is solved with exact costs on the entries a
     float32 build selects and certified against both exact matrices of every pairing — the same assignment vectors, inlier counts
-    and transforms as the exact mode, bit for bit."""
+    and transforms as the exact mode, bit for bit.  (The mode hands clouds below FILTER_MIN_POINTS to the relaxed mode; the
+    threshold is lowered here so that the small cases run through the filter too; the last case is above it as shipped.)"""
+    if min(n, m) < g.P.FILTER_MIN_POINTS:
+        monkeypatch.setattr(g.P, "FILTER_MIN_POINTS", g.P.RELAXED_MIN_POINTS)
     mv, fx, _ = synth_pair(max(n, m), seed)
     mv, fx = np.ascontiguousarray(mv[:, :n]), np.ascontiguousarray(fx[:, :m])
     kw = dict(ransac_trials=400, icp_iterations=6, seed=5)
@@ -206,7 +209,8 @@ def test_filter_mode_returns_the_exact_modes_registration(g, n, m, seed):
         print("%d x %d: %s; polishing rounds %s" % (n, m, modes[0], [d.get("polish_violated") for d in dr["assignment"]["details"][:4]]))
 
 
-def test_filter_mode_on_tied_clouds_builds_the_pairings_exactly(g):
+def test_filter_mode_on_tied_clouds_builds_the_pairings_exactly(g, monkeypatch):
+    monkeypatch.setattr(g.P, "FILTER_MIN_POINTS", g.P.RELAXED_MIN_POINTS)
     n = 1400
     mv, fx, _ = synth_pair(n, 23)
     mv, fx = mv.copy(), fx.copy()

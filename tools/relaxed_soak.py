@@ -4,7 +4,7 @@ lattices (tied distances, duplicates), the same cloud twice (zero-cost matches, 
 (copies of nuclei displaced by 1e-9..1e-5 of the cloud's size: cost rows that differ in the 9th to 14th digit — alternatives inside,
 at and above the certificate's margins).  Every case must return the exact mode's assignment vectors, inlier counts and 4x4
 matrices bit for bit, whether its hypotheses were certified on the relaxed build or rebuilt exactly (both are counted).
-Usage: python tools/relaxed_soak.py [seconds] [max_points] [first_seed]"""
+Usage: python tools/relaxed_soak.py [seconds] [max_points] [first_seed] [relaxed|filter]"""
 import os
 import sys
 import time
@@ -22,6 +22,9 @@ from platymatch_amd.estimate_transform import perform_icp as pi  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 max_points = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+mode = sys.argv[4] if len(sys.argv) > 4 else "relaxed"        # or "filter" (its size threshold is lowered so that every case runs through it)
+if mode == "filter":
+    P.FILTER_MIN_POINTS = P.RELAXED_MIN_POINTS
 pi.VERBOSE = False
 lo = P.RELAXED_MIN_POINTS
 
@@ -60,7 +63,7 @@ while time.perf_counter() < t_end:
     try:
         de, dr = {}, {}
         a = P.estimate_transform(mv, fx, details=de, **kw)
-        b = P.estimate_transform(mv, fx, details=dr, cost_mode='relaxed', **kw)
+        b = P.estimate_transform(mv, fx, details=dr, cost_mode=mode, **kw)
         same = all(np.array_equal(de["lsa"][h][0], dr["lsa"][h][0]) and np.array_equal(de["lsa"][h][1], dr["lsa"][h][1]) for h in range(8))
         same = same and np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
         if not same:
@@ -68,14 +71,14 @@ while time.perf_counter() < t_end:
         modes = [d.get("cost_mode", "") for d in dr.get("assignment", {}).get("details", [])]
         c = counts.setdefault(kind, dict(cases=0, certified_on_relaxed=0, rebuilt_exactly=0))
         c["cases"] += 1
-        c["certified_on_relaxed"] += sum(m.startswith("relaxed") for m in modes)
+        c["certified_on_relaxed"] += sum(m.startswith(mode) for m in modes)
         c["rebuilt_exactly"] += sum(m.startswith("exact") for m in modes)
     except Exception as e:      # noqa: BLE001 — a probe: report and go on
         fails.append(tag + ": %s: %s" % (type(e).__name__, str(e)[:200]))
     seed += 1
-print("relaxed soak: seeds %d..%d, %d..%d points" % (seed0, seed - 1, lo, max_points))
+print("%s soak: seeds %d..%d, %d..%d points" % (mode, seed0, seed - 1, lo, max_points))
 for kind, c in sorted(counts.items()):
-    print("  %-18s %4d cases: %5d hypotheses certified on the relaxed build, %5d rebuilt exactly" % (kind, c["cases"], c["certified_on_relaxed"], c["rebuilt_exactly"]))
+    print("  %-18s %4d cases: %5d hypotheses settled without an exact matrix, %5d built exactly" % (kind, c["cases"], c["certified_on_relaxed"], c["rebuilt_exactly"]))
 print("mismatches: %d" % len(fails))
 for f in fails[:40]:
     print("  " + f)
