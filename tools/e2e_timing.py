@@ -81,5 +81,5 @@ for mode in ("relaxed", "filter"):
         wall = (time.perf_counter() - t) * 1e3
         modes = [d.get("cost_mode", "?") for d in det.get("assignment", {}).get("details", [])]
         print("%-34s %9.1f ms   (hypotheses settled without an exact matrix %d of 8, built exactly %d; assignments equal the exact mode's: %s)  stages %s"
-              % ("estimate_transform, " + mode, wall, sum(m.startswith(mode) for m in modes), sum(m.startswith("exact") for m in modes),
+              % ("estimate_transform, " + mode, wall, sum(m.startswith(("relaxed", "filter")) for m in modes), sum(m.startswith("exact") for m in modes),
                  all(np.array_equal(x[1], y[1]) for x, y in zip(det["lsa"], lsa)), {k: round(v, 3) for k, v in det.get("timing", {}).items()}), flush=True)
