@@ -899,6 +899,7 @@ def solve_core(M, info=None):
             # reduced cost can lie below the collection margin is listed and priced with its exact cost, until none violates: the duals
             # are then feasible on all of them to the bit and every unlisted entry is further than the margin from tight.
             polish = 0
+            t_p = time.perf_counter()
             while True:
                 lst = M.threshold_select(u, v, c4r)
                 if lst is None or not np.isfinite(lst[1][lst[0] >= 0]).all():
@@ -908,6 +909,9 @@ def solve_core(M, info=None):
                 if info is not None:
                     info.setdefault("polish_violated", []).append(violated)
                 if violated == 0:
+                    if info is not None:
+                        info.update(polish_seconds=time.perf_counter() - t_p, polish_list_shape=tuple(lst[0].shape),
+                                    polish_listed=int((lst[0] >= 0).sum()))
                     break
                 if polish >= MAX_PRICING_ROUNDS:
                     return None
