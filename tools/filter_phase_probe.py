@@ -9,7 +9,7 @@ from conftest import synth_pair
 from platymatch_amd import pipeline as P
 from platymatch_amd.estimate_transform import perform_icp as pi
 pi.VERBOSE=False
-n=int(sys.argv[1])
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 mv,fx,_=synth_pair(n,42)
 for rep in range(3):
     det={"timing":True}
