@@ -7,9 +7,9 @@ which releases the GIL: `solve_many` runs the eight solves on eight host threads
 the GPU."""
 import ctypes
 import os
-from concurrent.futures import ThreadPoolExecutor
-
+import threading
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -1136,6 +1136,7 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
     infos = [dict() for _ in range(8)]
     pairs = [(h, [t for t, s_ in TWINS.items() if s_ == h][0]) for h in range(4)]
     caller = torch.cuda.current_stream(F4.device).cuda_stream
+    exact_turn = threading.Lock()
 
     def pair(t):
         h, twin = pairs[t]
@@ -1161,11 +1162,12 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
             if got[0] is None or got[1] is None:
                 infos[h].clear()
                 infos[twin].clear()
-                U2 = exact_pair(t)
-                got = solve_pair_on_device(U2[0], U2[1], infos[h], infos[twin], allow_host, accept_near_ties)
+                with exact_turn:        # one pairing's exact matrices at a time: four filter matrices + two exact ones never exceed the exact mode's eight
+                    U2 = exact_pair(t)
+                    got = solve_pair_on_device(U2[0], U2[1], infos[h], infos[twin], allow_host, accept_near_ties)
+                    del U2
                 for i in (infos[h], infos[twin]):
                     i["cost_mode"] = "exact (built: the filtered solve did not certify)"
-                del U2
             out[h], out[twin] = got
             stream.synchronize()
 
