@@ -203,6 +203,10 @@ size_t pm_chi2_filter_workspace_bytes(int nM, int nF);
 double pm_chi2_filter_delta(void);
 int pm_chi2_filter4(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out4, size_t ld, size_t matrix_stride,
                     void *ws, size_t ws_bytes, void *stream);
+/* One pairing's filter matrix alone (out1 [nM][ld]; a quarter of the launch, the same values): for clouds whose four filter
+ * matrices do not fit in HBM together. */
+int pm_chi2_filter_pair(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out1, size_t ld,
+                        void *ws, size_t ws_bytes, void *stream);
 
 /* Listed entries of one pairing's two EXACT matrices (the bits of pm_chi2_cost_pair_sym's): out_natural[e], out_rolled[e] =
  * entry (rows[e], cols[e]) of the natural-order matrix (U11, U12, U13, U14 for pairing 0..3) and of its rolled-order twin (U22,

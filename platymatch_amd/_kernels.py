@@ -339,6 +339,21 @@ def chi2_filter4(sc_m1, sc_f1, out=None):
     return out
 
 
+def chi2_filter_pair(sc_m1, sc_f1, pairing, out=None):
+    """One pairing's filter matrix alone -> [nM, nF] float64 (pm_chi2_filter_pair: matrix `pairing` of chi2_filter4, the same values)."""
+    torch = _t()
+    a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
+    nM, nF = a.shape[0], b.shape[0]
+    if out is None:
+        out = torch.empty((nM, nF), dtype=torch.float64, device=a.device)
+    if tuple(out.shape) != (nM, nF) or out.dtype != torch.float64 or out.device != a.device or out.stride(1) != 1 or out.stride(0) < nF:
+        raise ValueError("out must be a float64 tensor [nM, nF] on the descriptors' device with unit column stride")
+    lib = nat.load()
+    ws = torch.empty(int(lib.pm_chi2_filter_workspace_bytes(nM, nF)), dtype=torch.uint8, device=a.device)
+    check(lib.pm_chi2_filter_pair(ptr(a), nM, ptr(b), nF, int(pairing), ptr(out), out.stride(0), ptr(ws), ws.numel(), nat.stream_ptr()))
+    return out
+
+
 def chi2_filter_delta():
     """Absolute per-entry error bound of chi2_filter4 against the exact cost (csrc/pm_chi2.hip: PM_CHI2_FILTER_DELTA)."""
     return float(nat.load().pm_chi2_filter_delta())

@@ -85,6 +85,7 @@ SIGNATURES = {
     "pm_chi2_filter_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
     "pm_chi2_filter_delta": (_c_double, []),
     "pm_chi2_filter4": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_size_t, _c_size_t, _c_void_p, _c_size_t, _c_void_p]),
+    "pm_chi2_filter_pair": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p, _c_size_t, _c_void_p]),
     "pm_chi2_entries_sym": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "pm_chi2_cost8_relaxed": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_size_t, _c_size_t, _c_void_p, _c_size_t, _c_int, _c_void_p]),
     "pm_chi2_cost8_sym_ws": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_size_t, _c_size_t, _c_void_p, _c_size_t, _c_void_p]),

@@ -481,6 +481,7 @@ __global__ __launch_bounds__(256) void entries_sym_kernel(const double *__restri
 #define PM_CHI2_FILTER_DELTA 1e-6
 typedef float pm_f2 __attribute__((ext_vector_type(2)));
 
+template <int TSEL>      // -1: the four pairings -> out + t * mstride; t: pairing t alone -> out
 __global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__restrict__ scA, int nA, const double *__restrict__ scB, int nB,
                                                                 double *__restrict__ out, size_t ld, size_t mstride, int nTi,
                                                                 unsigned int nblocks, const double *__restrict__ sumA,
@@ -496,11 +497,12 @@ __global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__
     const int i0 = ti * TI, j0 = tj * CH_TJ;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double acc[RI][4];
+    constexpr int NT = TSEL < 0 ? 4 : 1;
+    double acc[RI][NT];
 #pragma unroll
     for (int r = 0; r < RI; ++r)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[r][t] = 0.0;
+        for (int t = 0; t < NT; ++t) acc[r][t] = 0.0;
     for (int g = 0; g < CH_STAGES; ++g) {
         __syncthreads();
         if (tid < TI * CH_K) {
@@ -521,26 +523,27 @@ __global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__
         }
 #pragma unroll
         for (int r = 0; r < RI; ++r) {
-            pm_f2 a[6], s4[4];
+            pm_f2 a[6], s4[NT];
 #pragma unroll
             for (int k = 0; k < 6; ++k) a[k] = *reinterpret_cast<const pm_f2 *>(&A_s[wave * RI + r][2 * k]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) s4[t] = (pm_f2){0.f, 0.f};
+            for (int t = 0; t < NT; ++t) s4[t] = (pm_f2){0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 // moving bins (2k, 2k+1) meet fixed bins: pairing 0 the same; 1: +6; 2: (11-2k, 10-2k) = pair 5-k swapped;
                 // 3: (17-2k, 16-2k) mod 12 = pair (8-k) mod 6 swapped
                 const pm_f2 q[4] = {b[k], b[(k + 3) % 6], br[5 - k], br[(8 - k) % 6]};
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int tt = 0; tt < NT; ++tt) {
+                    const int t = TSEL < 0 ? tt : TSEL;
                     const pm_f2 sm = a[k] + q[t];
                     const pm_f2 pr = a[k] * q[t];
                     const pm_f2 rc = (pm_f2){__builtin_amdgcn_rcpf(sm.x), __builtin_amdgcn_rcpf(sm.y)};
-                    s4[t] = __builtin_elementwise_fma(pr, rc, s4[t]);
+                    s4[tt] = __builtin_elementwise_fma(pr, rc, s4[tt]);
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[r][t] += (double)(s4[t].x + s4[t].y);
+            for (int t = 0; t < NT; ++t) acc[r][t] += (double)(s4[t].x + s4[t].y);
         }
     }
     const int gj = j0 + lane;
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__
             if (gi < nA) {
                 const double half = 0.5 * (sumA[gi] + sumB[gj]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) out[(size_t)t * mstride + (size_t)gi * ld + gj] = __builtin_fma(-2.0, acc[r][t], half);
+                for (int t = 0; t < NT; ++t) out[(size_t)t * mstride + (size_t)gi * ld + gj] = __builtin_fma(-2.0, acc[r][t], half);
             }
         }
     }
@@ -772,22 +775,43 @@ extern "C" size_t pm_chi2_filter_workspace_bytes(int nM, int nF) {
 
 extern "C" double pm_chi2_filter_delta(void) { return PM_CHI2_FILTER_DELTA; }
 
-extern "C" int pm_chi2_filter4(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out4, size_t ld, size_t matrix_stride,
-                               void *ws, size_t ws_bytes, void *stream) {
-    if (!sc_m1 || !sc_f1 || !out4 || nM <= 0 || nF <= 0 || ld < (size_t)nF || matrix_stride < (size_t)nM * ld)
+namespace pm {
+static int filter_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out, size_t ld, size_t matrix_stride,
+                         void *ws, size_t ws_bytes, void *stream) {
+    if (!sc_m1 || !sc_f1 || !out || nM <= 0 || nF <= 0 || ld < (size_t)nF || (pairing < 0 && matrix_stride < (size_t)nM * ld))
         return PM_ERR_INVALID_ARG;
     if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < pm_chi2_filter_workspace_bytes(nM, nF)) return PM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     double *sumA = (double *)ws;
-    double *sumB = (double *)((char *)ws + pm::align_up((size_t)nM * 8, 256));
-    pm::relaxed_rowsum_kernel<<<(nM + 255) / 256, 256, 0, s>>>(sc_m1, nM, sumA);
-    pm::relaxed_rowsum_kernel<<<(nF + 255) / 256, 256, 0, s>>>(sc_f1, nF, sumB);
-    const long nTi = ((long)nM + 15) / 16, nTj = ((long)nF + pm::CH_TJ - 1) / pm::CH_TJ;
+    double *sumB = (double *)((char *)ws + align_up((size_t)nM * 8, 256));
+    relaxed_rowsum_kernel<<<(nM + 255) / 256, 256, 0, s>>>(sc_m1, nM, sumA);
+    relaxed_rowsum_kernel<<<(nF + 255) / 256, 256, 0, s>>>(sc_f1, nF, sumB);
+    const long nTi = ((long)nM + 15) / 16, nTj = ((long)nF + CH_TJ - 1) / CH_TJ;
     const long nblocks = nTi * nTj;
     if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
-    pm::filter4_kernel<<<(unsigned int)nblocks, pm::CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out4, ld, matrix_stride, (int)nTi,
-                                                                       (unsigned int)nblocks, sumA, sumB);
-    return pm::launch_status();
+    const unsigned int grid = (unsigned int)nblocks;
+    switch (pairing) {
+        case -1: filter4_kernel<-1><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, (int)nTi, grid, sumA, sumB); break;
+        case 0: filter4_kernel<0><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
+        case 1: filter4_kernel<1><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
+        case 2: filter4_kernel<2><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
+        case 3: filter4_kernel<3><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
+        default: return PM_ERR_INVALID_ARG;
+    }
+    return launch_status();
+}
+}  // namespace pm
+
+extern "C" int pm_chi2_filter4(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out4, size_t ld, size_t matrix_stride,
+                               void *ws, size_t ws_bytes, void *stream) {
+    return pm::filter_launch(sc_m1, nM, sc_f1, nF, -1, out4, ld, matrix_stride, ws, ws_bytes, stream);
+}
+
+// one pairing's filter matrix alone (a quarter of the launch): for clouds whose four filter matrices do not fit in HBM together
+extern "C" int pm_chi2_filter_pair(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out1, size_t ld,
+                                   void *ws, size_t ws_bytes, void *stream) {
+    if (pairing < 0 || pairing > 3) return PM_ERR_INVALID_ARG;
+    return pm::filter_launch(sc_m1, nM, sc_f1, nF, pairing, out1, ld, 0, ws, ws_bytes, stream);
 }
 
 extern "C" int pm_chi2_entries_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, const int32_t *rows,

@@ -1122,33 +1122,46 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
     return out
 
 
-def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pair, info=None, allow_host=True, accept_near_ties=False):
+def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pair, info=None, allow_host=True, accept_near_ties=False,
+                        build=None, shape=None, device=None, in_flight=4):
     """The widget's eight assignments from FOUR approximate matrices F4 [4, N, M] (pm_chi2_filter4: matrix t within cost_delta of
     hypothesis PAIRINGS[t][0]'s exact matrix and of its twin's), none of the exact matrices built: per pairing (four host threads)
     the sparse-core solve runs on a FilteredMatrix — the approximate matrix selects entries, every cost comes from
     exact_entries(t)(rows, cols) -> (hypothesis's exact values, twin's) [exact_entries_t: the same with GPU tensors] — and the
     result is certified against both exact matrices on their listed entries (certify_listed).  A pairing that cannot be certified
     (ties, near-ties, non-finite costs) gets its two exact matrices from exact_pair(t) -> [2, N, M] and goes the exact mode's
-    way (solve_pair_on_device).  -> list of eight (row_ind, col_ind)."""
+    way (solve_pair_on_device), one such pairing at a time.  -> list of eight (row_ind, col_ind).
+    STREAMED form (F4 = None; clouds whose four filter matrices do not fit in HBM together): build(t) -> the filter matrix of
+    pairing t with the SHORT side as its rows ([N, M] if N <= M, else [M, N]: pm_chi2_filter_pair with the roles swapped — the
+    terms are symmetric in their two descriptors and each pairing's bin map is an involution, so that IS the transposed filter
+    to within cost_delta), made on the pairing's own stream when its turn comes; at most in_flight pairings are resident."""
     torch = nat.torch_mod()
-    n, m = F4.shape[1], F4.shape[2]
+    if F4 is not None:
+        n, m = F4.shape[1], F4.shape[2]
+        device = F4.device
+        in_flight = 4
+    else:
+        n, m = shape
     out = [None] * 8
     infos = [dict() for _ in range(8)]
     pairs = [(h, [t for t, s_ in TWINS.items() if s_ == h][0]) for h in range(4)]
-    caller = torch.cuda.current_stream(F4.device).cuda_stream
+    caller = torch.cuda.current_stream(device).cuda_stream
     exact_turn = threading.Lock()
 
     def pair(t):
         h, twin = pairs[t]
-        stream = nat.side_stream(F4.device, ("pair", caller, h))
-        with torch.cuda.device(F4.device), torch.cuda.stream(stream):
+        stream = nat.side_stream(device, ("pair", caller, h))
+        with torch.cuda.device(device), torch.cuda.stream(stream):
             got = [None, None]
             if min(n, m) >= DEVICE_MIN_ROWS:
                 fetch, fetch_t = exact_entries(t), exact_entries_t(t)
                 if n > m:                                       # the solve runs on the transpose: rows are fixed nuclei
                     f0, f0_t = fetch, fetch_t
                     fetch, fetch_t = (lambda rows, cols: f0(cols, rows)), (lambda rows, cols: f0_t(cols, rows))
-                W = DeviceMatrix(F4[t] if n <= m else transposed(F4[t]))
+                if F4 is not None:
+                    W = DeviceMatrix(F4[t] if n <= m else transposed(F4[t]))
+                else:
+                    W = DeviceMatrix(build(t))
                 M = FilteredMatrix(W, fetch, cost_delta, fetch_t)
                 sol = solve_core(M, infos[h])
                 if sol is not None:
@@ -1159,21 +1172,34 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
                         for i in (infos[h], infos[twin]):
                             i["cost_mode"] = "filter (approximate matrix as selector, exact costs on %d listed entries)" % M.exact_evaluated
                 del W, M
+            if (got[0] is None or got[1] is None) and F4 is None:
+                deferred.append(t)      # streamed: the exact matrices are built once every filter matrix has been released
+                stream.synchronize()
+                return
             if got[0] is None or got[1] is None:
-                infos[h].clear()
-                infos[twin].clear()
-                with exact_turn:        # one pairing's exact matrices at a time: four filter matrices + two exact ones never exceed the exact mode's eight
-                    U2 = exact_pair(t)
-                    got = solve_pair_on_device(U2[0], U2[1], infos[h], infos[twin], allow_host, accept_near_ties)
-                    del U2
-                for i in (infos[h], infos[twin]):
-                    i["cost_mode"] = "exact (built: the filtered solve did not certify)"
-            out[h], out[twin] = got
+                exact(t)
+            else:
+                out[h], out[twin] = got
             stream.synchronize()
 
-    torch.cuda.current_stream(F4.device).synchronize()       # F4 was produced on the caller's stream
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    def exact(t):
+        h, twin = pairs[t]
+        infos[h].clear()
+        infos[twin].clear()
+        with exact_turn:        # one pairing's exact matrices at a time: four filter matrices + two exact ones never exceed the exact mode's eight
+            U2 = exact_pair(t)
+            out[h], out[twin] = solve_pair_on_device(U2[0], U2[1], infos[h], infos[twin], allow_host, accept_near_ties)
+            del U2
+        for i in (infos[h], infos[twin]):
+            i["cost_mode"] = "exact (built: the filtered solve did not certify)"
+
+    deferred = []
+    torch.cuda.current_stream(device).synchronize()       # the descriptors / F4 were produced on the caller's stream
+    with ThreadPoolExecutor(max_workers=max(1, min(4, int(in_flight)))) as ex:
         list(ex.map(pair, range(4)))
+    for t in sorted(deferred):
+        with torch.cuda.device(device):
+            exact(t)
     if info is not None:
         info["routes"] = [i.get("route") for i in infos]
         info["details"] = infos

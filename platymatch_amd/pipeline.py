@@ -889,6 +889,10 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             sc_m, sc_f, bn = build_descriptors(be, mov, fix, group, guards=guards, views=views)
             # all eight matrices at once when they fit (four assignments then run side by side); otherwise two at a time
             need = cost_bytes(sc_m.shape[1], mov.shape[1], sc_f.shape[1], world)
+            use_filter = (cost_mode == 'filter' and min(mov.shape[1], fix.shape[1]) >= FILTER_MIN_POINTS and world == 1 and mov.is_cuda
+                          and getattr(be, "device_sampler", False) and (sc_f.shape[0] == 1 or be.K.chi2_symmetric(sc_m, sc_f)))
+            if use_filter:
+                need = need * 3 // 4          # four filter matrices + one pairing's two exact ones at the worst
             if stream_hypotheses is not None:
                 streamed = bool(stream_hypotheses)
             else:
@@ -901,12 +905,10 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             else:
                 if keep_cost_buffer and mov.is_cuda and need >= COST_CACHE_MIN_BYTES and world == 1:
                     lease = cost_buffer(mov.device, (8, sc_m.shape[1], sc_f.shape[1]))     # None: another registration holds it
-                use_filter = cost_mode == 'filter' and min(mov.shape[1], fix.shape[1]) >= FILTER_MIN_POINTS
                 if (cost_mode in ('relaxed', 'filter') and not use_filter and world == 1 and mov.is_cuda and hasattr(be, "chi2_cost8_relaxed")
                         and min(mov.shape[1], fix.shape[1]) >= RELAXED_MIN_POINTS):
                     relaxed = be.chi2_cost8_relaxed(sc_m, sc_f, out=None if lease is None else lease.view)
-                if (use_filter and world == 1 and mov.is_cuda and getattr(be, "device_sampler", False)
-                        and (sc_f.shape[0] == 1 or be.K.chi2_symmetric(sc_m, sc_f))):
+                if use_filter:
                     filtered = True
                     U = be.K.chi2_filter4(sc_m[0], sc_f[0], out=None if lease is None else lease.view[:4])
                 elif relaxed is not None:
@@ -920,23 +922,32 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             raise
         t0 = mark("gpu_descriptors_costs", t0)
         try:
-            if streamed:
-                lsa = assign_streamed(be, sc_m, sc_f, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None),
-                                      accept_near_ties=accept_near_ties)
-            elif filtered:
+            if filtered or (streamed and use_filter):
                 from .lsap import solve_four_filtered
                 sc_m1, sc_f1 = sc_m[0], sc_f[0]
+                n_, m_ = mov.shape[1], fix.shape[1]
 
                 def entries_np(t):
                     return lambda rows, cols: tuple(x.cpu().numpy() for x in be.K.chi2_entries(sc_m1, sc_f1, t, rows, cols))
 
                 def entries_t(t):              # (index lists from the library's own kernels: no range check, no read-back)
                     return lambda rows, cols: be.K.chi2_entries(sc_m1, sc_f1, t, rows, cols, trusted=True)
-                lsa = solve_four_filtered(U, entries_np, entries_t, be.K.chi2_filter_delta() + 1e-13,
-                                          lambda t: be.K.chi2_cost_pair(sc_m, sc_f, t, sc_f.shape[0] == 1 or be.K.chi2_symmetric(sc_m, sc_f)),
-                                          info=a_info, accept_near_ties=accept_near_ties)
+
+                def build_pairing(t):          # streamed: one pairing's filter matrix, the short side as its rows
+                    return be.K.chi2_filter_pair(sc_m1, sc_f1, t) if n_ <= m_ else be.K.chi2_filter_pair(sc_f1, sc_m1, t)
+                in_flight = 4
+                if not filtered:
+                    in_flight = max(1, min(4, int(0.85 * be.free_bytes() // (8 * n_ * m_))))
+                lsa = solve_four_filtered(U if filtered else None, entries_np, entries_t, be.K.chi2_filter_delta() + 1e-13,
+                                          lambda t: be.K.chi2_cost_pair(sc_m, sc_f, t, True), info=a_info, accept_near_ties=accept_near_ties,
+                                          build=build_pairing, shape=(n_, m_), device=mov.device, in_flight=in_flight)
+                if a_info is not None and not filtered:
+                    a_info["mode"] = "streamed: %d filter matri%s resident at a time" % (in_flight, "x" if in_flight == 1 else "ces")
                 if any(a is None for a in lsa):
                     raise RuntimeError("a hypothesis could not be assigned (see accept_near_ties)")
+            elif streamed:
+                lsa = assign_streamed(be, sc_m, sc_f, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None),
+                                      accept_near_ties=accept_near_ties)
             elif relaxed is not None:
                 from .lsap import solve_eight_on_device
                 from ._kernels import PAIRINGS

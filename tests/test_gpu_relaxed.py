@@ -228,3 +228,31 @@ def test_filter_mode_on_tied_clouds_builds_the_pairings_exactly(g, monkeypatch):
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     modes = [d.get("cost_mode", "") for d in dr["assignment"]["details"]]
     assert all(x.startswith("exact (built") for x in modes), modes
+
+
+@pytest.mark.parametrize("n,m,tied", [(9000, 8400, False), (8400, 9000, False), (1500, 1400, True), (1400, 1500, True)])
+def test_streamed_filter_mode_builds_one_pairing_at_a_time_and_returns_the_exact_modes_registration(g, n, m, tied, monkeypatch):
+    """cost_mode='filter' with the hypotheses streamed (what clouds beyond HBM's four filter matrices get): each pairing's filter
+    matrix is built on its own stream when its turn comes — for N > M with the descriptors' roles swapped, which is the transposed
+    filter —, solved and certified as in the resident form; pairings that cannot be certified (the tied clouds) are built exactly
+    after every filter matrix has been released."""
+    if min(n, m) < g.P.FILTER_MIN_POINTS:
+        monkeypatch.setattr(g.P, "FILTER_MIN_POINTS", g.P.RELAXED_MIN_POINTS)
+    mv, fx, _ = synth_pair(max(n, m), 61 + n)
+    mv, fx = np.ascontiguousarray(mv[:, :n]).copy(), np.ascontiguousarray(fx[:, :m]).copy()
+    if tied:
+        mv[:, 100:108] = mv[:, 200:208]
+        fx[:, 300:304] = fx[:, 900:904]
+    kw = dict(ransac_trials=300, icp_iterations=4, seed=8)
+    de, dr = {}, {}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", g.P.EdgeGuardWarning)
+        a = g.P.estimate_transform(mv, fx, details=de, **kw)
+        b = g.P.estimate_transform(mv, fx, details=dr, cost_mode='filter', stream_hypotheses=True, **kw)
+    for h in range(8):
+        assert np.array_equal(de["lsa"][h][0], dr["lsa"][h][0]) and np.array_equal(de["lsa"][h][1], dr["lsa"][h][1]), h
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    modes = [d.get("cost_mode", "") for d in dr["assignment"]["details"]]
+    assert "streamed" in dr["assignment"]["mode"] and "filter" in dr["assignment"]["mode"], dr["assignment"]["mode"]
+    assert all(x.startswith("exact (built") if tied else x.startswith("filter") for x in modes), modes
