@@ -1131,8 +1131,8 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
     result is certified against both exact matrices on their listed entries (certify_listed).  A pairing that cannot be certified
     (ties, near-ties, non-finite costs) gets its two exact matrices from exact_pair(t) -> [2, N, M] and goes the exact mode's
     way (solve_pair_on_device), one such pairing at a time.  -> list of eight (row_ind, col_ind).
-    STREAMED form (F4 = None; clouds whose four filter matrices do not fit in HBM together): build(t) -> the filter matrix of
-    pairing t with the SHORT side as its rows ([N, M] if N <= M, else [M, N]: pm_chi2_filter_pair with the roles swapped — the
+    STREAMED form (F4 = None; clouds whose four filter matrices do not fit in HBM together): build(t, out) -> the filter matrix of
+    pairing t, written into the buffer `out`, with the SHORT side as its rows ([N, M] if N <= M, else [M, N]: pm_chi2_filter_pair with the roles swapped — the
     terms are symmetric in their two descriptors and each pairing's bin map is an involution, so that IS the transposed filter
     to within cost_delta), made on the pairing's own stream when its turn comes; at most in_flight pairings are resident."""
     torch = nat.torch_mod()
@@ -1158,10 +1158,12 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
                 if n > m:                                       # the solve runs on the transpose: rows are fixed nuclei
                     f0, f0_t = fetch, fetch_t
                     fetch, fetch_t = (lambda rows, cols: f0(cols, rows)), (lambda rows, cols: f0_t(cols, rows))
+                slot = None
                 if F4 is not None:
                     W = DeviceMatrix(F4[t] if n <= m else transposed(F4[t]))
                 else:
-                    W = DeviceMatrix(build(t))
+                    slot = pool.get()                           # one of the in_flight buffers, allocated once (22 ms per GB on this pool)
+                    W = DeviceMatrix(build(t, slot))
                 M = FilteredMatrix(W, fetch, cost_delta, fetch_t)
                 sol = solve_core(M, infos[h])
                 if sol is not None:
@@ -1172,6 +1174,9 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
                         for i in (infos[h], infos[twin]):
                             i["cost_mode"] = "filter (approximate matrix as selector, exact costs on %d listed entries)" % M.exact_evaluated
                 del W, M
+                if slot is not None:
+                    stream.synchronize()                        # the solve's last passes have read the buffer
+                    pool.put(slot)
             if (got[0] is None or got[1] is None) and F4 is None:
                 deferred.append(t)      # streamed: the exact matrices are built once every filter matrix has been released
                 stream.synchronize()
@@ -1194,9 +1199,18 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
             i["cost_mode"] = "exact (built: the filtered solve did not certify)"
 
     deferred = []
+    workers = max(1, min(4, int(in_flight)))
+    pool = None
+    if F4 is None:
+        import queue
+        pool = queue.Queue()
+        with torch.cuda.device(device):
+            for _ in range(workers):
+                pool.put(torch.empty((min(n, m), max(n, m)), dtype=torch.float64, device=device))
     torch.cuda.current_stream(device).synchronize()       # the descriptors / F4 were produced on the caller's stream
-    with ThreadPoolExecutor(max_workers=max(1, min(4, int(in_flight)))) as ex:
+    with ThreadPoolExecutor(max_workers=workers) as ex:
         list(ex.map(pair, range(4)))
+    pool = None                                           # (the buffers go back to the allocator before any exact matrix is built)
     for t in sorted(deferred):
         with torch.cuda.device(device):
             exact(t)

@@ -933,8 +933,8 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                 def entries_t(t):              # (index lists from the library's own kernels: no range check, no read-back)
                     return lambda rows, cols: be.K.chi2_entries(sc_m1, sc_f1, t, rows, cols, trusted=True)
 
-                def build_pairing(t):          # streamed: one pairing's filter matrix, the short side as its rows
-                    return be.K.chi2_filter_pair(sc_m1, sc_f1, t) if n_ <= m_ else be.K.chi2_filter_pair(sc_f1, sc_m1, t)
+                def build_pairing(t, out):     # streamed: one pairing's filter matrix, the short side as its rows
+                    return be.K.chi2_filter_pair(sc_m1, sc_f1, t, out=out) if n_ <= m_ else be.K.chi2_filter_pair(sc_f1, sc_m1, t, out=out)
                 in_flight = 4
                 if not filtered:
                     in_flight = max(1, min(4, int(0.85 * be.free_bytes() // (8 * n_ * m_))))

@@ -2,7 +2,7 @@
 """One complete unsupervised registration of two N-point clouds through the driver, with the stage split — for sizes
 at which the eight cost matrices (64 N M bytes) exceed HBM and the pipeline streams the hypotheses two matrices at a time
 (N > ~67 000 on one MI355X).  Since round 4 a hypothesis whose optimum has a near-tie is settled on its block (lsap.resolve_near_ties):
-the call passes NO accept_near_ties and must not raise.  Usage: python tools/big_registration.py N [ransac_trials [icp_iterations]]"""
+the call passes NO accept_near_ties and must not raise.  Usage: python tools/big_registration.py N [ransac_trials [icp_iterations [cost_mode]]]"""
 import os
 import sys
 import threading
@@ -21,6 +21,7 @@ from platymatch_amd.estimate_transform import perform_icp as pi  # noqa: E402
 n = int(sys.argv[1])
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 8000
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+cost_mode = sys.argv[4] if len(sys.argv) > 4 else "exact"
 pi.VERBOSE = False
 t_start = time.perf_counter()
 stop = threading.Event()
@@ -37,11 +38,11 @@ mv, fx, A_gt = synth_pair(n, 42)
 P.estimate_transform(mv[:, :400], fx[:, :400], ransac_trials=50, icp_iterations=2)          # warm-up
 det = {"timing": True}
 t = time.perf_counter()
-A_sc, A_icp, inl = P.estimate_transform(mv, fx, ransac_trials=trials, ransac_error=16, icp_iterations=iters, seed=0, details=det)
+A_sc, A_icp, inl = P.estimate_transform(mv, fx, ransac_trials=trials, ransac_error=16, icp_iterations=iters, seed=0, details=det, cost_mode=cost_mode)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t
 stop.set()
 err = np.linalg.norm(A_icp @ A_sc - A_gt) / np.linalg.norm(A_gt)
-print("N = M = %d: complete registration in %.1f s; inliers %s; rel. error vs ground truth %.2e" % (n, dt, inl.tolist(), err))
+print("N = M = %d, cost_mode=%r: complete registration in %.1f s; inliers %s; rel. error vs ground truth %.2e" % (n, cost_mode, dt, inl.tolist(), err))
 print("stage seconds:", {k: round(v, 2) for k, v in det["timing"].items()})
 print("assignment:", det["assignment"].get("mode", "eight matrices resident"), det["assignment"].get("routes"))
