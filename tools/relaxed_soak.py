@@ -54,6 +54,7 @@ def case(seed):
 
 counts, fails = {}, []
 t_end = time.perf_counter() + budget
+t_print = time.perf_counter() + 30.0
 seed = seed0
 warnings.simplefilter("ignore", P.EdgeGuardWarning)
 while time.perf_counter() < t_end:
@@ -76,6 +77,9 @@ while time.perf_counter() < t_end:
     except Exception as e:      # noqa: BLE001 — a probe: report and go on
         fails.append(tag + ": %s: %s" % (type(e).__name__, str(e)[:200]))
     seed += 1
+    if time.perf_counter() > t_print:              # a progress line every half minute (a silent run is taken to be hung)
+        print("... %d cases, %d mismatches" % (sum(c["cases"] for c in counts.values()), len(fails)), flush=True)
+        t_print = time.perf_counter() + 30.0
 print("%s soak: seeds %d..%d, %d..%d points" % (mode, seed0, seed - 1, lo, max_points))
 for kind, c in sorted(counts.items()):
     print("  %-18s %4d cases: %5d hypotheses settled without an exact matrix, %5d built exactly" % (kind, c["cases"], c["certified_on_relaxed"], c["rebuilt_exactly"]))

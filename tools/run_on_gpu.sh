@@ -42,7 +42,7 @@ for JOB in "$@"; do
     soak)       # random registrations against the oracle for SOAK_SECONDS (tests/probes/soak_parity.py; PM_SOAK_LOPSIDED=1 for the lopsided family)
       timeout -k 10 $(( ${SOAK_SECONDS:-240} + 120 )) python tests/probes/soak_parity.py ${SOAK_SECONDS:-240} ${SOAK_POINTS:-500} ${SOAK_SEED:-0} 2>&1 | grep -v amdgpu.ids > $O/${TAG}_soak_parity.txt || true; tail -6 $O/${TAG}_soak_parity.txt ;;
     rsoak)      # cost_mode='relaxed' against the exact mode on random registrations for SOAK_SECONDS (tools/relaxed_soak.py)
-      timeout -k 10 $(( ${SOAK_SECONDS:-240} + 120 )) python tools/relaxed_soak.py ${SOAK_SECONDS:-240} ${SOAK_POINTS:-3000} ${SOAK_SEED:-0} ${SOAK_MODE:-relaxed} 2>&1 | grep -v amdgpu.ids > $O/${TAG}_relaxed_soak.txt || true; tail -8 $O/${TAG}_relaxed_soak.txt ;;
+      timeout -k 10 $(( ${SOAK_SECONDS:-240} + 120 )) python tools/relaxed_soak.py ${SOAK_SECONDS:-240} ${SOAK_POINTS:-3000} ${SOAK_SEED:-0} ${SOAK_MODE:-relaxed} 2>&1 | grep --line-buffered -v amdgpu.ids > $O/${TAG}_relaxed_soak.txt || true; tail -8 $O/${TAG}_relaxed_soak.txt ;;
     icp)        # ICP per-iteration timing and phase stamps (diagnostic build)
       for n in 5000 20000 50000; do timeout -k 10 200 python tools/icp_profile.py $n 2>&1 | grep -v amdgpu.ids; done > $O/${TAG}_icp_timing.txt; tail -6 $O/${TAG}_icp_timing.txt ;;
     *) echo "unknown job $JOB"; exit 2 ;;
