@@ -195,7 +195,7 @@ int pm_chi2_cost8_relaxed(const double *sc_m1, int nM, const double *sc_f1, int 
                           size_t matrix_stride, void *ws, size_t ws_bytes, int variant, void *stream);
 /* OPT-IN (round 4): the FILTER build — the four pairings' matrices (out4 + t * matrix_stride, t = 0..3: U11/U22, U12/U21, U13/U24,
  * U14/U23, each pair one matrix) in packed float32 arithmetic, written as float64; every entry within pm_chi2_filter_delta()
- * (absolute, 1e-6) of the exact cost.  3.2x faster than the exact eight-matrix launch, half its output.  Not the reference's
+ * (absolute, 1.1e-6) of the exact cost.  3.2x faster than the exact eight-matrix launch, half its output.  Not the reference's
  * values and never handed out as such: the matrices only tell the assignment solver WHICH entries can matter, every cost it uses
  * is evaluated exactly by pm_chi2_entries_sym (the Python mirror: lsap.FilteredMatrix, estimate_transform(cost_mode='filter')).
  * ws: pm_chi2_filter_workspace_bytes of 16-byte aligned device memory.  Same precondition as pm_chi2_cost8_sym (symmetry flag 0). */
@@ -207,6 +207,20 @@ int pm_chi2_filter4(const double *sc_m1, int nM, const double *sc_f1, int nF, do
  * matrices do not fit in HBM together. */
 int pm_chi2_filter_pair(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out1, size_t ld,
                         void *ws, size_t ws_bytes, void *stream);
+/* The same filter matrices STORED as float32 (within pm_chi2_filter_delta() of the exact cost all the same): half the memory — four
+ * matrices of 100 000 x 100 000 resident, one of 200 000 x 200 000 — and half the traffic of the solver's dense passes, which
+ * have float32 forms for them: pm_lsap_row_select_f32, pm_lsap_col_min_f32, pm_lsap_certificate_f32 (same contracts as their
+ * float64 namesakes; reduced costs are formed in float64 from the converted entry). */
+int pm_chi2_filter4_f32(const double *sc_m1, int nM, const double *sc_f1, int nF, float *out4, size_t ld, size_t matrix_stride,
+                        void *ws, size_t ws_bytes, void *stream);
+int pm_chi2_filter_pair_f32(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, float *out1, size_t ld,
+                            void *ws, size_t ws_bytes, void *stream);
+int pm_lsap_row_select_f32(const float *U, int nr, int nc, size_t ld, const double *v, int k, int32_t *out_col, double *out_cost,
+                           int32_t *nonfinite1, void *stream);
+int pm_lsap_col_min_f32(const float *U, int nr, int nc, size_t ld, double *v, void *ws, size_t ws_bytes, void *stream);
+int pm_lsap_certificate_f32(const float *U, int nr, int nc, size_t ld, const double *u, const double *v, const int32_t *col4row,
+                            double delta, double eps, int32_t *summary4, double *stats2, int32_t *tight, double *tight_red, int cap,
+                            double *row_slack, double *row_neg, void *stream);
 
 /* Listed entries of one pairing's two EXACT matrices (the bits of pm_chi2_cost_pair_sym's): out_natural[e], out_rolled[e] =
  * entry (rows[e], cols[e]) of the natural-order matrix (U11, U12, U13, U14 for pairing 0..3) and of its rolled-order twin (U22,

@@ -321,36 +321,40 @@ def chi2_relaxed_delta():
     return float(nat.load().pm_chi2_relaxed_delta())
 
 
-def chi2_filter4(sc_m1, sc_f1, out=None):
-    """OPT-IN: the four pairings' cost matrices in packed float32 arithmetic -> [4, nM, nF] float64, every entry within
-    chi2_filter_delta() of the exact cost (pm_chi2_filter4).  A FILTER for the assignment solver (lsap.FilteredMatrix), never a
-    result: matrix t stands for hypothesis PAIRINGS[t][0] and for its twin."""
+def chi2_filter4(sc_m1, sc_f1, out=None, dtype=None):
+    """OPT-IN: the four pairings' cost matrices in packed float32 arithmetic -> [4, nM, nF] float64 (or float32: dtype / out's),
+    every entry within chi2_filter_delta() of the exact cost (pm_chi2_filter4 / _f32).  A FILTER for the assignment solver
+    (lsap.FilteredMatrix), never a result: matrix t stands for hypothesis PAIRINGS[t][0] and for its twin."""
     torch = _t()
     a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
     nM, nF = a.shape[0], b.shape[0]
     if out is None:
-        out = torch.empty((4, nM, nF), dtype=torch.float64, device=a.device)
-    if (tuple(out.shape) != (4, nM, nF) or out.dtype != torch.float64 or out.device != a.device or out.stride(2) != 1
+        out = torch.empty((4, nM, nF), dtype=dtype or torch.float64, device=a.device)
+    if (tuple(out.shape) != (4, nM, nF) or out.dtype not in (torch.float64, torch.float32) or out.device != a.device or out.stride(2) != 1
             or out.stride(1) < nF or out.stride(0) < nM * out.stride(1)):
-        raise ValueError("out must be a float64 tensor [4, nM, nF] on the descriptors' device with unit column stride")
+        raise ValueError("out must be a float64 or float32 tensor [4, nM, nF] on the descriptors' device with unit column stride")
     lib = nat.load()
     ws = torch.empty(int(lib.pm_chi2_filter_workspace_bytes(nM, nF)), dtype=torch.uint8, device=a.device)
-    check(lib.pm_chi2_filter4(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(), nat.stream_ptr()))
+    fn = lib.pm_chi2_filter4_f32 if out.dtype == torch.float32 else lib.pm_chi2_filter4
+    check(fn(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(), nat.stream_ptr()))
     return out
 
 
-def chi2_filter_pair(sc_m1, sc_f1, pairing, out=None):
-    """One pairing's filter matrix alone -> [nM, nF] float64 (pm_chi2_filter_pair: matrix `pairing` of chi2_filter4, the same values)."""
+def chi2_filter_pair(sc_m1, sc_f1, pairing, out=None, dtype=None):
+    """One pairing's filter matrix alone -> [nM, nF] float64 or float32 (pm_chi2_filter_pair / _f32: matrix `pairing` of
+    chi2_filter4, the same values)."""
     torch = _t()
     a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
     nM, nF = a.shape[0], b.shape[0]
     if out is None:
-        out = torch.empty((nM, nF), dtype=torch.float64, device=a.device)
-    if tuple(out.shape) != (nM, nF) or out.dtype != torch.float64 or out.device != a.device or out.stride(1) != 1 or out.stride(0) < nF:
-        raise ValueError("out must be a float64 tensor [nM, nF] on the descriptors' device with unit column stride")
+        out = torch.empty((nM, nF), dtype=dtype or torch.float64, device=a.device)
+    if (tuple(out.shape) != (nM, nF) or out.dtype not in (torch.float64, torch.float32) or out.device != a.device or out.stride(1) != 1
+            or out.stride(0) < nF):
+        raise ValueError("out must be a float64 or float32 tensor [nM, nF] on the descriptors' device with unit column stride")
     lib = nat.load()
     ws = torch.empty(int(lib.pm_chi2_filter_workspace_bytes(nM, nF)), dtype=torch.uint8, device=a.device)
-    check(lib.pm_chi2_filter_pair(ptr(a), nM, ptr(b), nF, int(pairing), ptr(out), out.stride(0), ptr(ws), ws.numel(), nat.stream_ptr()))
+    fn = lib.pm_chi2_filter_pair_f32 if out.dtype == torch.float32 else lib.pm_chi2_filter_pair
+    check(fn(ptr(a), nM, ptr(b), nF, int(pairing), ptr(out), out.stride(0), ptr(ws), ws.numel(), nat.stream_ptr()))
     return out
 
 

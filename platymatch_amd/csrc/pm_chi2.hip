@@ -476,14 +476,14 @@ __global__ __launch_bounds__(256) void entries_sym_kernel(const double *__restri
 // float32 chains added into a float64 sum per (row, pairing).  NOT the reference's values: every entry is within PM_CHI2_FILTER_DELTA of
 // the exact cost — per term 8 x 2^-24 relative (a, b rounded to float32: 2 each; a + b, a b: 1 each; v_rcp_f32: 2), i.e. <= 2.4e-7 on
 // the sum (<= 0.5); the six fused adds and the final add of a shell's chains 7 x 2^-24 of that shell's sum, <= 2.1e-7 over all shells;
-// doubled by the factor 2: < 1e-6.  It serves as a FILTER only (lsap.FilteredMatrix): it says which entries can matter, their exact
+// doubled by the factor 2: < 1e-6; stored as float32 (pm_chi2_filter4_f32) another 2^-24 of an entry <= 1: PM_CHI2_FILTER_DELTA covers both.  It serves as a FILTER only (lsap.FilteredMatrix): it says which entries can matter, their exact
 // costs come from entries_sym_kernel.  out4 + t * mstride = the matrix of pairing t (both U11/U22-type twins: one matrix).
-#define PM_CHI2_FILTER_DELTA 1e-6
+#define PM_CHI2_FILTER_DELTA 1.1e-6
 typedef float pm_f2 __attribute__((ext_vector_type(2)));
 
-template <int TSEL>      // -1: the four pairings -> out + t * mstride; t: pairing t alone -> out
+template <int TSEL, typename OUT>      // -1: the four pairings -> out + t * mstride; t: pairing t alone -> out.  OUT: float64 or float32 storage
 __global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__restrict__ scA, int nA, const double *__restrict__ scB, int nB,
-                                                                double *__restrict__ out, size_t ld, size_t mstride, int nTi,
+                                                                OUT *__restrict__ out, size_t ld, size_t mstride, int nTi,
                                                                 unsigned int nblocks, const double *__restrict__ sumA,
                                                                 const double *__restrict__ sumB) {
     constexpr int RI = 4, TI = 4 * RI;
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__
             if (gi < nA) {
                 const double half = 0.5 * (sumA[gi] + sumB[gj]);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) out[(size_t)t * mstride + (size_t)gi * ld + gj] = __builtin_fma(-2.0, acc[r][t], half);
+                for (int t = 0; t < NT; ++t) out[(size_t)t * mstride + (size_t)gi * ld + gj] = (OUT)__builtin_fma(-2.0, acc[r][t], half);
             }
         }
     }
@@ -776,7 +776,8 @@ extern "C" size_t pm_chi2_filter_workspace_bytes(int nM, int nF) {
 extern "C" double pm_chi2_filter_delta(void) { return PM_CHI2_FILTER_DELTA; }
 
 namespace pm {
-static int filter_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out, size_t ld, size_t matrix_stride,
+template <typename OUT>
+static int filter_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, OUT *out, size_t ld, size_t matrix_stride,
                          void *ws, size_t ws_bytes, void *stream) {
     if (!sc_m1 || !sc_f1 || !out || nM <= 0 || nF <= 0 || ld < (size_t)nF || (pairing < 0 && matrix_stride < (size_t)nM * ld))
         return PM_ERR_INVALID_ARG;
@@ -791,11 +792,11 @@ static int filter_launch(const double *sc_m1, int nM, const double *sc_f1, int n
     if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
     const unsigned int grid = (unsigned int)nblocks;
     switch (pairing) {
-        case -1: filter4_kernel<-1><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, (int)nTi, grid, sumA, sumB); break;
-        case 0: filter4_kernel<0><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
-        case 1: filter4_kernel<1><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
-        case 2: filter4_kernel<2><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
-        case 3: filter4_kernel<3><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
+        case -1: filter4_kernel<-1, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, (int)nTi, grid, sumA, sumB); break;
+        case 0: filter4_kernel<0, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
+        case 1: filter4_kernel<1, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
+        case 2: filter4_kernel<2, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
+        case 3: filter4_kernel<3, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
         default: return PM_ERR_INVALID_ARG;
     }
     return launch_status();
@@ -805,6 +806,18 @@ static int filter_launch(const double *sc_m1, int nM, const double *sc_f1, int n
 extern "C" int pm_chi2_filter4(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out4, size_t ld, size_t matrix_stride,
                                void *ws, size_t ws_bytes, void *stream) {
     return pm::filter_launch(sc_m1, nM, sc_f1, nF, -1, out4, ld, matrix_stride, ws, ws_bytes, stream);
+}
+
+// the same matrices stored as float32: half the memory and half the traffic of the solver's dense passes (pm_lsap_*_f32)
+extern "C" int pm_chi2_filter4_f32(const double *sc_m1, int nM, const double *sc_f1, int nF, float *out4, size_t ld, size_t matrix_stride,
+                                   void *ws, size_t ws_bytes, void *stream) {
+    return pm::filter_launch(sc_m1, nM, sc_f1, nF, -1, out4, ld, matrix_stride, ws, ws_bytes, stream);
+}
+
+extern "C" int pm_chi2_filter_pair_f32(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, float *out1, size_t ld,
+                                       void *ws, size_t ws_bytes, void *stream) {
+    if (pairing < 0 || pairing > 3) return PM_ERR_INVALID_ARG;
+    return pm::filter_launch(sc_m1, nM, sc_f1, nF, pairing, out1, ld, 0, ws, ws_bytes, stream);
 }
 
 // one pairing's filter matrix alone (a quarter of the launch): for clouds whose four filter matrices do not fit in HBM together

@@ -17,19 +17,20 @@ constexpr int LS_THREADS = 256;
 // one on ties); the 256 thread minima are ranked by (red, col) and the k best written in rank order.  The row's overall
 // minimum is always among them (rank 0); the rest are a cheap, deterministic sample of the row's small entries — pricing
 // repairs whatever the sample missed, so it need not be the exact k smallest.  Slots beyond the row's width get col = -1.
-template <bool HAS_V>
-__global__ __launch_bounds__(LS_THREADS) void row_select_kernel(const double *__restrict__ U, int nc, size_t ld,
+// (T: the matrix's element type — float64, or float32 for the filter matrices of lsap.FilteredMatrix, which only SELECT entries.)
+template <bool HAS_V, typename T = double>
+__global__ __launch_bounds__(LS_THREADS) void row_select_kernel(const T *__restrict__ U, int nc, size_t ld,
                                                                 const double *__restrict__ v, int k, int32_t *__restrict__ out_col,
                                                                 double *__restrict__ out_cost, int32_t *__restrict__ nonfinite) {
     __shared__ double s_red[LS_THREADS];
     __shared__ int s_col[LS_THREADS];
     const int tid = threadIdx.x;
-    const double *row = U + (size_t)blockIdx.x * ld;
+    const T *row = U + (size_t)blockIdx.x * ld;
     double best = INFINITY, best_cost = INFINITY;
     int best_col = 0x7fffffff;
     bool bad = false;
     for (int j = tid; j < nc; j += LS_THREADS) {
-        const double c = row[j];
+        const double c = (double)row[j];
         bad |= !(fabs(c) < INFINITY);                       // NaN or +-inf: the caller takes SciPy's own path for such matrices
         const double red = HAS_V ? c - v[j] : c;
         if (red < best) { best = red; best_cost = c; best_col = j; }
@@ -106,14 +107,15 @@ __global__ __launch_bounds__(LS_THREADS) void bid_kernel(const double *__restric
 // rows streamed in slabs so that the launch has enough workgroups; slab minima combined by a second tiny kernel.
 constexpr int CM_ROWS = 256;          // rows per slab
 
-__global__ __launch_bounds__(LS_THREADS) void col_min_slab_kernel(const double *__restrict__ U, int nr, int nc, size_t ld,
+template <typename T = double>
+__global__ __launch_bounds__(LS_THREADS) void col_min_slab_kernel(const T *__restrict__ U, int nr, int nc, size_t ld,
                                                                   double *__restrict__ slab_min) {
     const int j = blockIdx.x * LS_THREADS + threadIdx.x;
     if (j >= nc) return;
     const int r0 = blockIdx.y * CM_ROWS, r1 = min(nr, r0 + CM_ROWS);
     double best = INFINITY;
     for (int i = r0; i < r1; ++i) {
-        const double c = U[(size_t)i * ld + j];
+        const double c = (double)U[(size_t)i * ld + j];
         best = c < best ? c : best;
     }
     slab_min[(size_t)blockIdx.y * nc + j] = best;
@@ -144,7 +146,8 @@ __global__ __launch_bounds__(LS_THREADS) void col_min_final_kernel(const double 
 // patterns (non-negative doubles order like their bit patterns, so an integer atomic max does it).
 constexpr int CERT_STAGE = 1024;      // tight entries of one row staged in LDS (12 KB)
 
-__global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *__restrict__ U, int nc, size_t ld,
+template <typename T = double>
+__global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const T *__restrict__ U, int nc, size_t ld,
                                                                  const double *__restrict__ u, const double *__restrict__ v,
                                                                  const int32_t *__restrict__ col4row, double delta, double eps,
                                                                  int32_t *__restrict__ summary, unsigned long long *__restrict__ stats,
@@ -159,13 +162,13 @@ __global__ __launch_bounds__(LS_THREADS) void certificate_kernel(const double *_
     if (tid < 2) { s_cnt[tid] = 0; s_max[tid] = 0ull; }
     if (tid == 0) { s_nt = 0; s_base = -1; }
     __syncthreads();
-    const double *row = U + (size_t)i * ld;
+    const T *row = U + (size_t)i * ld;
     const double ui = u[i];
     const int jm = col4row[i];
     int viol = 0, loose = 0;
     double worst = 0.0, slack = 0.0;
     for (int j = tid; j < nc; j += LS_THREADS) {
-        const double red = (row[j] - v[j]) - ui;
+        const double red = ((double)row[j] - v[j]) - ui;
         if (j == jm) {
             if (!(fabs(red) <= delta)) ++loose;
             slack = fmax(slack, fabs(red));                  // fmax drops NaN; `loose` has counted it
@@ -275,7 +278,7 @@ int pm_lsap_col_min(const double *U, int nr, int nc, size_t ld, double *v, void 
     if (!ws || ws_bytes < pm_lsap_col_min_workspace(nr, nc)) return PM_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int slabs = (nr + pm::CM_ROWS - 1) / pm::CM_ROWS, cb = (nc + pm::LS_THREADS - 1) / pm::LS_THREADS;
-    pm::col_min_slab_kernel<<<dim3(cb, slabs), pm::LS_THREADS, 0, s>>>(U, nr, nc, ld, (double *)ws);
+    pm::col_min_slab_kernel<double><<<dim3(cb, slabs), pm::LS_THREADS, 0, s>>>(U, nr, nc, ld, (double *)ws);
     pm::col_min_final_kernel<<<cb, pm::LS_THREADS, 0, s>>>((const double *)ws, slabs, nc, v);
     return pm::launch_status();
 }
@@ -289,8 +292,45 @@ int pm_lsap_certificate(const double *U, int nr, int nc, size_t ld, const double
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(summary4, 0, 4 * sizeof(int32_t), s) != hipSuccess) return pm::launch_status();
     if (hipMemsetAsync(stats2, 0, 2 * sizeof(double), s) != hipSuccess) return pm::launch_status();
-    pm::certificate_kernel<<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, u, v, col4row, delta, eps, summary4, (unsigned long long *)stats2,
-                                                          tight, tight_red, cap, row_slack, row_neg);
+    pm::certificate_kernel<double><<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, u, v, col4row, delta, eps, summary4, (unsigned long long *)stats2,
+                                                                  tight, tight_red, cap, row_slack, row_neg);
+    return pm::launch_status();
+}
+
+// The same three passes over a FLOAT32 matrix (a filter matrix: lsap.FilteredMatrix) — reduced costs are formed in float64 from the
+// converted entry; out_cost receives the converted entries.
+int pm_lsap_row_select_f32(const float *U, int nr, int nc, size_t ld, const double *v, int k, int32_t *out_col, double *out_cost,
+                           int32_t *nonfinite1, void *stream) {
+    if (!U || !out_col || !out_cost || !nonfinite1 || nr <= 0 || nc <= 0 || ld < (size_t)nc || k <= 0 || k > pm::LS_THREADS)
+        return PM_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(nonfinite1, 0, sizeof(int32_t), s) != hipSuccess) return pm::launch_status();
+    if (v) pm::row_select_kernel<true, float><<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, v, k, out_col, out_cost, nonfinite1);
+    else pm::row_select_kernel<false, float><<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, nullptr, k, out_col, out_cost, nonfinite1);
+    return pm::launch_status();
+}
+
+int pm_lsap_col_min_f32(const float *U, int nr, int nc, size_t ld, double *v, void *ws, size_t ws_bytes, void *stream) {
+    if (!U || !v || nr <= 0 || nc <= 0 || ld < (size_t)nc) return PM_ERR_INVALID_ARG;
+    if (!ws || ws_bytes < pm_lsap_col_min_workspace(nr, nc)) return PM_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int slabs = (nr + pm::CM_ROWS - 1) / pm::CM_ROWS, cb = (nc + pm::LS_THREADS - 1) / pm::LS_THREADS;
+    pm::col_min_slab_kernel<float><<<dim3(cb, slabs), pm::LS_THREADS, 0, s>>>(U, nr, nc, ld, (double *)ws);
+    pm::col_min_final_kernel<<<cb, pm::LS_THREADS, 0, s>>>((const double *)ws, slabs, nc, v);
+    return pm::launch_status();
+}
+
+int pm_lsap_certificate_f32(const float *U, int nr, int nc, size_t ld, const double *u, const double *v, const int32_t *col4row,
+                            double delta, double eps, int32_t *summary4, double *stats2, int32_t *tight, double *tight_red, int cap,
+                            double *row_slack, double *row_neg, void *stream) {
+    if (!U || !u || !v || !col4row || !summary4 || !stats2 || !tight || !tight_red || nr <= 0 || nc < nr || ld < (size_t)nc || cap <= 0 ||
+        !(delta >= 0.0) || !(eps >= 0.0))
+        return PM_ERR_INVALID_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(summary4, 0, 4 * sizeof(int32_t), s) != hipSuccess) return pm::launch_status();
+    if (hipMemsetAsync(stats2, 0, 2 * sizeof(double), s) != hipSuccess) return pm::launch_status();
+    pm::certificate_kernel<float><<<nr, pm::LS_THREADS, 0, s>>>(U, nc, ld, u, v, col4row, delta, eps, summary4, (unsigned long long *)stats2,
+                                                                 tight, tight_red, cap, row_slack, row_neg);
     return pm::launch_status();
 }
 

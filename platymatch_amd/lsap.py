@@ -159,6 +159,8 @@ class DeviceMatrix:
         self.U = U
         self.shape = tuple(U.shape)
         self.ld = U.stride(0) if U.shape[0] > 1 else U.shape[1]      # a one-row tensor's row stride is arbitrary
+        # a float32 matrix (a filter matrix, FilteredMatrix below) goes through the float32 forms of the three streaming passes
+        self.f32 = str(U.dtype) == "torch.float32"
 
     def row_select_t(self, v, k):
         """pm_lsap_row_select with everything left on the device -> (cols [nr, k] int32, costs [nr, k] float64, nonfinite flag [1]
@@ -172,8 +174,9 @@ class DeviceMatrix:
         v_dev = None if v is None else nat.to_dev(v, dev=U.device)
         if v_dev is not None and v_dev.numel() != nc:
             raise ValueError("v must hold one dual per column")
-        nat.check(nat.load().pm_lsap_row_select(nat.ptr(U), nr, nc, self.ld, nat.ptr(v_dev), k, nat.ptr(cols), nat.ptr(costs),
-                                                nat.ptr(flag), nat.stream_ptr(U)))
+        lib = nat.load()
+        nat.check((lib.pm_lsap_row_select_f32 if self.f32 else lib.pm_lsap_row_select)(nat.ptr(U), nr, nc, self.ld, nat.ptr(v_dev), k, nat.ptr(cols),
+                                                                                       nat.ptr(costs), nat.ptr(flag), nat.stream_ptr(U)))
         return cols, costs, flag
 
     def row_select(self, v, k):
@@ -225,7 +228,8 @@ class DeviceMatrix:
         lib = nat.load()
         ws = nat.workspace(lib.pm_lsap_col_min_workspace(nr, nc), U.device)
         v = torch.empty(nc, dtype=torch.float64, device=U.device)
-        nat.check(lib.pm_lsap_col_min(nat.ptr(U), nr, nc, self.ld, nat.ptr(v), nat.ptr(ws), ws.numel(), nat.stream_ptr(U)))
+        nat.check((lib.pm_lsap_col_min_f32 if self.f32 else lib.pm_lsap_col_min)(nat.ptr(U), nr, nc, self.ld, nat.ptr(v), nat.ptr(ws), ws.numel(),
+                                                                                 nat.stream_ptr(U)))
         return v.cpu().numpy()
 
     def certificate(self, u, v, col4row, delta, eps, cap):
@@ -248,9 +252,10 @@ class DeviceMatrix:
         tight = torch.empty((cap, 2), dtype=torch.int32, device=U.device)
         red = torch.empty(cap, dtype=torch.float64, device=U.device)
         rows = torch.empty((2, nr), dtype=torch.float64, device=U.device)
-        nat.check(nat.load().pm_lsap_certificate(nat.ptr(U), nr, nc, self.ld, nat.ptr(u_d), nat.ptr(v_d), nat.ptr(c_d), float(delta),
-                                                 float(eps), nat.ptr(summary), nat.ptr(stats), nat.ptr(tight), nat.ptr(red), cap,
-                                                 nat.ptr(rows[0]), nat.ptr(rows[1]), nat.stream_ptr(U)))
+        lib = nat.load()
+        nat.check((lib.pm_lsap_certificate_f32 if self.f32 else lib.pm_lsap_certificate)(
+            nat.ptr(U), nr, nc, self.ld, nat.ptr(u_d), nat.ptr(v_d), nat.ptr(c_d), float(delta), float(eps), nat.ptr(summary), nat.ptr(stats),
+            nat.ptr(tight), nat.ptr(red), cap, nat.ptr(rows[0]), nat.ptr(rows[1]), nat.stream_ptr(U)))
         viol, n_tight, loose, _ = summary.cpu().tolist()
         rows_h = rows.cpu().numpy()
         bound = float(rows_h[0].sum() + rows_h[1].sum())         # what the observed imperfections can cost any alternative, in total
@@ -744,7 +749,7 @@ def _native_options(min_eps=0.0):
 
 def _native_ok(M):
     """The native driver takes a DeviceMatrix with this module's stock flow (no row-reduction warm start, <= 64 candidates per row)."""
-    return (NATIVE_DRIVER and isinstance(M, DeviceMatrix) and ROW_REDUCTION_ROUNDS == 0 and CORE_EDGES_PER_ROW <= 64
+    return (NATIVE_DRIVER and isinstance(M, DeviceMatrix) and not M.f32 and ROW_REDUCTION_ROUNDS == 0 and CORE_EDGES_PER_ROW <= 64
             and PRICE_EDGES_PER_ROW <= 64)
 
 
@@ -1123,9 +1128,10 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
 
 
 def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pair, info=None, allow_host=True, accept_near_ties=False,
-                        build=None, shape=None, device=None, in_flight=4):
-    """The widget's eight assignments from FOUR approximate matrices F4 [4, N, M] (pm_chi2_filter4: matrix t within cost_delta of
-    hypothesis PAIRINGS[t][0]'s exact matrix and of its twin's), none of the exact matrices built: per pairing (four host threads)
+                        build=None, shape=None, device=None, in_flight=4, storage=None):
+    """The widget's eight assignments from FOUR approximate matrices F4 (pm_chi2_filter4, float64 or float32 storage: matrix t within
+    cost_delta of hypothesis PAIRINGS[t][0]'s exact matrix and of its twin's; for shape = (N, M) with N > M the matrices hold the
+    TRANSPOSED problem, [4, M, N] — built with the descriptors' roles swapped, see below), none of the exact matrices built: per pairing (four host threads)
     the sparse-core solve runs on a FilteredMatrix — the approximate matrix selects entries, every cost comes from
     exact_entries(t)(rows, cols) -> (hypothesis's exact values, twin's) [exact_entries_t: the same with GPU tensors] — and the
     result is certified against both exact matrices on their listed entries (certify_listed).  A pairing that cannot be certified
@@ -1134,10 +1140,13 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
     STREAMED form (F4 = None; clouds whose four filter matrices do not fit in HBM together): build(t, out) -> the filter matrix of
     pairing t, written into the buffer `out`, with the SHORT side as its rows ([N, M] if N <= M, else [M, N]: pm_chi2_filter_pair with the roles swapped — the
     terms are symmetric in their two descriptors and each pairing's bin map is an involution, so that IS the transposed filter
-    to within cost_delta), made on the pairing's own stream when its turn comes; at most in_flight pairings are resident."""
+    to within cost_delta), made on the pairing's own stream when its turn comes; at most in_flight pairings are resident, in
+    buffers of dtype `storage` (default float64) allocated once."""
     torch = nat.torch_mod()
     if F4 is not None:
-        n, m = F4.shape[1], F4.shape[2]
+        n, m = shape if shape is not None else (F4.shape[1], F4.shape[2])
+        if tuple(F4.shape[1:]) != (min(n, m), max(n, m)):
+            raise ValueError("F4 must hold the filter matrices with the short side as rows: [4, %d, %d]" % (min(n, m), max(n, m)))
         device = F4.device
         in_flight = 4
     else:
@@ -1160,7 +1169,7 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
                     fetch, fetch_t = (lambda rows, cols: f0(cols, rows)), (lambda rows, cols: f0_t(cols, rows))
                 slot = None
                 if F4 is not None:
-                    W = DeviceMatrix(F4[t] if n <= m else transposed(F4[t]))
+                    W = DeviceMatrix(F4[t])
                 else:
                     slot = pool.get()                           # one of the in_flight buffers, allocated once (22 ms per GB on this pool)
                     W = DeviceMatrix(build(t, slot))
@@ -1206,7 +1215,7 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
         pool = queue.Queue()
         with torch.cuda.device(device):
             for _ in range(workers):
-                pool.put(torch.empty((min(n, m), max(n, m)), dtype=torch.float64, device=device))
+                pool.put(torch.empty((min(n, m), max(n, m)), dtype=storage or torch.float64, device=device))
     torch.cuda.current_stream(device).synchronize()       # the descriptors / F4 were produced on the caller's stream
     with ThreadPoolExecutor(max_workers=workers) as ex:
         list(ex.map(pair, range(4)))

@@ -353,6 +353,7 @@ def gather_fixed_descriptors(be, sc_m_loc, sc_f_loc, bounds, group=None):
 
 STATS_ON_TWO_STREAMS = True
 RELAXED_CERTIFY_ON_EXACT_ENTRIES = True     # cost_mode='relaxed': certify on the exact matrix's listed entries (lsap.certify_listed); False: a 2 N delta margin on the relaxed one
+FILTER_STORAGE_F32 = True      # the filter matrices as float32 (half the memory and dense-pass traffic; same bound); False: float64
 FILTER_MIN_POINTS = 8192       # cost_mode='filter' below this: the relaxed mode (the filter's extra round trips cost more than its build saves: measured 36 / 30 ms at 5k, 72 / 78 at 10k, 178 / 212 at 20k, 0.99 / 1.24 s at 50k)
 RELAXED_MIN_POINTS = 1024      # cost_mode='relaxed' below this: exact (the dense host solver takes such matrices, no certificate to lean on)
 
@@ -891,8 +892,8 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
             need = cost_bytes(sc_m.shape[1], mov.shape[1], sc_f.shape[1], world)
             use_filter = (cost_mode == 'filter' and min(mov.shape[1], fix.shape[1]) >= FILTER_MIN_POINTS and world == 1 and mov.is_cuda
                           and getattr(be, "device_sampler", False) and (sc_f.shape[0] == 1 or be.K.chi2_symmetric(sc_m, sc_f)))
-            if use_filter:
-                need = need * 3 // 4          # four filter matrices + one pairing's two exact ones at the worst
+            if use_filter:                    # four filter matrices + one pairing's two exact ones at the worst
+                need = need // 2 if FILTER_STORAGE_F32 else need * 3 // 4
             if stream_hypotheses is not None:
                 streamed = bool(stream_hypotheses)
             else:
@@ -909,8 +910,18 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                         and min(mov.shape[1], fix.shape[1]) >= RELAXED_MIN_POINTS):
                     relaxed = be.chi2_cost8_relaxed(sc_m, sc_f, out=None if lease is None else lease.view)
                 if use_filter:
+                    # the filter matrices with the SHORT side as rows (N > M: the descriptors' roles swapped — the terms are symmetric
+                    # and every pairing's bin map is an involution, so that is the transposed filter to within its bound), carved
+                    # out of the kept buffer when there is one
                     filtered = True
-                    U = be.K.chi2_filter4(sc_m[0], sc_f[0], out=None if lease is None else lease.view[:4])
+                    n_, m_ = mov.shape[1], fix.shape[1]
+                    fshape = (4, min(n_, m_), max(n_, m_))
+                    fdtype = torch.float32 if FILTER_STORAGE_F32 else torch.float64
+                    fout = None
+                    if lease is not None:
+                        fout = lease.view.view(fdtype).reshape(-1)[:4 * n_ * m_].view(fshape)
+                    a_, b_ = (sc_m[0], sc_f[0]) if n_ <= m_ else (sc_f[0], sc_m[0])
+                    U = be.K.chi2_filter4(a_, b_, out=fout, dtype=fdtype)
                 elif relaxed is not None:
                     U, relaxed_delta = relaxed
                 else:
@@ -936,11 +947,12 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                 def build_pairing(t, out):     # streamed: one pairing's filter matrix, the short side as its rows
                     return be.K.chi2_filter_pair(sc_m1, sc_f1, t, out=out) if n_ <= m_ else be.K.chi2_filter_pair(sc_f1, sc_m1, t, out=out)
                 in_flight = 4
+                fdtype = torch.float32 if FILTER_STORAGE_F32 else torch.float64
                 if not filtered:
-                    in_flight = max(1, min(4, int(0.85 * be.free_bytes() // (8 * n_ * m_))))
+                    in_flight = max(1, min(4, int(0.85 * be.free_bytes() // ((4 if FILTER_STORAGE_F32 else 8) * n_ * m_))))
                 lsa = solve_four_filtered(U if filtered else None, entries_np, entries_t, be.K.chi2_filter_delta() + 1e-13,
                                           lambda t: be.K.chi2_cost_pair(sc_m, sc_f, t, True), info=a_info, accept_near_ties=accept_near_ties,
-                                          build=build_pairing, shape=(n_, m_), device=mov.device, in_flight=in_flight)
+                                          build=build_pairing, shape=(n_, m_), device=mov.device, in_flight=in_flight, storage=fdtype)
                 if a_info is not None and not filtered:
                     a_info["mode"] = "streamed: %d filter matri%s resident at a time" % (in_flight, "x" if in_flight == 1 else "ces")
                 if any(a is None for a in lsa):

@@ -256,3 +256,32 @@ def test_streamed_filter_mode_builds_one_pairing_at_a_time_and_returns_the_exact
     modes = [d.get("cost_mode", "") for d in dr["assignment"]["details"]]
     assert "streamed" in dr["assignment"]["mode"] and "filter" in dr["assignment"]["mode"], dr["assignment"]["mode"]
     assert all(x.startswith("exact (built") if tied else x.startswith("filter") for x in modes), modes
+
+
+def test_float32_storage_of_the_filter_and_the_float32_passes_agree_with_the_float64_ones(g):
+    """pm_chi2_filter4_f32 == float32(pm_chi2_filter4) entry by entry, and the float32 forms of the solver's three streaming passes
+    (row_select, col_min, certificate) answer a float32 matrix as the float64 forms answer the same values converted."""
+    n, m = 1500, 2100
+    mv, fx, _ = synth_pair(max(n, m), 71)
+    be = g.P.GpuBackend()
+    sc_m, sc_f, _ = g.P.build_descriptors(be, be.cloud(np.ascontiguousarray(mv[:, :n])), be.cloud(np.ascontiguousarray(fx[:, :m])))
+    F64 = g.K.chi2_filter4(sc_m[0], sc_f[0])
+    F32 = g.K.chi2_filter4(sc_m[0], sc_f[0], dtype=g.t.float32)
+    assert F32.dtype == g.t.float32 and g.t.equal(F32, F64.to(g.t.float32))
+    for t in range(4):
+        assert g.t.equal(g.K.chi2_filter_pair(sc_m[0], sc_f[0], t, dtype=g.t.float32), F32[t])
+        assert g.t.equal(g.K.chi2_filter_pair(sc_m[0], sc_f[0], t), F64[t])
+    A, B = g.L.DeviceMatrix(F32[1]), g.L.DeviceMatrix(F32[1].to(g.t.float64))
+    assert A.f32 and not B.f32
+    v = B.col_min()
+    assert np.array_equal(A.col_min(), v)
+    ca, xa, fa = A.row_select(v, 16)
+    cb, xb, fb = B.row_select(v, 16)
+    assert np.array_equal(ca, cb) and np.array_equal(xa, xb) and fa == fb == 0
+    u = xb[:, 0] - v[cb[:, 0]]
+    c4r = np.arange(n, dtype=np.int32)
+    ra, rb = A.certificate(u, v, c4r, 1.0, 1e-3, 64 * m), B.certificate(u, v, c4r, 1.0, 1e-3, 64 * m)
+    assert ra[0] == rb[0] and ra[1] == rb[1]
+    ka = np.lexsort((ra[2][:, 1], ra[2][:, 0]))
+    kb = np.lexsort((rb[2][:, 1], rb[2][:, 0]))
+    assert np.array_equal(ra[2][ka], rb[2][kb]) and np.array_equal(ra[3][ka], rb[3][kb])
