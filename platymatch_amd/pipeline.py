@@ -16,6 +16,7 @@ Cloud statistics (centroid, mean distance, PCA axis) are O(N)…O(N^2) on 24·N 
 redundantly by every rank: identical inputs and a fixed reduction order give identical values
 without a collective.
 """
+import os
 import threading
 
 import numpy as np
@@ -353,7 +354,7 @@ def gather_fixed_descriptors(be, sc_m_loc, sc_f_loc, bounds, group=None):
 
 STATS_ON_TWO_STREAMS = True
 RELAXED_CERTIFY_ON_EXACT_ENTRIES = True     # cost_mode='relaxed': certify on the exact matrix's listed entries (lsap.certify_listed); False: a 2 N delta margin on the relaxed one
-FILTER_STORAGE_F32 = True      # the filter matrices as float32 (half the memory and dense-pass traffic; same bound); False: float64
+FILTER_STORAGE_F32 = os.environ.get("PM_FILTER_F64") != "1"      # the filter matrices as float32 (half the memory and dense-pass traffic; same bound); PM_FILTER_F64=1: float64
 FILTER_MIN_POINTS = 8192       # cost_mode='filter' below this: the relaxed mode (the filter's extra round trips cost more than its build saves: measured 36 / 30 ms at 5k, 72 / 78 at 10k, 178 / 212 at 20k, 0.99 / 1.24 s at 50k)
 RELAXED_MIN_POINTS = 1024      # cost_mode='relaxed' below this: exact (the dense host solver takes such matrices, no certificate to lean on)
 
