@@ -34,6 +34,9 @@ def heartbeat():
 
 
 threading.Thread(target=heartbeat, daemon=True).start()
+if os.environ.get("PM_BIG_STACKS"):              # diagnosis: every thread's Python stack every PM_BIG_STACKS seconds
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ["PM_BIG_STACKS"]), repeat=True)
 mv, fx, A_gt = synth_pair(n, 42)
 P.estimate_transform(mv[:, :400], fx[:, :400], ransac_trials=50, icp_iterations=2)          # warm-up
 det = {"timing": True}
