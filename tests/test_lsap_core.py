@@ -491,3 +491,53 @@ def test_filter_settles_what_lies_below_its_own_accuracy_and_refuses_exact_ties(
             assert ok and np.array_equal(sol[2], scipy_lsa(C)[1]), (gap, info, ci)
         else:
             assert not ok and ci.get("unique") is False, (gap, ci)
+
+
+def test_fuzz_a_certified_answer_of_the_listed_certificate_is_the_exact_matrices_unique_optimum():
+    """Soundness of what cost_mode='relaxed' / 'filter' rest on, by brute force on small problems: whenever certify_listed says yes
+    — after a plain solve on the approximate matrix (the relaxed flow) or after the FilteredMatrix flow — the assignment is
+    SciPy's on the EXACT matrix and no other assignment comes within 1e-12 of its cost (checked by forbidding each matched entry
+    in turn).  Generic, rectangular, duplicated-row (tied) and engineered near-tie matrices; perturbations from 1e-12 to 1e-4."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(2024)
+    said_yes = {"relaxed": 0, "filter": 0}
+    generic = {"relaxed": [0, 0], "filter": [0, 0]}
+    for case in range(140):
+        n = int(rng.integers(8, 48))
+        m = n if case % 3 else n + int(rng.integers(1, 9))
+        C = rng.random((n, m)) * rng.random((1, m)) + 0.2 * rng.random((n, 1)) + 0.05 * rng.random((n, m))
+        kind = case % 5
+        if kind == 3:                                            # tied: a duplicated row
+            C[int(rng.integers(0, n))] = C[int(rng.integers(0, n))]
+        elif kind == 4:                                          # an alternative `gap` above the optimum
+            r, c = scipy_lsa(C)
+            i1, i2 = rng.choice(n, size=2, replace=False)
+            gap = 10.0 ** rng.uniform(-14, -6)
+            C[i1, c[i2]] += (C[i1, c[i1]] + C[i2, c[i2]] + gap) - (C[i1, c[i2]] + C[i2, c[i1]])
+        cost_delta = 10.0 ** rng.uniform(-12, -4)
+        A = C + rng.uniform(-cost_delta, cost_delta, size=C.shape)
+
+        def entries(rows, cols):
+            return (C[rows, cols],)
+        for flow in ("relaxed", "filter"):
+            M = HostMatrix(A) if flow == "relaxed" else L.FilteredMatrix(HostMatrix(A), entries, cost_delta)
+            sol = L.solve_core(M)
+            if sol is None:
+                continue
+            ok = L.certify_listed(M, *sol, exact_entries=entries, cost_delta=cost_delta, infos=[{}])[0]
+            if kind < 3:
+                generic[flow][0] += 1
+                generic[flow][1] += bool(ok)
+            if not ok:
+                continue
+            said_yes[flow] += 1
+            r, c = scipy_lsa(C)
+            assert np.array_equal(sol[2], c), (case, flow, kind, cost_delta)
+            best = C[r, c].sum()
+            for i in range(n):                                   # uniqueness by brute force
+                D = C.copy()
+                D[i, c[i]] = 1e6
+                r2, c2 = scipy_lsa(D)
+                assert D[r2, c2].sum() > best + 1e-12, (case, flow, kind, i, D[r2, c2].sum() - best)
+    assert said_yes["relaxed"] > 20 and said_yes["filter"] > 60, said_yes
+    assert generic["filter"][1] >= 0.9 * generic["filter"][0], generic        # the filter flow settles generic matrices whatever its accuracy
