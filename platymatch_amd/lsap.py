@@ -309,7 +309,7 @@ class FilteredMatrix:
     def _row_select_t(self, v, k):
         """row_select with selection, exact evaluation and re-sorting on the device: one read-back."""
         torch = nat.torch_mod()
-        cols, costs_a, flag = self.A.row_select_t(v, k)
+        cols, _, flag = self.A.row_select_t(v, k)
         valid = cols >= 0
         rows = torch.arange(cols.shape[0], dtype=torch.int32, device=cols.device)[:, None].expand_as(cols)
         exact = self.exact_entries_t(rows[valid].contiguous(), cols[valid].contiguous())[0]
@@ -388,7 +388,7 @@ class FilteredMatrix:
         cost can be below REL_EPS_COLLECT x scale, or None if the list overflowed."""
         if self.exact_entries_t is not None and hasattr(self.A, "certificate_t"):
             return self._threshold_select_t(u, v, col4row)
-        nr, nc = self.shape
+        nr = self.shape[0]
         tau = self._tau(u, v)
         _, _, tight, _, _ = self.certificate(u, v, col4row, 1.0, tau, 0)
         if tight is None:
