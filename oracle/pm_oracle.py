@@ -245,15 +245,38 @@ def get_bin_index_direct(neighbors, mean_dist):
 
 
 def get_shape_context(neighbors, mean_dist, r_inner=1 / 8, r_outer=2, n_rbins=5, n_thetabins=6, n_phibins=12):
-    """shape_context.py:10-42.  Only the default binning exists anywhere in the reference."""
-    assert (r_inner, r_outer, n_rbins, n_thetabins, n_phibins) == (1 / 8, 2, 5, 6, 12)
-    idx = get_bin_index_direct(neighbors, mean_dist)
-    sc = np.zeros(360)
-    for v in idx:
-        if v >= 0 and v < 360 and v == np.floor(v):
-            sc[int(v)] += 1
-    with np.errstate(invalid="ignore", divide="ignore"):
-        return sc / sc.sum()
+    """shape_context.py:10-42.  The default binning (the only one get_unary ever uses, SURVEY.md §5) goes through the C port;
+    any other parameter set is the reference's own sequence of NumPy calls, neighbour by neighbour (a Python loop: small
+    cases only) — np.linalg.norm, np.arccos, np.arctan2 and the float floor divisions of get_bin_index (:46-58)."""
+    if (r_inner, r_outer, n_rbins, n_thetabins, n_phibins) == (1 / 8, 2, 5, 6, 12):
+        idx = get_bin_index_direct(neighbors, mean_dist)
+        sc = np.zeros(360)
+        for v in idx:
+            if v >= 0 and v < 360 and v == np.floor(v):
+                sc[int(v)] += 1
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return sc / sc.sum()
+    nb = _f64(neighbors)
+    n_bins = n_rbins * n_thetabins * n_phibins
+    with np.errstate(all="ignore"):
+        r_edges = np.logspace(np.log10(r_inner), np.log10(r_outer), n_rbins)            # :24
+        sc = np.zeros(n_bins)
+        for x_, y_, z_ in nb:
+            r_ = np.linalg.norm(np.array([x_, y_, z_]))                                  # :29
+            r = r_ / mean_dist                                                           # :30
+            theta = np.arccos(z_ / r_)                                                   # :31
+            phi = np.arctan2(y_, x_)                                                     # :32-35
+            if phi < 0:
+                phi = 2 * np.pi + phi
+            r_index = n_rbins - 1                                                        # :49
+            for ind, edge in enumerate(r_edges):                                         # :53-56
+                if r < edge:
+                    r_index = ind
+                    break
+            index = r_index * n_thetabins * n_phibins + theta // (np.pi / n_thetabins) * n_phibins + phi // (2 * np.pi / n_phibins)
+            if index == index and 0 <= index < n_bins and index == np.floor(index):       # :38-40: index.count(i), i = 0..n_bins-1
+                sc[int(index)] += 1
+        return sc / sc.sum()                                                             # :41
 
 
 def unary_distance_matrix(scA, scB):

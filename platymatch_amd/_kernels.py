@@ -234,6 +234,30 @@ def shape_context_neighbors(nb, mean_dist):
     return hist, counts, total
 
 
+def shape_context_neighbors_binned(nb, mean_dist, r_edges, cos_steps, phi_steps, n_thetabins, n_phibins):
+    """get_shape_context with the caller's binning (pm_shape_context_neighbors_binned): nb [n, 3] float64 GPU; r_edges, cos_steps,
+    phi_steps: float64 host arrays (estimate_transform/binning.py) -> (counts int64 host [n_bins], rows int64 host: the neighbours
+    the kernel left to the host — within 2^-46 of a phi step)."""
+    torch = _t()
+    if not (nat.is_torch(nb) and nb.is_cuda and nb.dtype == torch.float64 and nb.dim() == 2 and nb.shape[1] == 3
+            and nb.is_contiguous() and nb.shape[0] >= 1):
+        raise ValueError("neighbors must be a contiguous float64 GPU tensor [n, 3]")
+    r_edges, cos_steps, phi_steps = (np.ascontiguousarray(a, dtype=np.float64) for a in (r_edges, cos_steps, phi_steps))
+    n_bins = int(r_edges.size) * int(n_thetabins) * int(n_phibins)
+    tab = nat.to_dev(np.concatenate([r_edges, cos_steps, phi_steps, np.zeros(1)]), dev=nb.device)
+    n = nb.shape[0]
+    ints = torch.empty(n_bins + 2 + n, dtype=torch.int32, device=nb.device)     # counts | total | n_unsure | unsure rows
+    base = tab.data_ptr()
+    check(nat.load().pm_shape_context_neighbors_binned(
+        ptr(nb), n, float(mean_dist), base, int(r_edges.size), base + 8 * r_edges.size, int(cos_steps.size),
+        base + 8 * (r_edges.size + cos_steps.size), int(phi_steps.size), int(n_thetabins), int(n_phibins),
+        ints.data_ptr(), ints.data_ptr() + 4 * n_bins, ints.data_ptr() + 4 * (n_bins + 2), ints.data_ptr() + 4 * (n_bins + 1),
+        nat.stream_ptr()))
+    host = ints.cpu().numpy()
+    counts, n_unsure = host[:n_bins].astype(np.int64), int(host[n_bins + 1])
+    return counts, np.sort(host[n_bins + 2:n_bins + 2 + n_unsure].astype(np.int64))
+
+
 def _desc(x, name):
     torch = _t()
     if not (nat.is_torch(x) and x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.shape[1] == NBINS

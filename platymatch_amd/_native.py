@@ -77,6 +77,8 @@ SIGNATURES = {
     "pm_shape_context_tiled": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int,
                                         _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_shape_context_neighbors": (_c_int, [_c_void_p, _c_int, _c_double, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_shape_context_neighbors_binned": (_c_int, [_c_void_p, _c_int, _c_double, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int,
+                                                   _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "pm_chi2_cost": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "pm_chi2_cost8": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int,
                                _c_void_p, _c_size_t, _c_size_t, _c_void_p]),

@@ -362,7 +362,83 @@ __global__ __launch_bounds__(SC_THREADS) void neighbors_kernel(const double *__r
     if (total && threadIdx.x == 0) total[0] = (int32_t)tot;
 }
 
+// get_shape_context with the CALLER's binning (shape_context.py:10-42 called with explicit r_inner, r_outer, n_rbins,
+// n_thetabins, n_phibins — get_unary never does, the stand-alone function's signature allows it).  The reference evaluates
+// arccos / arctan2 and two float floor divisions per neighbour (:31-35, :51-52).  Here, per neighbour:
+//   ring   the reference's own loop: first edge of np.logspace(...) with r_/mean_dist < edge, else n_rbins - 1 (IEEE division and
+//          comparisons: the same bits on any machine);
+//   theta  theta_index = #{k : c <= cos_steps[k]}, c = z_/r_ — cos_steps[k] is the largest float64 c whose
+//          np.arccos(c) // (pi/n_thetabins) reaches k + 1, found on the HOST with NumPy's own functions (estimate_transform/binning.py):
+//          exact for every c, no arccos here;
+//   phi    atan2 of the device library, wrapped as the reference does (:32-35), compared with phi_steps[m] (the smallest float64
+//          phi whose phi // (2 pi/n_phibins) reaches m + 1, again from NumPy).  The device's atan2 may differ from the host
+//          libm's in the last bits, so a neighbour within 2^-46 (16 ulps of 2 pi) of a step is NOT counted here: its index goes
+//          to `unsure` and the host decides it with the reference's own NumPy calls (lattice data: neighbours exactly on a
+//          sector plane; generic data: none).
+// Bin = ring * n_thetabins * n_phibins + theta_index * n_phibins + phi_index, counted if < n_bins (theta = pi and phi = 2 pi spill into
+// the next shell or ring exactly as the reference's float index does); NaN coordinates, r_ = 0, |c| > 1 are not counted.
+#define PM_TWO_PI 0x1.921fb54442d18p+2          // 2 * np.pi
+#define PM_PHI_UNSURE 0x1p-46
+__global__ __launch_bounds__(256) void neighbors_binned_kernel(const double *__restrict__ nb, int n, double md,
+                                                               const double *__restrict__ r_edges, int n_r,
+                                                               const double *__restrict__ cos_steps, int k_t,
+                                                               const double *__restrict__ phi_steps, int k_p, int n_t, int n_p,
+                                                               long n_bins, int32_t *__restrict__ counts, int32_t *__restrict__ total,
+                                                               int32_t *__restrict__ unsure, int32_t *__restrict__ n_unsure) {
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) {
+        const double vx = nb[3 * j], vy = nb[3 * j + 1], vz = nb[3 * j + 2];
+        const double r_ = __builtin_sqrt((vx * vx + vy * vy) + vz * vz);      // :29 (np.linalg.norm of three numbers)
+        const double r = r_ / md;                                              // :30
+        const double c = vz / r_;                                              // :31 argument of arccos
+        if (!(__builtin_fabs(c) <= 1.0) || vx != vx || vy != vy) continue;     // arccos / arctan2 -> NaN: never counted
+        int ring = n_r - 1;                                                    // :49
+        for (int k = 0; k < n_r; ++k)
+            if (r < r_edges[k]) { ring = k; break; }                           // :53-56
+        int th = 0;
+        for (int k = 0; k < k_t; ++k) th += (c <= cos_steps[k]);
+        double phi = atan2(vy, vx);                                            // :32
+        if (phi < 0.0) phi = PM_TWO_PI + phi;                                  // :33
+        int ph = 0;
+        bool sure = true;
+        for (int m = 0; m < k_p; ++m) {
+            const double d = phi - phi_steps[m];
+            ph += (d >= 0.0);
+            sure = sure && (__builtin_fabs(d) > PM_PHI_UNSURE);
+        }
+        if (!sure) {
+            unsure[atomicAdd(n_unsure, 1)] = (int32_t)j;
+            continue;
+        }
+        const long idx = ((long)ring * n_t + th) * n_p + ph;
+        if (idx < n_bins) {
+            atomicAdd(&counts[idx], 1);
+            atomicAdd(total, 1);
+        }
+    }
+}
+
 }  // namespace pm
+
+extern "C" int pm_shape_context_neighbors_binned(const double *nb, int n, double mean_dist, const double *r_edges, int n_rbins,
+                                                 const double *cos_steps, int n_cos_steps, const double *phi_steps, int n_phi_steps,
+                                                 int n_thetabins, int n_phibins, int32_t *counts, int32_t *total, int32_t *unsure,
+                                                 int32_t *n_unsure, void *stream) {
+    if (!nb || n <= 0 || !r_edges || n_rbins < 1 || n_thetabins < 1 || n_phibins < 1 || n_cos_steps < 0 || n_phi_steps < 0 ||
+        (n_cos_steps > 0 && !cos_steps) || (n_phi_steps > 0 && !phi_steps) || !counts || !total || !unsure || !n_unsure)
+        return PM_ERR_INVALID_ARG;
+    const long n_bins = (long)n_rbins * n_thetabins * n_phibins;
+    if (n_bins > (1L << 24) || n_cos_steps > 4096 || n_phi_steps > 4096 || n_rbins > 4096) return PM_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)n_bins, st) != hipSuccess || hipMemsetAsync(total, 0, sizeof(int32_t), st) != hipSuccess ||
+        hipMemsetAsync(n_unsure, 0, sizeof(int32_t), st) != hipSuccess) {
+        pm::launch_status();                  // records the HIP error for pm_last_hip_error
+        return PM_ERR_LAUNCH;
+    }
+    const int blocks = (int)std::min<long>(((long)n + 255) / 256, 2048);
+    pm::neighbors_binned_kernel<<<blocks, 256, 0, st>>>(nb, n, mean_dist, r_edges, n_rbins, cos_steps, n_cos_steps, phi_steps, n_phi_steps,
+                                                        n_thetabins, n_phibins, n_bins, counts, total, unsure, n_unsure);
+    return pm::launch_status();
+}
 
 extern "C" int pm_shape_context_neighbors(const double *nb, int n, double mean_dist, int32_t *counts, int32_t *total,
                                           double *hist, void *stream) {

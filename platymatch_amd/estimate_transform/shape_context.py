@@ -114,14 +114,29 @@ def get_Y(z, x):
 def get_shape_context(neighbors, mean_dist, r_inner=1 / 8, r_outer=2, n_rbins=5, n_thetabins=6, n_phibins=12):
     """shape_context.py:10-42: histogram of neighbours already expressed in the local frame
     ((N-1) x 3 rows of x_, y_, z_), normalised by the number counted."""
-    if (r_inner, r_outer, n_rbins, n_thetabins, n_phibins) != (1 / 8, 2, 5, 6, 12):
-        raise ValueError("only the reference's default binning (r 1/8..2, 5 x 6 x 12) is implemented: "
-                         "the reference never passes anything else (SURVEY.md §5)")
     nb = nat.to_dev(neighbors)
     if nb.dim() != 2 or nb.shape[1] != 3:
         raise ValueError("neighbors must be (N-1) x 3")
-    hist, _, _ = K.shape_context_neighbors(nb.contiguous(), float(mean_dist))
-    return nat.like_input(hist, neighbors)
+    if (r_inner, r_outer, n_rbins, n_thetabins, n_phibins) == (1 / 8, 2, 5, 6, 12):
+        hist, _, _ = K.shape_context_neighbors(nb.contiguous(), float(mean_dist))
+        return nat.like_input(hist, neighbors)
+    # Any other binning (get_unary never asks for one; this function's signature allows it): the ring edges, the arccos steps and
+    # the floor-division steps of the azimuth are tabulated on the host with the reference's own NumPy calls (binning.py), the
+    # neighbours are binned on the device against those tables, and the few whose device atan2 lies within 2^-46 of an azimuth
+    # step (neighbours exactly on a sector plane) are binned by the reference's expressions themselves.
+    from . import binning as B
+    B.check_arguments(n_rbins, n_thetabins, n_phibins)
+    n_rbins, n_thetabins, n_phibins = int(n_rbins), int(n_thetabins), int(n_phibins)
+    edges = B.r_edges(r_inner, r_outer, n_rbins)
+    counts, rows = K.shape_context_neighbors_binned(nb.contiguous(), float(mean_dist), edges, B.cos_steps(n_thetabins),
+                                                    B.phi_steps(n_phibins), n_thetabins, n_phibins)
+    if rows.size:
+        idx = B.bin_rows(nb[nat.torch_mod().as_tensor(rows, device=nb.device)].cpu().numpy(), float(mean_dist), edges, n_thetabins, n_phibins)
+        np.add.at(counts, idx[idx >= 0], 1)
+    sc = counts.astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sc = sc / sc.sum()                                                       # :41 (0 / 0 = NaN as in the reference)
+    return nat.to_dev(sc, dev=nb.device) if nat.is_torch(neighbors) else sc
 
 
 def get_bin_index(r, theta, phi, r_edges, n_rbins, n_thetabins, n_phibins):
