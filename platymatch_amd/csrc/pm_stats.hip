@@ -112,11 +112,63 @@ __device__ __forceinline__ void md_advance(int &i, int &j, int by, int n) {
     while (j >= n && i < n - 2) { const int over = j - n; ++i; j = i + 1 + over; }
 }
 
+// a block that crosses rows of the pair list: every lane follows its own pair
+__device__ __forceinline__ void md_block_across_rows(const double *__restrict__ P0, const double *__restrict__ P1,
+                                                               const double *__restrict__ P2, int n, long long eb, int lane, double *blk) {
+    int i, j;
+    md_locate(eb + lane, n, i, j);
+    for (int t = 0; t < 16; ++t) {
+        blk[(t >> 1) * MDX_LEAF_PITCH + (t & 1) * 64 + lane] = md_dist(P0, P1, P2, i, j);
+        md_advance(i, j, 64, n);
+    }
+}
+
+// The partial last piece: plan its leaves (lane 0), leaf sums by all lanes, tree by lane 0 -> the piece sum (valid in lane 0).
+// A kernel of its own (mean_distance_partial_piece, one wave) since round 4's second session: inside mean_distance_chunks its
+// plan, unrolled leaf sums and index arithmetic raised that kernel to 191 vector registers — two waves per SIMD for a loop that
+// needs more to hide its square-root chains — for the sake of ONE piece in 152 588 at 50 000 points.
+__device__ __forceinline__ double md_partial_piece(const double *__restrict__ P0, const double *__restrict__ P1,
+                                                             const double *__restrict__ P2, int n, long long e0, int len, int lane,
+                                                             double *s_leaf_w, int *s_off_w, int *s_cf_w) {
+    double chunk_sum;
+    if (lane == 0) {
+        const int leaves = pm_pw_plan(len, s_off_w, 160, s_cf_w, 4);
+        s_cf_w[3] = leaves;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int leaves = s_cf_w[3];
+    for (int lf = lane; lf < leaves; lf += 64) {
+        const int o = s_off_w[lf], ll = s_off_w[lf + 1] - o;
+        int i, j;
+        md_locate(e0 + o, n, i, j);
+        double res;
+        if (ll < 8) {
+            res = 0.0;
+            for (int t = 0; t < ll; ++t) { res += md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
+        } else {
+            double r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { r[u] = md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
+            int t = 8;
+            for (; t < ll - (ll % 8); t += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { r[u] += md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
+            }
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            for (; t < ll; ++t) { res += md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
+        }
+        s_leaf_w[lf] = res;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    chunk_sum = 0.0;
+    if (lane == 0) chunk_sum = pm_pw_combine(s_leaf_w, s_off_w, s_cf_w, 1, len);
+    return chunk_sum;
+}
+
 __global__ __launch_bounds__(MDX_WAVES * 64) void mean_distance_chunks(const double *__restrict__ xyz, int n, long long P, int nchunks,
                                                                        int first, int stride, double *__restrict__ partial) {
-    __shared__ int s_off[MDX_WAVES][160];
-    __shared__ int s_cf[MDX_WAVES][4];
-    __shared__ double s_leaf[MDX_WAVES][160];
     __shared__ double s_blk[MDX_WAVES][8 * MDX_LEAF_PITCH];          // a wave's block of 1 024 distances (eight leaves)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double *P0 = xyz, *P1 = xyz + (size_t)n, *P2 = xyz + 2 * (size_t)n;
@@ -160,12 +212,7 @@ __global__ __launch_bounds__(MDX_WAVES * 64) void mean_distance_chunks(const dou
                         blk[(t >> 1) * MDX_LEAF_PITCH + (t & 1) * 64 + lane] = __builtin_sqrt(__builtin_fma(d2, d2, __builtin_fma(d1, d1, d0 * d0)));
                     }
                 } else {                                             // the block crosses rows of the pair list: every lane follows its own pair
-                    int i, j;
-                    md_locate(eb + lane, n, i, j);
-                    for (int t = 0; t < 16; ++t) {
-                        blk[(t >> 1) * MDX_LEAF_PITCH + (t & 1) * 64 + lane] = md_dist(P0, P1, P2, i, j);
-                        md_advance(i, j, 64, n);
-                    }
+                    md_block_across_rows(P0, P1, P2, n, eb, lane, blk);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -188,43 +235,23 @@ __global__ __launch_bounds__(MDX_WAVES * 64) void mean_distance_chunks(const dou
             for (int st = 1; st < 64; st <<= 1) keep = keep + __shfl_down(keep, st, 64);   // balanced tree: left + right
             chunk_sum = keep;                                        // valid in lane 0
         } else {
-            // the partial last piece: plan its leaves (lane 0), leaf sums by all lanes, tree by lane 0
-            if (lane == 0) {
-                const int leaves = pm_pw_plan(len, s_off[wave], 160, s_cf[wave], 4);
-                s_cf[wave][3] = leaves;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const int leaves = s_cf[wave][3];
-            for (int lf = lane; lf < leaves; lf += 64) {
-                const int o = s_off[wave][lf], ll = s_off[wave][lf + 1] - o;
-                int i, j;
-                md_locate(e0 + o, n, i, j);
-                double res;
-                if (ll < 8) {
-                    res = 0.0;
-                    for (int t = 0; t < ll; ++t) { res += md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
-                } else {
-                    double r[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { r[u] = md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
-                    int t = 8;
-                    for (; t < ll - (ll % 8); t += 8) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { r[u] += md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
-                    }
-                    res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-                    for (; t < ll; ++t) { res += md_dist(P0, P1, P2, i, j); md_advance(i, j, 1, n); }
-                }
-                s_leaf[wave][lf] = res;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            chunk_sum = 0.0;
-            if (lane == 0) chunk_sum = pm_pw_combine(s_leaf[wave], s_off[wave], s_cf[wave], 1, len);
+            continue;                                                // the one partial piece of a cloud: mean_distance_partial_piece
         }
         if (lane == 0) partial[c] = chunk_sum;
     }
+}
+
+// The last piece of the pair list when it is not a full one (one wave; launched beside mean_distance_chunks by the rank that owns it).
+__global__ __launch_bounds__(64) void mean_distance_partial_piece(const double *__restrict__ xyz, int n, long long P, int nchunks,
+                                                                  double *__restrict__ partial) {
+    __shared__ int s_off[160];
+    __shared__ int s_cf[4];
+    __shared__ double s_leaf[160];
+    const int c = nchunks - 1;
+    const long long e0 = (long long)c * PM_PW_CHUNK;
+    const int len = (int)(P - e0);
+    const double s = md_partial_piece(xyz, xyz + (size_t)n, xyz + 2 * (size_t)n, n, e0, len, (int)threadIdx.x, s_leaf, s_off, s_cf);
+    if (threadIdx.x == 0) partial[c] = s;
 }
 
 // the piece sums, one after the other (np.add.reduce across its buffer-sized pieces), divided by P
@@ -374,7 +401,11 @@ static int md_launch(const double *xyz, int n, int first, int stride, double *pa
     const long long mine = (nchunks - 1 - first) / stride + 1;
     const long long want = (mine + pm::MDX_WAVES - 1) / pm::MDX_WAVES;
     const int blocks = (int)(want < 8192 ? want : 8192);             // (waves stride over the pieces beyond that)
-    pm::mean_distance_chunks<<<blocks, pm::MDX_WAVES * 64, 0, s>>>(xyz, n, md_pairs(n), nchunks, first, stride, partial);
+    const long long P = md_pairs(n);
+    if (P % PM_PW_CHUNK != 0 && (nchunks - 1 - first) % stride == 0)    // this rank holds the last piece and it is a partial one
+        pm::mean_distance_partial_piece<<<1, 64, 0, s>>>(xyz, n, P, nchunks, partial);
+    // (loads batched 2, 4, 8 or 16 at a time measure the same, 2.71-2.77 ms with the serial finish at 50 000 points: profiles/r04_stats_timing.txt)
+    pm::mean_distance_chunks<<<blocks, pm::MDX_WAVES * 64, 0, s>>>(xyz, n, P, nchunks, first, stride, partial);
     return pm::launch_status();
 }
 
