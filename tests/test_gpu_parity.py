@@ -153,8 +153,11 @@ def test_neighbor_list_histogram(gpu, micro):
     for md, key in ((1.0, "grid_sc_md1"), (3.0, "grid_sc_md3")):
         assert np.array_equal(get_shape_context(micro["grid_neighbors"], md), micro[key])
     assert np.array_equal(get_shape_context(micro["rand_neighbors"], 55.0), micro["rand_sc"])
+    # (other binnings: tests/test_gpu_binning.py against the reference's own histograms; here only that the arguments are taken)
+    four_rings = get_shape_context(micro["rand_neighbors"], 55.0, n_rbins=4)
+    assert four_rings.shape == (4 * 6 * 12,) and abs(np.nansum(four_rings) - 1.0) < 1e-12
     with pytest.raises(ValueError):
-        get_shape_context(micro["rand_neighbors"], 55.0, n_rbins=4)
+        get_shape_context(micro["rand_neighbors"], 55.0, n_rbins=0)
 
 
 # ------------------------------------------------------------------------------------------------ chi-square
