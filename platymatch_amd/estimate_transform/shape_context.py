@@ -114,6 +114,10 @@ def get_Y(z, x):
 def get_shape_context(neighbors, mean_dist, r_inner=1 / 8, r_outer=2, n_rbins=5, n_thetabins=6, n_phibins=12):
     """shape_context.py:10-42: histogram of neighbours already expressed in the local frame
     ((N-1) x 3 rows of x_, y_, z_), normalised by the number counted."""
+    if (neighbors.numel() if nat.is_torch(neighbors) else np.asarray(neighbors).size) == 0:
+        # no neighbour at all: the reference's loops run zero times and sc / sc.sum() is 0 / 0 in every bin (:37-41)
+        sc = np.full(int(n_rbins) * int(n_thetabins) * int(n_phibins), np.nan)
+        return nat.torch_mod().as_tensor(sc, device=neighbors.device) if nat.is_torch(neighbors) else sc
     nb = nat.to_dev(neighbors)
     if nb.dim() != 2 or nb.shape[1] != 3:
         raise ValueError("neighbors must be (N-1) x 3")

@@ -86,6 +86,16 @@ def test_legacy_get_bin_index_helper(micro):
     assert np.allclose(y, [[0.0, 1.0, 0.0]])
 
 
+def test_an_empty_neighbour_list_gives_the_references_all_nan_histogram():
+    """shape_context.py:25-41 with no neighbour: the loops run zero times and sc / sc.sum() is 0 / 0 in every bin (what the unmodified
+    reference returns: a (360,) array of NaN); no device is involved."""
+    from platymatch_amd.estimate_transform.shape_context import get_shape_context
+    for empty in (np.zeros((0, 3)), []):
+        sc = get_shape_context(empty, 1.0)
+        assert isinstance(sc, np.ndarray) and sc.shape == (360,) and np.isnan(sc).all()
+    assert get_shape_context([], 2.0, n_rbins=3, n_thetabins=4, n_phibins=5).shape == (60,)
+
+
 def test_install_as_platymatch_aliases():
     import sys
     import platymatch_amd
