@@ -350,7 +350,7 @@ __global__ __launch_bounds__(SC_THREADS) void neighbors_kernel(const double *__r
     __syncthreads();
     for (int j = threadIdx.x; j < n; j += SC_THREADS) {
         const double vx = nb[3 * (size_t)j], vy = nb[3 * (size_t)j + 1], vz = nb[3 * (size_t)j + 2];
-        const double r_ = __builtin_sqrt((vx * vx + vy * vy) + vz * vz);
+        const double r_ = __builtin_sqrt(__builtin_fma(vz, vz, __builtin_fma(vy, vy, vx * vx)));   // np.linalg.norm of three numbers: BLAS ddot's fused chain (as pm_stats.hip)
         const int b = pm_bin_index(vx, vy, vz, r_, r_ / md);
         if (b != PM_DROP) { atomicAdd(&h[b], 1u); atomicAdd(&tot, 1u); }
     }
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void neighbors_binned_kernel(const double *__r
                                                                int32_t *__restrict__ unsure, int32_t *__restrict__ n_unsure) {
     for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x) {
         const double vx = nb[3 * j], vy = nb[3 * j + 1], vz = nb[3 * j + 2];
-        const double r_ = __builtin_sqrt((vx * vx + vy * vy) + vz * vz);      // :29 (np.linalg.norm of three numbers)
+        const double r_ = __builtin_sqrt(__builtin_fma(vz, vz, __builtin_fma(vy, vy, vx * vx)));      // :29 (np.linalg.norm of three numbers: ddot's fused chain)
         const double r = r_ / md;                                              // :30
         const double c = vz / r_;                                              // :31 argument of arccos
         if (!(__builtin_fabs(c) <= 1.0) || vx != vx || vy != vy) continue;     // arccos / arctan2 -> NaN: never counted

@@ -349,7 +349,9 @@ class FilteredMatrix:
             keep = L[5] <= eps                               # the same duals were listed (with a margin at least as wide): reuse
             return 0, 0, L[4][keep], L[5][keep], 0.0
         cap = max(int(cap), self.LIST_CAPACITY_PER_COLUMN * self.shape[1])
-        _, _, tight, red, _ = self.A.certificate(u, v, col4row, 1.0, eps, cap)      # (delta = 1: nothing is set aside as a violation)
+        viol, _, tight, red, _ = self.A.certificate(u, v, col4row, float("inf"), eps, cap)      # (delta = inf: nothing is set aside as a violation)
+        if viol:
+            tight = None                                     # (cannot happen with delta = inf; an unlisted entry must never pass for feasible)
         if tight is not None:
             self._listed = (np.array(u, copy=True), np.array(v, copy=True), np.array(col4row, copy=True), float(eps), tight, red)
         return 0, 0, tight, red, 0.0
@@ -363,8 +365,8 @@ class FilteredMatrix:
         torch = nat.torch_mod()
         nr, nc = self.shape
         tau = self._tau(u, v)
-        _, _, tight, red, _ = self.A.certificate_t(u, v, col4row, 1.0, tau, self.LIST_CAPACITY_PER_COLUMN * nc)
-        if tight is None:
+        viol, _, tight, red, _ = self.A.certificate_t(u, v, col4row, float("inf"), tau, self.LIST_CAPACITY_PER_COLUMN * nc)
+        if tight is None or viol:
             return None
         self._listed = (np.array(u, copy=True), np.array(v, copy=True), np.array(col4row, copy=True), tau, tight.cpu().numpy(), red.cpu().numpy())
         if tight.shape[0] == 0:
@@ -390,7 +392,7 @@ class FilteredMatrix:
             return self._threshold_select_t(u, v, col4row)
         nr = self.shape[0]
         tau = self._tau(u, v)
-        _, _, tight, _, _ = self.certificate(u, v, col4row, 1.0, tau, 0)
+        _, _, tight, _, _ = self.certificate(u, v, col4row, float("inf"), tau, 0)
         if tight is None:
             return None
         if len(tight) == 0:

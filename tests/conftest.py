@@ -56,3 +56,35 @@ def synth_pair(n, seed, sigma=1.0, m=None):
     if m is not None:
         fx = np.ascontiguousarray(fx[:, :m])
     return np.ascontiguousarray(mv), fx, A_gt
+
+
+def ring_edge_neighbours(count=48, seed=77):
+    """Single neighbours that sit EXACTLY on a ring radius of the shape context under the reference's own norm — np.linalg.norm of a
+    3-vector, BLAS ddot's fused chain on x86-64 — and one ulp inside it under the unfused sum of squares (the two
+    differ for ~10 % of vectors).  -> list of (neighbour [1, 3], mean_dist, the reference's histogram by its literal NumPy lines).
+    mean_dist = norm / edge, kept only where norm / mean_dist is the edge to the bit."""
+    rng = np.random.default_rng(seed)
+    out = []
+    edges = np.logspace(np.log10(1 / 8), np.log10(2), 5)          # :24 (two of the five are one ulp above a power of two)
+    while len(out) < count:
+        v = rng.normal(size=3) * rng.choice([0.01, 1.0, 50.0, 1e4])
+        ref = float(np.linalg.norm(v))
+        plain = float(np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]))
+        edge = float(edges[len(out) % 5])
+        md = ref / edge
+        if not (plain < ref and ref / md == edge and plain / md < edge):
+            continue
+        r, theta, phi = ref / md, np.arccos(v[2] / ref), np.arctan2(v[1], v[0])          # shape_context.py:29-35
+        if phi < 0:
+            phi = 2 * np.pi + phi
+        r_index = 4                                                                        # :49-57
+        for k, e in enumerate(edges):
+            if r < e:
+                r_index = k
+                break
+        idx = r_index * 72 + theta // (np.pi / 6) * 12 + phi // (2 * np.pi / 12)
+        sc = np.zeros(360)
+        if 0 <= idx < 360:
+            sc[int(idx)] = 1.0
+        out.append((v.reshape(1, 3).copy(), md, sc / sc.sum()))
+    return out

@@ -160,6 +160,19 @@ def test_neighbor_list_histogram(gpu, micro):
         get_shape_context(micro["rand_neighbors"], 55.0, n_rbins=0)
 
 
+def test_neighbour_list_kernels_take_numpys_fused_norm(gpu):
+    """ADVICE r04: both neighbour-list kernels restate np.linalg.norm(neighbor) (shape_context.py:29) as BLAS ddot's fused chain;
+    neighbours exactly on a ring radius under that form (one ulp inside under the unfused one) fall into the reference's ring,
+    with the compiled tables and with tables built at call time."""
+    from conftest import ring_edge_neighbours
+    from platymatch_amd.estimate_transform.shape_context import get_shape_context
+    for nb, md, want in ring_edge_neighbours():
+        assert np.array_equal(get_shape_context(nb, md), want)
+        assert np.array_equal(get_shape_context(nb, md, 1 / 8, 2, 5, 6, 12 + 0), want)
+        six = get_shape_context(nb, md, n_phibins=6)                      # (tables built at call time: neighbors_binned_kernel)
+        assert six.shape == (180,) and np.nansum(six) == 1.0 and int(np.nanargmax(six)) // 36 == int(np.nanargmax(want)) // 72
+
+
 # ------------------------------------------------------------------------------------------------ chi-square
 def fixture_descriptors(oracle, d):
     um = oracle.normalise_counts(*oracle.shape_context_counts(d["centroid_m"], d["mean_dist_m"], d["moving"], "moving", x0=d["x0_m"]))

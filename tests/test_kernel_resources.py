@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-pytestmark = pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not found")
+pytestmark = pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="hipcc not found")     # (build._hipcc's own search)
 
 #          file                    kernel name starts with                              max vgpr  scratch allowed
 BUDGETS = [("pm_stats.hip", "pm::mean_distance_chunks", 96, False),
@@ -37,5 +37,5 @@ def test_hot_kernels_keep_their_register_budget(rows, file, prefix, max_vgpr, sc
     if not match:
         pytest.skip("kernel names not demangled on this host (no c++filt)")
     for r in match:
-        assert r["vgpr"] + r["agpr"] <= max_vgpr, r
+        assert r["vgpr"] <= max_vgpr, r            # (.vgpr_count is the unified total on gfx950: it contains the AGPRs)
         assert r["spills"] == 0 and (scratch_ok or r["scratch"] == 0), r

@@ -265,3 +265,11 @@ def test_pca_axis_is_sklearns_bit_for_bit(oracle):
         kind = int(d["c%02d_kind" % k][0])
         view = sc.pca_view(d["c%02d_cloud" % k], transposed=(kind == 2))
         assert np.array_equal(sc.pca_axis_host(view), want), k
+
+
+def test_explicit_neighbour_lists_take_numpys_fused_norm(oracle):
+    """shape_context.py:29 on an explicit list: a neighbour exactly on a ring radius under np.linalg.norm's fused chain (one ulp
+    inside it under the unfused form) lands in the reference's ring."""
+    from conftest import ring_edge_neighbours
+    for nb, md, want in ring_edge_neighbours():
+        assert np.array_equal(oracle.get_shape_context(nb, md), want)

@@ -13,18 +13,21 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "platymatch_amd", "csrc")
+sys.path.insert(0, ROOT)
+from platymatch_amd import build as B  # noqa: E402
 
 
 def census(files=None):
-    """-> list of dicts {file, name (demangled where c++filt exists, arguments cut), vgpr, agpr, lds, scratch, spills, waves, workgroups}"""
+    """-> list of dicts {file, name (demangled where c++filt exists, arguments cut), vgpr (unified total), agpr (its accumulation part), lds, scratch, spills, waves, workgroups}"""
     files = files or sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     filt = shutil.which("c++filt") or shutil.which("llvm-cxxfilt")
     rows = []
     for f in files:
         with tempfile.TemporaryDirectory() as d:
             out = os.path.join(d, "k.s")
-            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-S",
-                            "--cuda-device-only", os.path.join(CSRC, f), "-o", out], check=True, capture_output=True)
+            # the compiler, target and flags of the product's own build (platymatch_amd/build.py)
+            subprocess.run([B._hipcc()] + [x for x in B.FLAGS if x != "-fPIC"] + ["-S", "--cuda-device-only", os.path.join(CSRC, f), "-o", out],
+                           check=True, capture_output=True)
             text = open(out).read()
         meta = text[text.find("amdhsa.kernels:"):]
         for blk in re.split(r"\n  - \.agpr_count:", meta)[1:]:
@@ -37,7 +40,9 @@ def census(files=None):
                 name = subprocess.run([filt, name], capture_output=True, text=True).stdout.strip()
             name = re.sub(r"\(.*", "", name)
             vgpr, lds = g("vgpr_count"), g("group_segment_fixed_size")
-            regs = (vgpr + agpr + 7) // 8 * 8
+            # gfx90a and later have ONE register file per lane: .vgpr_count is the unified total and already contains the
+            # accumulation registers .agpr_count reports (adding them counted those twice)
+            regs = (vgpr + 7) // 8 * 8
             rows.append(dict(file=f, name=name, vgpr=vgpr, agpr=agpr, lds=lds, scratch=g("private_segment_fixed_size"), spills=g("vgpr_spill_count"),
                              waves=min(8, 512 // max(regs, 8)), workgroups=(160 * 1024 // lds) if lds else None))
     return rows
