@@ -100,6 +100,10 @@ static double bin_index(double x_, double y_, double z_, double mean_dist) {
  * input, so :29 is restated to the bit: np.linalg.norm of a 3-vector is sqrt(x.dot(x)) with BLAS ddot, whose x86-64 kernels
  * accumulate with fused multiply-adds — sqrt(fma(z, z, fma(y, y, x * x))) (20 000 of 20 000 random vectors on this host; the
  * plain order matches 17 905; tests/test_oracle_golden.py pins it against NumPy itself). */
+int pmo_bin_index_projected(const double *nb, int n, double mean_dist, double *idx_out) {     /* get_unary's inner step as sc_one_point takes it */
+    for (int i = 0; i < n; ++i) idx_out[i] = bin_index(nb[3 * i], nb[3 * i + 1], nb[3 * i + 2], mean_dist);
+    return 0;
+}
 int pmo_bin_index(const double *nb, int n, double mean_dist, double *idx_out) {
     for (int i = 0; i < n; ++i) {
         const double x_ = nb[3 * i], y_ = nb[3 * i + 1], z_ = nb[3 * i + 2];

@@ -236,11 +236,14 @@ def get_unary(centroid, mean_distance, detections, type, transposed=False, x0=No
     return sc[0], sc[1], np.array([]), np.array([])
 
 
-def get_bin_index_direct(neighbors, mean_dist):
-    """Float bin index of each (already frame-expressed) neighbour: shape_context.py:25-36 + 46-58."""
+def get_bin_index_direct(neighbors, mean_dist, projected=False):
+    """Float bin index of each (already frame-expressed) neighbour: shape_context.py:25-36 + 46-58.  Default: the reference's
+    arithmetic on an explicit list to the bit (:29 = np.linalg.norm's fused chain); projected=True: the step as
+    shape_context_counts takes it on its directly projected neighbours (:29 in the plain order — pm_oracle.c: bin_index)."""
     nb = _f64(neighbors)
     out = np.empty(nb.shape[0], dtype=np.float64)
-    lib().pmo_bin_index(_p(nb), ctypes.c_int(nb.shape[0]), ctypes.c_double(float(mean_dist)), _p(out))
+    fn = lib().pmo_bin_index_projected if projected else lib().pmo_bin_index
+    fn(_p(nb), ctypes.c_int(nb.shape[0]), ctypes.c_double(float(mean_dist)), _p(out))
     return out
 
 

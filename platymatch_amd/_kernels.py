@@ -413,7 +413,7 @@ def _sym_workspace(lib, nM, nF, device):
     return _t().empty(int(lib.pm_chi2_sym_workspace_bytes(nM, nF)), dtype=_t().uint8, device=device)
 
 
-PAIRINGS = ((0, 5), (1, 4), (2, 7), (3, 6))      # pairing t -> (hypothesis summed in natural order, its twin), widget numbering
+from ._pairings import PAIRINGS  # noqa: E402  pairing t -> (hypothesis summed in natural order, its twin), widget numbering
 
 
 def chi2_cost8_frame1_by_pairings(sc_m1, sc_f1, out=None):

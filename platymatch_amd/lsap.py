@@ -66,7 +66,7 @@ COLUMN_REDUCTION = True          # start square solves from the column reduction
 DEVICE_MIN_ROWS = 1024           # below this the dense host solver is quicker than the round trips of the device scheme
 # The eight matrices hold four distinct sets of terms: U11/U22, U12/U21, U13/U24, U14/U23 differ only in
 # summation order (<= 6e-16 per entry), so one solve serves both — the twin is CERTIFIED on its own entries, not assumed.
-TWINS = {5: 0, 4: 1, 7: 2, 6: 3}
+from ._pairings import PAIRINGS, TWINS  # noqa: E402
 
 
 class _Core:

@@ -315,7 +315,6 @@ def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=No
     hypothesis or None, col4row of the twin or None) on EVERY rank; None = not certified (the caller takes another route
     for that matrix).  N <= M required.  accept_near_ties: an assignment certified optimal but not proven unique
     (lsap.certify: info["optimal"]) is returned instead of None; info["near_tie"] lists which (0 = hypothesis, 1 = twin)."""
-    torch = _torch()
     wire = _Wire(bounds, n_cols, group, root)
     locals_ = [local_h] + ([local_twin] if local_twin is not None else [])
     out = [None, None, None]                              # col4row, twin's col4row, error message
@@ -356,7 +355,13 @@ def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=No
             ShardedMatrix(locals_, 0, wire).stop()
     else:
         serve(locals_, wire)
-    # the result, to every rank: int64 (has hypothesis, has twin, failed) | int32 [2, N] | the message if it failed
+    return _share_result(wire, out, root)
+
+
+def _share_result(wire, out, root):
+    """out = [col4row of the hypothesis | None, of the twin | None, error message | None] on the root -> the two vectors on EVERY
+    rank: int64 (has hypothesis, has twin, failed) | int32 [2, N] | the message if it failed (raised on all ranks)."""
+    torch = _torch()
     if wire.is_root:
         res = wire.tensor(np.array([out[0] is not None, out[1] is not None, out[2] is not None], dtype=np.int64), torch.int64)
         both = np.zeros((2, wire.nr), dtype=np.int32)
@@ -374,3 +379,34 @@ def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=No
         raise RuntimeError("sharded assignment failed on rank %d: %s" % (root, _message(_host(msg)[2:])))
     got = _host(c4r)
     return (got[0].copy() if has_h else None), (got[1].copy() if has_t else None)
+
+
+def solve_pair_sharded_filtered(local_filter, exact_entries, cost_delta, bounds, n_cols, group, root, info=None):
+    """One pairing (hypothesis + twin) from ROW BLOCKS OF ITS FILTER MATRIX (pipeline.assign_sharded_filtered): local_filter is this
+    rank's block of an approximate matrix within cost_delta of both exact matrices (lsap.DeviceMatrix over the float32 block; the CPU
+    tests pass a NumPy double).  The root runs lsap.solve_core on a lsap.FilteredMatrix whose selector is the ShardedMatrix over
+    those blocks — column minima, row selection and the listing pass are answered by every rank for its rows — and whose costs are
+    exact_entries(rows, cols) -> (hypothesis's exact values, twin's), evaluated on the root alone (only the root calls it); the
+    result is certified against both exact matrices on their listed entries (lsap.certify_listed: the exact mode's own margins).
+    -> (col4row, col4row) on every rank, or (None, None) if the pairing could not be proven (the caller builds it exactly)."""
+    wire = _Wire(bounds, n_cols, group, root)
+    locals_ = [local_filter]
+    out = [None, None, None]
+    if wire.is_root:
+        try:
+            info = {} if info is None else info
+            tinfo = info["twin"] = {}
+            M = lsap.FilteredMatrix(ShardedMatrix(locals_, 0, wire), exact_entries, cost_delta)
+            sol = lsap.solve_core(M, info)
+            if sol is not None:
+                ok = lsap.certify_listed(M, *sol, exact_entries=exact_entries, cost_delta=cost_delta, infos=[info, tinfo])
+                if len(ok) == 2 and all(ok):
+                    out[0] = out[1] = sol[2]
+                    info["exact_evaluated"] = M.exact_evaluated
+        except Exception as e:                            # the workers are waiting for queries: release them, then raise everywhere
+            out[2] = "%s: %s" % (type(e).__name__, e)
+        finally:
+            ShardedMatrix(locals_, 0, wire).stop()
+    else:
+        serve(locals_, wire)
+    return _share_result(wire, out, root)

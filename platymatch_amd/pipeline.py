@@ -16,6 +16,7 @@ Cloud statistics (centroid, mean distance, PCA axis) are O(N)…O(N^2) on 24·N 
 redundantly by every rank: identical inputs and a fixed reduction order give identical values
 without a collective.
 """
+import dataclasses
 import os
 import threading
 
@@ -24,7 +25,7 @@ import numpy as np
 from . import _native as nat
 from .lsap import linear_sum_assignment, solve_many
 
-HYPOTHESES = ("11", "12", "13", "14", "21", "22", "23", "24")
+from ._pairings import HYPOTHESES, PAIRINGS  # noqa: E402
 _RNG_LOCK = threading.RLock()
 
 # The eight cost matrices of a large registration (160 GB at 50 000 x 50 000) are kept by THIS module between calls, one buffer
@@ -162,17 +163,39 @@ class GpuBackend:
         return self.K.chi2_cost8(sc_m, sc_f, out=out)
 
     def chi2_cost8_relaxed(self, sc_m, sc_f, out=None):
-        """Opt-in experiment: the eight matrices in relaxed float64 arithmetic (K.chi2_cost8_relaxed) — only where the
-        frame-permutation relation holds; -> (U, delta) or None if it does not (the caller builds exactly)."""
-        if sc_f.shape[0] != 1 and not self.K.chi2_symmetric(sc_m, sc_f):
-            return None
+        """The eight matrices in relaxed float64 arithmetic (K.chi2_cost8_relaxed) -> (U, delta).  Only where the frame-permutation
+        relation holds: the caller has checked it (chi2_symmetric / the sharded gather's verdict)."""
         return self.K.chi2_cost8_relaxed(sc_m[0], sc_f[0], out=out, variant=RELAXED_VARIANT), self.K.chi2_relaxed_delta()
+
+    def chi2_cost_pair_into(self, sc_m1, sc_f1, pairing, out8):
+        """One pairing's two EXACT matrices written over their slots of an eight-matrix buffer (the relaxed route's rebuild)."""
+        return self.K.chi2_cost_pair_into(sc_m1, sc_f1, pairing, out8)
 
     def chi2_cost_pair(self, sc_m, sc_f, pairing, out=None):
         """The two matrices of one pairing (hypothesis + twin) only -> [2, rows, M]; symmetric iff sc_f holds frame 1 only or
         the permutation relation checks out (symmetric_hint caches the check of the whole-cloud call)."""
         sym = sc_f.shape[0] == 1 or self.K.chi2_symmetric(sc_m, sc_f)
         return self.K.chi2_cost_pair(sc_m, sc_f, pairing, sym, out=out)
+
+    def chi2_symmetric(self, sc_m, sc_f):
+        """Do frames 2..4 permute frame 1's phi sectors bit for bit on these rows (the premise of the half-cost, relaxed and filter
+        builds)?  One pass over the descriptors."""
+        return sc_f.shape[0] == 1 or self.K.chi2_symmetric(sc_m, sc_f)
+
+    def chi2_filter4(self, a1, b1, out=None, dtype=None):
+        """The four pairings' FILTER matrices [4, rows of a1, rows of b1] (packed float32 arithmetic; within chi2_filter_delta() of
+        the exact costs) — a1's rows may be a rank's block."""
+        return self.K.chi2_filter4(a1, b1, out=out, dtype=dtype)
+
+    def chi2_filter_pair(self, a1, b1, pairing, out=None, dtype=None):
+        return self.K.chi2_filter_pair(a1, b1, pairing, out=out, dtype=dtype)
+
+    def chi2_filter_delta(self):
+        return self.K.chi2_filter_delta()
+
+    def chi2_entries(self, sc_m1, sc_f1, pairing, rows, cols, trusted=False):
+        """Listed entries of pairing t's two EXACT matrices (hypothesis, twin) -> two float64 GPU tensors."""
+        return self.K.chi2_entries(sc_m1, sc_f1, pairing, rows, cols, trusted=trusted)
 
     def chi2_cost_single(self, scA, scB):
         """One matrix chi2(scA[i], scB[j]) for any two descriptor sets [*, 360] (pm_chi2_cost)."""
@@ -422,12 +445,14 @@ def expand_frames(sc1, n_frames):
     return torch.stack([sc1[:, torch.as_tensor(_PHI[f], device=sc1.device)] for f in range(n_frames)])
 
 
-def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=None, accept_near_ties=False):
+def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=None, accept_near_ties=False, pairings=(0, 1, 2, 3)):
     """Cost matrices and assignments two matrices at a time, for clouds whose eight matrices (64 N M bytes per rank-block) do not
     fit in HBM together: for each pairing t the hypothesis and its twin are built (be.chi2_cost_pair: a quarter of the
     eight-matrix launch, the same bits), assigned with the matrices resident (one GPU: lsap.solve_pair_on_device; sharded:
     lsap_sharded.solve_pair_sharded, nothing gathered) and released.  -> list of eight (row_ind, col_ind), widget order.
-    A hypothesis that can be neither certified nor (for its size) handed to the dense solver raises."""
+    A hypothesis that can be neither certified nor (for its size) handed to the dense solver raises.
+    pairings: which of the four (hypothesis, twin) pairings to build and assign (the others' slots stay None) — the sharded filter
+    route's exact fallback asks for one."""
     from . import lsap
     rank, world = _world(group)
     n, m = bounds[-1], sc_f.shape[1]
@@ -447,7 +472,8 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
         sc_m_full = all_gather_rows(sc_m, bounds, 1, group)                           # [2, N, 360]
         f_all = sc_f if sc_f.shape[0] == 4 else expand_frames(sc_f[0], 4)             # (frame 1 only travelled: derive 2..4)
         f_loc = f_all[:, bm[rank]:bm[rank + 1]]
-        for t, (h, twin) in enumerate(((0, 5), (1, 4), (2, 7), (3, 6))):
+        for t in pairings:
+            h, twin = PAIRINGS[t]
             (ah, bh), (at, bt) = ((int(c) - 1 for c in HYPOTHESES[h]), (int(c) - 1 for c in HYPOTHESES[twin]))
             UT_h = be.chi2_cost_single(f_loc[bh], sc_m_full[ah])                      # [M_g, N] = U_h[:, block]^T
             UT_t = be.chi2_cost_single(f_loc[bt], sc_m_full[at])
@@ -471,7 +497,8 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
             info["routes"] = routes
             info["mode"] = "streamed: two matrices resident at a time"
         return out
-    for t, (h, twin) in enumerate(((0, 5), (1, 4), (2, 7), (3, 6))):
+    for t in pairings:
+        h, twin = PAIRINGS[t]
         U2 = be.chi2_cost_pair(sc_m, sc_f, t, out=buf)
         buf = U2
         ih, it = {}, {}
@@ -801,18 +828,15 @@ def _shared_device_seed(group, device):
     return int(t.item()) & ((1 << 64) - 1)
 
 
-def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
-                       ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, group=None,
-                       backend=None, icp_shard_min_points=ICP_SHARD_MIN_POINTS, private_rng=False, stream_hypotheses=None,
-                       accept_near_ties=False, sampler='auto', icp_one_launch=None, keep_cost_buffer=True, cost_mode='exact'):
-    """Reproduces _dock_widget.py:526-718 -> (A_sc, A_icp, inliers[8]); final transform = A_icp @ A_sc (:428).
+COST_MODES = ('auto', 'exact', 'relaxed', 'filter')
 
-    moving, fixed   3 x N / 3 x M float64 (rows z, y, x), NumPy or torch
-    mode            'unsupervised' (shape context + Hungarian + RANSAC) or 'supervised'
-                    (keypoints=(kp_moving, kp_fixed), 3 x k each; _dock_widget.py:707-711)
-    ransac_error    16 for CSV detections (_dock_widget.py:613-614); with nucleus sizes the widget uses
-                    0.5 * (mean(size_m)**(1/3) + mean(size_f)**(1/3)) — pass that value
-    seed            if not None, np.random.seed(seed) right before the eight RANSAC runs
+
+@dataclasses.dataclass
+class Options:
+    """What estimate_transform takes BESIDE the reference's arguments (and seed / details / cost_mode / group): pass
+    options=Options(...) or a dict of these fields.
+
+    backend         the compute backend (default: GpuBackend() on the current device; the CPU tests pass a double)
     sampler         where the RANSAC index sets come from.  'numpy': NumPy's global generator, call for call as the reference
                     consumes it (8 x trials np.random.choice calls = full shuffles, drawn on a helper thread) — with a seed, the
                     reference's own sets; 'device': drawn on the GPU in front of each trial's fit (Philox + Floyd's subset
@@ -821,231 +845,349 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                     not: the reference never seeds, so an unseeded run is random there too
     private_rng     with a seed: draw from a private RandomState(seed) and leave NumPy's global generator untouched
                     (same index sets; what estimate_transform_batch uses so that concurrent runs do not queue)
-    group           torch.distributed process group to shard over (None = this GPU only); every rank
-                    passes the same clouds and gets the same results
-    icp_shard_min_points  moving-cloud size from which ICP is sharded too (below it every rank runs it whole)
-    stream_hypotheses     None: build all eight cost matrices at once if they fit in HBM (64 N M bytes), else two at a time
-                          (assign_streamed); True / False force one or the other
-    accept_near_ties      for matrices beyond the reach of SciPy's dense algorithm (> 2^30 entries): if a hypothesis has a second
-                          assignment within ~1e-11 of the optimal cost, which of the two SciPy's rounding would return cannot be
-                          told; False raises, True takes the certified optimum (details['assignment']['routes'] says so)
-    keep_cost_buffer  large registrations (eight matrices >= 8 GiB) write their cost matrices into a buffer this module keeps per
-                    (device, stream) between calls (see COST_CACHE_MIN_BYTES above; release_cost_buffers() frees it); False: a fresh
-                    allocation per call, returned to torch's allocator afterwards
-    cost_mode       'exact' (default): the eight cost matrices bit-identical to the reference's scalar loop.  Two opt-in modes (one
-                    GPU, clouds of >= 1 024 points) return the SAME assignment vectors by proof without those matrices:
-                    'relaxed': built in relaxed float64 arithmetic (1.55x faster at 50 000; every entry within 2e-13 of the exact
-                    cost), solved, and the result certified against the exact matrices on their matched and near-tight entries
-                    (lsap.certify_listed); 'filter' (>= 8 192 points, below that: 'relaxed'): four matrices in packed float32
-                    arithmetic (3.2x faster, within 1e-6) only SELECT entries, every cost the solver and the certificate use is
-                    evaluated exactly (lsap.FilteredMatrix).  A pairing that cannot be certified (ties, near-ties) gets its exact
-                    matrices built and goes the exact mode's way; details['assignment']['details'][h]['cost_mode'] says which
-                    route each hypothesis took
-    icp_one_launch  None: perform_icp.ONE_LAUNCH decides (default False: one launch per iteration); True: iterations 1 .. n-1 of the
-                    Affine ICP loop in one launch of persistent workgroups (only for a device that does nothing else meanwhile;
-                    estimate_transform_batch always passes False: its workers keep several streams busy) — identical results
-    details         optional dict filled with intermediate results (lsa, ransac_A, residuals, edge_guard: how many neighbours lie so
-                    close to a ring radius ("ring") or to a sector plane / polar cone ("sector") — or coincide with the queried
-                    point — that the reference itself would bin them by the rounding noise of its linear algebra; all zero =
-                    the integer histograms are the reference's by construction for this call)
-    """
-    import time
+    accept_near_ties  for matrices beyond the reach of SciPy's dense algorithm (> 2^30 entries): if a hypothesis has a second
+                    assignment within ~1e-11 of the optimal cost, which of the two SciPy's rounding would return cannot be
+                    told; False raises, True takes the certified optimum (details['assignment']['routes'] says so)
+    stream_hypotheses  None: keep all matrices of the chosen build resident if they fit in HBM, else build them pairing by
+                    pairing; True / False force one or the other
+    keep_cost_buffer  large registrations (>= 8 GiB of cost matrices) write them into a buffer this module keeps per (device,
+                    stream) between calls (COST_CACHE_MIN_BYTES; release_cost_buffers() frees it, reserve() makes it ahead of
+                    the first call); False: a fresh allocation per call, returned to torch's allocator afterwards
+    icp_shard_min_points  moving-cloud size from which a sharded run shards ICP too (below it every rank runs it whole)
+    icp_one_launch  None: perform_icp.ONE_LAUNCH decides (default False: one launch per iteration); True: iterations 1 .. n-1 of
+                    the Affine ICP loop in one launch of persistent workgroups (only for a device that does nothing else meanwhile;
+                    estimate_transform_batch always passes False) — identical results"""
+    backend: object = None
+    sampler: str = 'auto'
+    private_rng: bool = False
+    accept_near_ties: bool = False
+    stream_hypotheses: object = None
+    keep_cost_buffer: bool = True
+    icp_shard_min_points: int = ICP_SHARD_MIN_POINTS
+    icp_one_launch: object = None
+
+    @classmethod
+    def of(cls, options):
+        if options is None:
+            return cls()
+        if isinstance(options, cls):
+            return options
+        if isinstance(options, dict):
+            return cls(**options)                      # (an unknown field is a TypeError naming it)
+        raise TypeError("options must be a pipeline.Options, a dict of its fields, or None")
+
+
+def resolve_cost_mode(cost_mode, n, m, world, be):
+    """Which build the assignment stage STARTS from -> 'filter' | 'relaxed' | 'exact'.  'auto' (the default) and 'filter': the
+    float32 filter matrices from FILTER_MIN_POINTS points on (one GPU or sharded), the relaxed float64 build from
+    RELAXED_MIN_POINTS on (one GPU), the exact build below; 'relaxed': that build or the exact one; 'exact': always the exact
+    one.  Every route returns the exact build's assignment vectors — a pairing the cheaper build cannot PROVE (ties, near-ties
+    inside the exact mode's own margin, non-finite costs, descriptors whose frames do not permute) has its exact matrices built."""
+    if cost_mode not in COST_MODES:
+        raise ValueError("cost_mode must be one of %s" % (COST_MODES,))
+    small = min(int(n), int(m))
+    want = 'filter' if cost_mode == 'auto' else cost_mode
+    if want == 'filter' and small >= FILTER_MIN_POINTS and hasattr(be, "chi2_filter4"):
+        return 'filter'
+    if want in ('filter', 'relaxed') and world == 1 and small >= RELAXED_MIN_POINTS and hasattr(be, "chi2_cost8_relaxed"):
+        return 'relaxed'
+    return 'exact'
+
+
+def filter_bytes(n, m, rows_short=None):
+    """Device memory of the filter route at its peak on one rank: the four filter matrices of its block of the SHORT side's rows
+    (float32: 16 bytes per row and column; PM_FILTER_F64=1: 32) and, at the worst, one pairing's two exact matrices beside them."""
+    short, long_ = min(n, m), max(n, m)
+    rows = short if rows_short is None else rows_short
+    return (16.0 if FILTER_STORAGE_F32 else 32.0) * rows * long_, 16.0 * rows * long_
+
+
+def _filter_dtype():
     import torch
-    be = backend or GpuBackend()
-    if backend is None:
-        from . import self_check
-        self_check()                          # once per process: does this host's NumPy / BLAS round as the kernels restate it?
-    mov, fix = be.cloud(moving), be.cloud(fixed)
-    inliers = np.zeros(8, dtype=np.int64)
-    rank, world = _world(group)
-    timing = {} if (details is not None and details.get("timing")) else None     # details={"timing": True}: wall-clock split
+    return torch.float32 if FILTER_STORAGE_F32 else torch.float64
 
-    def mark(name, t0):
-        if timing is not None:
-            if mov.is_cuda:
-                torch.cuda.current_stream(mov.device).synchronize()
-            timing[name] = timing.get(name, 0.0) + time.perf_counter() - t0
-        return time.perf_counter()
 
-    t0 = time.perf_counter()
-    if sampler not in ('auto', 'numpy', 'device'):
-        raise ValueError("sampler must be 'auto', 'numpy' or 'device'")
-    if cost_mode not in ('exact', 'relaxed', 'filter'):
-        raise ValueError("cost_mode must be 'exact', 'relaxed' or 'filter'")
-    on_device = (sampler == 'device' or (sampler == 'auto' and seed is None)) and getattr(be, "device_sampler", False) \
-        and int(ransac_samples) <= min(mov.shape[1], fix.shape[1])
-    if mode == 'unsupervised':
-        # what do_ransac draws depends only on the number of matched pairs: start drawing before the GPU has built anything
-        # (device sampler: nothing to draw ahead — each trial's set is drawn in front of its fit)
-        draws = _SampleDraws(be, min(mov.shape[1], fix.shape[1]), int(ransac_samples), 0 if on_device else int(ransac_trials),
-                             seed, private_rng)
-        a_info = None if details is None else details.setdefault("assignment", {})
-        lease = relaxed = None
-        filtered = False
-        try:
-            guards = [] if getattr(be, "device_sampler", False) else None     # (the GPU backend: its descriptor launches count)
-            views = (None, None)
-            if getattr(be, "device_sampler", False):
-                from .estimate_transform.shape_context import pca_view
-                views = (pca_view(moving), pca_view(fixed))       # what the reference would hand to sklearn: the caller's own arrays
-            sc_m, sc_f, bn = build_descriptors(be, mov, fix, group, guards=guards, views=views)
-            # all eight matrices at once when they fit (four assignments then run side by side); otherwise two at a time
-            need = cost_bytes(sc_m.shape[1], mov.shape[1], sc_f.shape[1], world)
-            use_filter = (cost_mode == 'filter' and min(mov.shape[1], fix.shape[1]) >= FILTER_MIN_POINTS and world == 1 and mov.is_cuda
-                          and getattr(be, "device_sampler", False) and (sc_f.shape[0] == 1 or be.K.chi2_symmetric(sc_m, sc_f)))
-            if use_filter:                    # four filter matrices + one pairing's two exact ones at the worst
-                need = need // 2 if FILTER_STORAGE_F32 else need * 3 // 4
-            if stream_hypotheses is not None:
-                streamed = bool(stream_hypotheses)
-            else:
-                streamed = hasattr(be, "free_bytes") and hasattr(be, "chi2_cost_pair") and need > 0.85 * be.free_bytes()
-                # free memory and row counts differ from rank to rank: near the threshold ranks would take different branches,
-                # i.e. different sequences of collectives.  One rank that must stream makes all of them stream.
-                streamed = bool(agree_max(1 if streamed else 0, group, mov.device))
-            if streamed:
-                U = None
-            else:
-                if keep_cost_buffer and mov.is_cuda and need >= COST_CACHE_MIN_BYTES and world == 1:
-                    lease = cost_buffer(mov.device, (8, sc_m.shape[1], sc_f.shape[1]))     # None: another registration holds it
-                if (cost_mode in ('relaxed', 'filter') and not use_filter and world == 1 and mov.is_cuda and hasattr(be, "chi2_cost8_relaxed")
-                        and min(mov.shape[1], fix.shape[1]) >= RELAXED_MIN_POINTS):
-                    relaxed = be.chi2_cost8_relaxed(sc_m, sc_f, out=None if lease is None else lease.view)
-                if use_filter:
-                    # the filter matrices with the SHORT side as rows (N > M: the descriptors' roles swapped — the terms are symmetric
-                    # and every pairing's bin map is an involution, so that is the transposed filter to within its bound), carved
-                    # out of the kept buffer when there is one
-                    filtered = True
-                    n_, m_ = mov.shape[1], fix.shape[1]
-                    fshape = (4, min(n_, m_), max(n_, m_))
-                    fdtype = torch.float32 if FILTER_STORAGE_F32 else torch.float64
-                    fout = None
-                    if lease is not None:
-                        fout = lease.view.view(fdtype).reshape(-1)[:4 * n_ * m_].view(fshape)
-                    a_, b_ = (sc_m[0], sc_f[0]) if n_ <= m_ else (sc_f[0], sc_m[0])
-                    U = be.K.chi2_filter4(a_, b_, out=fout, dtype=fdtype)
-                elif relaxed is not None:
-                    U, relaxed_delta = relaxed
-                else:
-                    U = be.chi2_cost8(sc_m, sc_f, out=None if lease is None else lease.view)
-        except BaseException:
-            draws.thread.join()
-            if lease is not None:
-                lease.release()
-            raise
-        t0 = mark("gpu_descriptors_costs", t0)
-        try:
-            if filtered or (streamed and use_filter):
-                from .lsap import solve_four_filtered
-                sc_m1, sc_f1 = sc_m[0], sc_f[0]
-                n_, m_ = mov.shape[1], fix.shape[1]
+def _decide_streamed(be, need, opts, group, device):
+    """All matrices of the chosen build at once, or pairing by pairing?  One rank that must stream makes all of them stream (free
+    memory and row counts differ from rank to rank: near the threshold they would enter different sequences of collectives)."""
+    if opts.stream_hypotheses is not None:
+        return bool(opts.stream_hypotheses)
+    streamed = hasattr(be, "free_bytes") and hasattr(be, "chi2_cost_pair") and need > 0.85 * be.free_bytes()
+    return bool(agree_max(1 if streamed else 0, group, device))
 
-                def entries_np(t):
-                    return lambda rows, cols: tuple(x.cpu().numpy() for x in be.K.chi2_entries(sc_m1, sc_f1, t, rows, cols))
 
-                def entries_t(t):              # (index lists from the library's own kernels: no range check, no read-back)
-                    return lambda rows, cols: be.K.chi2_entries(sc_m1, sc_f1, t, rows, cols, trusted=True)
-
-                def build_pairing(t, out):     # streamed: one pairing's filter matrix, the short side as its rows
-                    return be.K.chi2_filter_pair(sc_m1, sc_f1, t, out=out) if n_ <= m_ else be.K.chi2_filter_pair(sc_f1, sc_m1, t, out=out)
-                in_flight = 4
-                fdtype = torch.float32 if FILTER_STORAGE_F32 else torch.float64
-                if not filtered:
-                    in_flight = max(1, min(4, int(0.85 * be.free_bytes() // ((4 if FILTER_STORAGE_F32 else 8) * n_ * m_))))
-                lsa = solve_four_filtered(U if filtered else None, entries_np, entries_t, be.K.chi2_filter_delta() + 1e-13,
-                                          lambda t: be.K.chi2_cost_pair(sc_m, sc_f, t, True), info=a_info, accept_near_ties=accept_near_ties,
-                                          build=build_pairing, shape=(n_, m_), device=mov.device, in_flight=in_flight, storage=fdtype)
-                if a_info is not None and not filtered:
-                    a_info["mode"] = "streamed: %d filter matri%s resident at a time" % (in_flight, "x" if in_flight == 1 else "ces")
-                if any(a is None for a in lsa):
-                    raise RuntimeError("a hypothesis could not be assigned (see accept_near_ties)")
-            elif streamed:
-                lsa = assign_streamed(be, sc_m, sc_f, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None),
-                                      accept_near_ties=accept_near_ties)
-            elif relaxed is not None:
-                from .lsap import solve_eight_on_device
-                from ._kernels import PAIRINGS
-                sc_m1, sc_f1 = sc_m[0], sc_f[0]
-                pairing_of = {p[0]: t for t, p in enumerate(PAIRINGS)}
-
-                def exact_entries(h):
-                    # (rows, cols) -> the listed entries of hypothesis h's exact matrix and of its twin's (pm_chi2_entries_sym)
-                    def fetch(rows, cols):
-                        return tuple(x.cpu().numpy() for x in be.K.chi2_entries(sc_m1, sc_f1, pairing_of[h], rows, cols))
-                    return fetch
-                lsa = solve_eight_on_device(U, info=a_info, accept_near_ties=accept_near_ties,
-                                            exact_entries=exact_entries if RELAXED_CERTIFY_ON_EXACT_ENTRIES else None, cost_delta=relaxed_delta,
-                                            min_eps=2.0 * min(mov.shape[1], fix.shape[1]) * relaxed_delta,
-                                            exact_rebuild=lambda h: be.K.chi2_cost_pair_into(sc_m1, sc_f1, pairing_of[h], U))
-                if any(a is None for a in lsa):
-                    raise RuntimeError("a hypothesis could not be assigned (see accept_near_ties)")
-            else:
-                lsa = assign(U, bn, group, info=a_info, local_matrix=getattr(be, "local_matrix", None), accept_near_ties=accept_near_ties)
-        finally:
-            del U, sc_m, sc_f
-            if lease is not None:
-                if mov.is_cuda:
-                    torch.cuda.current_stream(mov.device).synchronize()     # the assignment's last passes have read the buffer
-                lease.release()
-            t0 = mark("host_assignment", t0)
-            sets = draws.result()                    # every rank draws the same 8 x trials: same RNG stream everywhere
-            t0 = mark("host_draws_exposed", t0)
-            if timing is not None:
-                timing["host_draws_thread"] = draws.seconds
-        A_h = []
-        if on_device:
-            dseed = (int(seed) & ((1 << 64) - 1)) if seed is not None else _shared_device_seed(group, mov.device)
-        # 'Affine': a run's winner is the device's fit of its sample; the hypothesis the registration goes on with gets the
-        # reference's own expression on the host afterwards (one read-back instead of eight; the other seven only appear in
-        # details["ransac_A"], equal to the reference's to ~1e-12)
-        can_defer = transform == 'Affine' and hasattr(be, "refit_winner")
-        deferred = [dict() for _ in range(8)]
-        pre = [None] * 8
-        if (on_device and transform == 'Affine' and int(ransac_samples) >= 4 and int(ransac_trials) > 0 and hasattr(be, "ransac_prelaunch")
-                and all(len(r) >= int(ransac_samples) for r, _ in lsa)):
-            # all eight hypotheses' fused draw + fit + score launches go out back to back; results are read afterwards
-            pre = [be.ransac_prelaunch(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, ransac_samples, dseed, h)
-                   for h, (r, c) in enumerate(lsa)]
-        for h, (r, c) in enumerate(lsa):
-            extra = {"defer": deferred[h]} if can_defer else {}
-            if pre[h] is not None:
-                extra["prelaunched"] = pre[h]
-            if on_device:                            # stream h of the registration's seed: the eight runs draw independent sets
-                A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
-                                    ransac_samples, device_seed=dseed, run=h, **extra)
-            else:
-                A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
-                                    ransac_samples, samples=sets[h], **extra)
-            A_h.append(nat.to_dev(A, dev=mov.device))
-            inliers[h] = k
-        h_best = int(np.argmax(inliers))             # first maximum (_dock_widget.py:683-703)
-        if can_defer and deferred[h_best]:
-            A_h[h_best] = be.refit_winner(deferred[h_best])
-        A_sc = A_h[h_best]
-        t0 = mark("gpu_ransac", t0)
-        if details is not None:
-            details.update(lsa=lsa, ransac_A=torch.stack(A_h).cpu().numpy())
-        if guards:
-            # neighbours (of this rank's rows) whose bin the tested accuracy of the mean distance / PCA axis does not settle:
-            # 0 everywhere = the integer histograms are the reference's by construction for this call (DESIGN.md §5)
-            gm, gf = (g.cpu().numpy() for g in guards[:2])
-            guard = {"moving": {"ring": int(gm[0]), "sector": int(gm[1])}, "fixed": {"ring": int(gf[0]), "sector": int(gf[1])}}
-            if details is not None:
-                details["edge_guard"] = guard
-            if int(gm.sum()) + int(gf.sum()) > 0:
-                import warnings
-                warnings.warn("estimate_transform: %d neighbour relations of the moving cloud and %d of the fixed cloud lie on a bin "
-                              "boundary of the shape context (ring radius, sector plane, polar cone, or a duplicate of the queried "
-                              "nucleus) to within the rounding noise of the reference's own np.linalg.inv (shape_context.py:61-84): "
-                              "the reference bins them as its LAPACK build happens to round, so its histograms — and what follows "
-                              "from them — are not reproducible for this input (lattice / voxel coordinates, planar clouds, "
-                              "duplicates); details['edge_guard'] has the counts" % (int(gm.sum()), int(gf.sum())),
-                              EdgeGuardWarning, stacklevel=2)
-    elif mode == 'supervised':
-        if keypoints is None:
-            raise ValueError("supervised mode needs keypoints=(moving_keypoints, fixed_keypoints)")
-        A_sc = be.fit(keypoints[0], keypoints[1], transform)
+def correspondences_one_gpu(be, mov, fix, sc_m, sc_f, bn, mode, opts, a_info, mark=None):
+    """The eight assignments (_dock_widget.py:547-611) on one GPU from the descriptors -> list of (row_ind, col_ind).
+    mode: resolve_cost_mode's answer (already 'exact' where the frames do not permute)."""
+    import torch
+    from . import lsap
+    n, m = mov.shape[1], fix.shape[1]
+    on_gpu = bool(getattr(mov, "is_cuda", False))
+    full = cost_bytes(sc_m.shape[1], n, m, 1)
+    if mode == 'filter':
+        f_bytes, x_bytes = filter_bytes(n, m)
+        need = f_bytes + x_bytes
     else:
-        raise ValueError("mode must be 'unsupervised' or 'supervised'")
+        f_bytes, need = 0.0, full
+    streamed = _decide_streamed(be, need, opts, None, mov.device)
+    lease = None
+    U = relaxed_delta = None
+    try:
+        if not streamed:
+            want = f_bytes if mode == 'filter' else 64.0 * n * m           # (bytes actually written into the kept buffer)
+            if opts.keep_cost_buffer and on_gpu and want >= COST_CACHE_MIN_BYTES:
+                lease = cost_buffer(mov.device, (int(want) // 8,))           # None: another registration holds it
+            if mode == 'filter':
+                # the filter matrices with the SHORT side as rows (N > M: the descriptors' roles swapped — the terms are symmetric
+                # and every pairing's bin map is an involution, so that is the transposed filter to within its bound), carved
+                # out of the kept buffer when there is one
+                fshape = (4, min(n, m), max(n, m))
+                fout = None if lease is None else lease.view.view(_filter_dtype())[:4 * n * m].view(fshape)
+                a_, b_ = (sc_m[0], sc_f[0]) if n <= m else (sc_f[0], sc_m[0])
+                U = be.chi2_filter4(a_, b_, out=fout, dtype=_filter_dtype())
+            else:
+                out8 = None if lease is None else lease.view[:8 * n * m].view(8, n, m)
+                if mode == 'relaxed':
+                    U, relaxed_delta = be.chi2_cost8_relaxed(sc_m, sc_f, out=out8)
+                else:
+                    U = be.chi2_cost8(sc_m, sc_f, out=out8)
+        if mark is not None:
+            mark("gpu_descriptors_costs")
+        if mode == 'filter':
+            sc_m1, sc_f1 = sc_m[0], sc_f[0]
+
+            def entries_np(t):
+                return lambda rows, cols: tuple(x.cpu().numpy() for x in be.chi2_entries(sc_m1, sc_f1, t, rows, cols))
+
+            def entries_t(t):              # (index lists from the library's own kernels: no range check, no read-back)
+                return lambda rows, cols: be.chi2_entries(sc_m1, sc_f1, t, rows, cols, trusted=True)
+
+            def build_pairing(t, out):     # streamed: one pairing's filter matrix, the short side as its rows
+                return be.chi2_filter_pair(sc_m1, sc_f1, t, out=out) if n <= m else be.chi2_filter_pair(sc_f1, sc_m1, t, out=out)
+            in_flight = 4
+            if streamed:
+                in_flight = max(1, min(4, int(0.85 * be.free_bytes() // (f_bytes / 4.0))))
+            lsa = lsap.solve_four_filtered(U, entries_np, entries_t, be.chi2_filter_delta() + 1e-13,
+                                           lambda t: be.chi2_cost_pair(sc_m, sc_f, t), info=a_info, accept_near_ties=opts.accept_near_ties,
+                                           build=build_pairing, shape=(n, m), device=mov.device, in_flight=in_flight, storage=_filter_dtype())
+            if a_info is not None and streamed:
+                a_info["mode"] = "streamed: %d filter matri%s resident at a time" % (in_flight, "x" if in_flight == 1 else "ces")
+        elif streamed:
+            lsa = assign_streamed(be, sc_m, sc_f, bn, None, info=a_info, local_matrix=getattr(be, "local_matrix", None),
+                                  accept_near_ties=opts.accept_near_ties)
+        elif mode == 'relaxed':
+            sc_m1, sc_f1 = sc_m[0], sc_f[0]
+            pairing_of = {p[0]: t for t, p in enumerate(PAIRINGS)}
+
+            def exact_entries(h):
+                # (rows, cols) -> the listed entries of hypothesis h's exact matrix and of its twin's (pm_chi2_entries_sym)
+                def fetch(rows, cols):
+                    return tuple(x.cpu().numpy() for x in be.chi2_entries(sc_m1, sc_f1, pairing_of[h], rows, cols))
+                return fetch
+            lsa = lsap.solve_eight_on_device(U, info=a_info, accept_near_ties=opts.accept_near_ties,
+                                             exact_entries=exact_entries if RELAXED_CERTIFY_ON_EXACT_ENTRIES else None, cost_delta=relaxed_delta,
+                                             min_eps=2.0 * min(n, m) * relaxed_delta,
+                                             exact_rebuild=lambda h: be.chi2_cost_pair_into(sc_m1, sc_f1, pairing_of[h], U))
+        else:
+            lsa = assign(U, bn, None, info=a_info, local_matrix=getattr(be, "local_matrix", None), accept_near_ties=opts.accept_near_ties)
+        if any(a is None for a in lsa):
+            raise RuntimeError("a hypothesis could not be assigned (see Options.accept_near_ties)")
+        return lsa
+    finally:
+        del U
+        if lease is not None:
+            if on_gpu:
+                torch.cuda.current_stream(mov.device).synchronize()     # the assignment's last passes have read the buffer
+            lease.release()
+
+
+def correspondences_sharded(be, mov, fix, sc_m, sc_f, bn, mode, opts, group, a_info, mark=None):
+    """The eight assignments with the moving rows (and the cost rows) sharded over the group's ranks -> the same list on every
+    rank.  Nothing of a cost matrix travels unless a hypothesis must go to the dense solver (assign)."""
+    rank, world = _world(group)
+    n, m = mov.shape[1], fix.shape[1]
+    lm = getattr(be, "local_matrix", None)
+    if mode == 'filter':
+        rows_short = (bn[rank + 1] - bn[rank]) if n <= m else (shard_bounds(m, world)[rank + 1] - shard_bounds(m, world)[rank])
+        f_bytes, x_bytes = filter_bytes(n, m, rows_short)
+        streamed = _decide_streamed(be, f_bytes + x_bytes, opts, group, mov.device)
+        if mark is not None:
+            mark("gpu_descriptors_costs")
+        return assign_sharded_filtered(be, sc_m, sc_f, bn, group, streamed=streamed, info=a_info, local_matrix=lm,
+                                       accept_near_ties=opts.accept_near_ties)
+    need = cost_bytes(sc_m.shape[1], n, m, world)
+    streamed = _decide_streamed(be, need, opts, group, mov.device)
+    U = None if streamed else be.chi2_cost8(sc_m, sc_f)
+    if mark is not None:
+        mark("gpu_descriptors_costs")
+    if streamed:
+        return assign_streamed(be, sc_m, sc_f, bn, group, info=a_info, local_matrix=lm, accept_near_ties=opts.accept_near_ties)
+    return assign(U, bn, group, info=a_info, local_matrix=lm, accept_near_ties=opts.accept_near_ties)
+
+
+def assign_sharded_filtered(be, sc_m, sc_f, bounds, group, streamed=False, info=None, local_matrix=None, accept_near_ties=False):
+    """cost_mode 'auto' / 'filter' on several ranks.  Every rank builds ITS ROW BLOCK of the four float32 filter
+    matrices (pm_chi2_filter4_f32 on its rows of the short side's frame-1 descriptors against all of the long side's: 16 bytes per
+    row and column, a quarter of the exact block) and answers the root solver's selection queries from it
+    (lsap_sharded.solve_pair_sharded_filtered); every COST the solver or the certificate uses is evaluated exactly on the root,
+    which holds both clouds' frame-1 descriptors (the moving ones are all-gathered: 2 880 N bytes, 144 MB at 50 000 — the only
+    exchange beside the queries' answers).  A pairing that cannot be proven there (ties, near-ties) has its two exact matrices
+    built in row blocks and goes the exact mode's sharded way (assign_streamed on that pairing alone).
+    N > M: the short side is the fixed cloud — its rows are sharded instead, the filter is built with the roles swapped.
+    streamed: one pairing's filter block at a time (pm_chi2_filter_pair) in a reused buffer.
+    -> list of eight (row_ind, col_ind), identical on every rank."""
+    from . import lsap
+    from .lsap_sharded import solve_pair_sharded_filtered
+    rank, world = _world(group)
+    n, m = bounds[-1], sc_f.shape[1]
+    lm = local_matrix or lsap.DeviceMatrix
+    sc_f1 = sc_f[0]
+    sc_m1_full = all_gather_rows(sc_m[:1].contiguous(), bounds, 1, group)[0]           # [N, 360] on every rank
+    if n <= m:
+        rb, a_loc, b_all = bounds, sc_m[0], sc_f1
+    else:
+        rb = shard_bounds(m, world)
+        a_loc, b_all = sc_f1[rb[rank]:rb[rank + 1]].contiguous(), sc_m1_full
+    delta = be.chi2_filter_delta() + 1e-13
+    F4 = None if streamed else be.chi2_filter4(a_loc, b_all, dtype=_filter_dtype())
+    buf = None
+    out, routes, details = [None] * 8, [None] * 8, [dict() for _ in range(8)]
+    fallback = []
+    for t, (h, twin) in enumerate(PAIRINGS):
+        if F4 is not None:
+            Ft = F4[t]
+        else:
+            Ft = buf = be.chi2_filter_pair(a_loc, b_all, t, out=buf, dtype=_filter_dtype())
+
+        def fetch(rows, cols, t=t):         # (root only) exact entries of the SHORT-side-by-long-side problem the solver sees
+            r, c = (rows, cols) if n <= m else (cols, rows)
+            return tuple(np.asarray(x.cpu().numpy() if nat.is_torch(x) else x, dtype=np.float64) for x in be.chi2_entries(sc_m1_full, sc_f1, t, r, c))
+        pinfo = {}
+        c_h, c_t = solve_pair_sharded_filtered(lm(Ft), fetch, delta, rb, max(n, m), group, t % world, pinfo)
+        if c_h is None or c_t is None:
+            fallback.append(t)
+            continue
+        out[h], out[twin] = lsap._answer(np.asarray(c_h), n, m), lsap._answer(np.asarray(c_t), n, m)
+        routes[h], routes[twin] = "sharded device (filter)", "sharded device (filter; sibling's duals certified)"
+        for k in (h, twin):
+            details[k].update(pinfo if k == h else pinfo.get("twin", {}))
+            details[k]["cost_mode"] = "filter (row blocks of the approximate matrix as selector, exact costs on the listed entries)"
+    del F4, buf
+    if fallback:
+        finfo = {}
+        got = assign_streamed(be, sc_m, sc_f, bounds, group, info=finfo, local_matrix=local_matrix, accept_near_ties=accept_near_ties,
+                              pairings=tuple(fallback))
+        for t in fallback:
+            for k in PAIRINGS[t]:
+                out[k], routes[k] = got[k], finfo["routes"][k]
+                details[k]["cost_mode"] = "exact (built: the filtered solve did not certify)"
+    if info is not None:
+        info["routes"], info["details"] = routes, details
+        info["mode"] = "sharded filter: %s" % ("one pairing's row block resident at a time" if streamed else "four row blocks resident")
+    return out
+
+
+def assignments(moving, fixed, *, cost_mode='auto', group=None, options=None, details=None):
+    """Stages 526-611 of the widget alone: statistics, descriptors, the cost build `cost_mode` starts from and the eight
+    linear_sum_assignment results -> list of eight (row_ind, col_ind) in widget order (11 ... 24), on every rank."""
+    opts = Options.of(options)
+    be = opts.backend or GpuBackend()
+    mov, fix = be.cloud(moving), be.cloud(fixed)
+    info = None if details is None else details.setdefault("assignment", {})
+    return _correspondences(be, mov, fix, moving, fixed, cost_mode, opts, group, info, details)
+
+
+def _correspondences(be, mov, fix, moving, fixed, cost_mode, opts, group, a_info, details, mark=None):
+    rank, world = _world(group)
+    gpu = bool(getattr(be, "device_sampler", False))
+    guards = [] if gpu else None          # (the GPU backend: its descriptor launches count the neighbours on bin boundaries)
+    views = (None, None)
+    if gpu:
+        from .estimate_transform.shape_context import pca_view
+        views = (pca_view(moving), pca_view(fixed))       # what the reference would hand to sklearn: the caller's own arrays
+    mode = resolve_cost_mode(cost_mode, mov.shape[1], fix.shape[1], world, be)
+    sc_m, sc_f, bn = build_descriptors(be, mov, fix, group, guards=guards, views=views)
+    if mode != 'exact':
+        # the cheaper builds derive frames 2..4 from frame 1: only where that relation holds bit for bit (sharded: every rank has
+        # verified its rows and the verdicts are max-reduced — frame 1 alone travelled)
+        ok = (sc_f.shape[0] == 1) if world > 1 else bool(be.chi2_symmetric(sc_m, sc_f))
+        if not ok:
+            mode = 'exact'
+    if a_info is not None:
+        a_info["cost_mode"] = mode
+    try:
+        if world == 1:
+            lsa = correspondences_one_gpu(be, mov, fix, sc_m, sc_f, bn, mode, opts, a_info, mark)
+        else:
+            lsa = correspondences_sharded(be, mov, fix, sc_m, sc_f, bn, mode, opts, group, a_info, mark)
+    finally:
+        del sc_m, sc_f
+    if guards:
+        _report_edge_guard(guards, details)
+    return lsa
+
+
+def _report_edge_guard(guards, details):
+    """Neighbours (of this rank's rows) whose bin the reference itself decides by the rounding noise of its linear algebra: 0
+    everywhere = the integer histograms are the reference's by construction for this call."""
+    gm, gf = (g.cpu().numpy() for g in guards[:2])
+    guard = {"moving": {"ring": int(gm[0]), "sector": int(gm[1])}, "fixed": {"ring": int(gf[0]), "sector": int(gf[1])}}
+    if details is not None:
+        details["edge_guard"] = guard
+    if int(gm.sum()) + int(gf.sum()) > 0:
+        import warnings
+        warnings.warn("estimate_transform: %d neighbour relations of the moving cloud and %d of the fixed cloud lie on a bin "
+                      "boundary of the shape context (ring radius, sector plane, polar cone, or a duplicate of the queried "
+                      "nucleus) to within the rounding noise of the reference's own np.linalg.inv (shape_context.py:61-84): "
+                      "the reference bins them as its LAPACK build happens to round, so its histograms, the eight assignment "
+                      "vectors and the inlier counts are not reproducible for this input (lattice / voxel coordinates, planar "
+                      "clouds, duplicates).  What this call returns is self-consistent (the direct projection's histograms, "
+                      "their exact costs and optimal assignments) and the final 4 x 4 normally agrees with the reference's to "
+                      "ICP's tolerance — it is refitted on nearest neighbours, not on the descriptors; details['edge_guard'] "
+                      "has the counts" % (int(gm.sum()), int(gf.sum())), EdgeGuardWarning, stacklevel=4)
+
+
+def _ransac_stage(be, mov, fix, lsa, sets, on_device, transform, ransac_samples, ransac_trials, ransac_error, seed, group, details):
+    """The eight do_ransac runs and the arg-max of their inlier counts (_dock_widget.py:622-703) -> (A_sc, inliers [8])."""
+    import torch
+    inliers = np.zeros(8, dtype=np.int64)
+    A_h = []
+    if on_device:
+        dseed = (int(seed) & ((1 << 64) - 1)) if seed is not None else _shared_device_seed(group, mov.device)
+    # 'Affine': a run's winner is the device's fit of its sample; the hypothesis the registration goes on with gets the
+    # reference's own expression on the host afterwards (one read-back instead of eight; the other seven only appear in
+    # details["ransac_A"], equal to the reference's to ~1e-12)
+    can_defer = transform == 'Affine' and hasattr(be, "refit_winner")
+    deferred = [dict() for _ in range(8)]
+    pre = [None] * 8
+    if (on_device and transform == 'Affine' and int(ransac_samples) >= 4 and int(ransac_trials) > 0 and hasattr(be, "ransac_prelaunch")
+            and all(len(r) >= int(ransac_samples) for r, _ in lsa)):
+        # all eight hypotheses' fused draw + fit + score launches go out back to back; results are read afterwards
+        pre = [be.ransac_prelaunch(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, ransac_samples, dseed, h)
+               for h, (r, c) in enumerate(lsa)]
+    for h, (r, c) in enumerate(lsa):
+        extra = {"defer": deferred[h]} if can_defer else {}
+        if pre[h] is not None:
+            extra["prelaunched"] = pre[h]
+        if on_device:                            # stream h of the registration's seed: the eight runs draw independent sets
+            A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
+                                ransac_samples, device_seed=dseed, run=h, **extra)
+        else:
+            A, k = be.do_ransac(mov, fix, r.astype(np.int32), c.astype(np.int32), ransac_trials, ransac_error, transform,
+                                ransac_samples, samples=sets[h], **extra)
+        A_h.append(nat.to_dev(A, dev=mov.device))
+        inliers[h] = k
+    h_best = int(np.argmax(inliers))             # first maximum (_dock_widget.py:683-703)
+    if can_defer and deferred[h_best]:
+        A_h[h_best] = be.refit_winner(deferred[h_best])
+    if details is not None:
+        details.update(lsa=lsa, ransac_A=torch.stack(A_h).cpu().numpy())
+    return A_h[h_best], inliers
+
+
+def _icp_stage(be, mov, fix, moving, A_sc, transform, icp_iterations, opts, group, details):
+    """apply_affine_transform + perform_icp (_dock_widget.py:714-717) -> A_icp."""
+    _, world = _world(group)
     if transform == 'Similar':
         # this mode's chain is reproduced only by the reference's own NumPy calls (find_transform.similar_transform_host)
         from .estimate_transform.find_transform import apply_affine_host
@@ -1053,24 +1195,105 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
         moved = apply_affine_host(np.ascontiguousarray(mov_h[:3]), A_sc.cpu().numpy() if nat.is_torch(A_sc) else np.asarray(A_sc))
     else:
         moved = be.apply_affine(A_sc, mov)                                          # :714
-    sharded_icp_done = False
-    if world > 1 and transform == 'Affine' and mov.shape[1] >= icp_shard_min_points:
+    if world > 1 and transform == 'Affine' and mov.shape[1] >= opts.icp_shard_min_points:
         try:
             A_icp, res = icp_sharded(be, moved, fix, int(icp_iterations), group)
-            sharded_icp_done = True
             if details is not None:
                 details['residuals'] = res.cpu().numpy()
+            return A_icp
         except PlanarCloud:
             pass                     # (every rank arrives here together) -> the replicated loop below, which has the host's pinv fits
-    if not sharded_icp_done:
-        log = {} if details is not None else None
-        if icp_one_launch is None:
-            A_icp = be.icp(moved, fix, int(icp_iterations), transform, log)         # :715-717
-        else:
-            A_icp = be.icp(moved, fix, int(icp_iterations), transform, log, one_launch=icp_one_launch)
-        if details is not None:
-            details.update(residuals=log['residuals'], nn=log['nn'])
-    t0 = mark("gpu_icp", t0)
+    log = {} if details is not None else None
+    if opts.icp_one_launch is None:
+        A_icp = be.icp(moved, fix, int(icp_iterations), transform, log)             # :715-717
+    else:
+        A_icp = be.icp(moved, fix, int(icp_iterations), transform, log, one_launch=opts.icp_one_launch)
+    if details is not None:
+        details.update(residuals=log['residuals'], nn=log['nn'])
+    return A_icp
+
+
+def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised', ransac_samples=4, ransac_trials=8000,
+                       ransac_error=16, icp_iterations=50, keypoints=None, seed=None, details=None, cost_mode='auto', group=None,
+                       options=None):
+    """Reproduces _dock_widget.py:526-718 -> (A_sc, A_icp, inliers[8]); final transform = A_icp @ A_sc (:428).
+
+    moving, fixed   3 x N / 3 x M (rows z, y, x; a 4th row is dropped), NumPy or torch; float64 is the reference's arithmetic —
+                    other dtypes are widened on the way in
+    transform       'Affine' | 'Similar'
+    mode            'unsupervised' (shape context + Hungarian + RANSAC) or 'supervised'
+                    (keypoints=(kp_moving, kp_fixed), 3 x k each; _dock_widget.py:707-711)
+    ransac_samples, ransac_trials, ransac_error, icp_iterations   the widget's spin boxes.  ransac_error: 16 for CSV detections
+                    (_dock_widget.py:613-614); with nucleus sizes the widget uses 0.5 * (mean(size_m)**(1/3) + mean(size_f)**(1/3))
+    seed            if not None, np.random.seed(seed) right before the eight RANSAC runs (the reference's seeded result, bit for bit)
+    details         optional dict filled with intermediate results: lsa, ransac_A, residuals, nn, assignment (cost_mode started
+                    from, route and counters per hypothesis), edge_guard (how many neighbours lie so close to a ring radius
+                    ("ring") or to a sector plane / polar cone ("sector") — or coincide with the queried point — that the
+                    reference itself would bin them by the rounding noise of its linear algebra; all zero = the integer
+                    histograms are the reference's by construction for this call); details={"timing": True} on
+                    entry adds a wall-clock split (and stream synchronisations)
+    cost_mode       how the eight assignments are obtained — ALWAYS the vectors scipy.optimize.linear_sum_assignment returns on
+                    the exact cost matrices.  'auto' (default): without building those matrices where that can be proven
+                    (resolve_cost_mode: float32 filter matrices from 8 192 points, relaxed float64 from 1 024, exact below; a
+                    pairing that cannot be proven — ties, near-ties — has its exact matrices built); 'exact': the eight exact
+                    matrices always; 'relaxed' / 'filter': start from that build
+    group           torch.distributed process group to shard over (None = this GPU only); every rank passes the same clouds
+                    and gets the same results
+    options         pipeline.Options (or a dict of its fields): backend, sampler, private_rng, accept_near_ties,
+                    stream_hypotheses, keep_cost_buffer, icp_shard_min_points, icp_one_launch
+    """
+    import time
+    import torch
+    opts = Options.of(options)
+    be = opts.backend or GpuBackend()
+    if opts.backend is None:
+        from . import self_check
+        self_check()                          # once per process: does this host's NumPy / BLAS round as the kernels restate it?
+    if opts.sampler not in ('auto', 'numpy', 'device'):
+        raise ValueError("sampler must be 'auto', 'numpy' or 'device'")
+    if cost_mode not in COST_MODES:
+        raise ValueError("cost_mode must be one of %s" % (COST_MODES,))
+    mov, fix = be.cloud(moving), be.cloud(fixed)
+    inliers = np.zeros(8, dtype=np.int64)
+    timing = {} if (details is not None and details.get("timing")) else None     # details={"timing": True}: wall-clock split
+    clock = [time.perf_counter()]
+
+    def mark(name):
+        if timing is not None:
+            if mov.is_cuda:
+                torch.cuda.current_stream(mov.device).synchronize()
+            timing[name] = timing.get(name, 0.0) + time.perf_counter() - clock[0]
+        clock[0] = time.perf_counter()
+
+    if mode == 'unsupervised':
+        on_device = (opts.sampler == 'device' or (opts.sampler == 'auto' and seed is None)) and getattr(be, "device_sampler", False) \
+            and int(ransac_samples) <= min(mov.shape[1], fix.shape[1])
+        # what do_ransac draws depends only on the number of matched pairs: start drawing before the GPU has built anything
+        # (device sampler: nothing to draw ahead — each trial's set is drawn in front of its fit)
+        draws = _SampleDraws(be, min(mov.shape[1], fix.shape[1]), int(ransac_samples), 0 if on_device else int(ransac_trials),
+                             seed, opts.private_rng)
+        a_info = None if details is None else details.setdefault("assignment", {})
+        try:
+            lsa = _correspondences(be, mov, fix, moving, fixed, cost_mode, opts, group, a_info, details, mark)
+        except BaseException:
+            draws.thread.join()
+            raise
+        mark("host_assignment")
+        sets = draws.result()                    # every rank draws the same 8 x trials: same RNG stream everywhere
+        mark("host_draws_exposed")
+        if timing is not None:
+            timing["host_draws_thread"] = draws.seconds
+        A_sc, inliers = _ransac_stage(be, mov, fix, lsa, sets, on_device, transform, ransac_samples, ransac_trials, ransac_error, seed,
+                                      group, details)
+        mark("gpu_ransac")
+    elif mode == 'supervised':
+        if keypoints is None:
+            raise ValueError("supervised mode needs keypoints=(moving_keypoints, fixed_keypoints)")
+        A_sc = be.fit(keypoints[0], keypoints[1], transform)
+    else:
+        raise ValueError("mode must be 'unsupervised' or 'supervised'")
+    A_icp = _icp_stage(be, mov, fix, moving, A_sc, transform, icp_iterations, opts, group, details)
+    mark("gpu_icp")
     if timing is not None:
         details["timing"] = timing
     if nat.is_torch(moving):
@@ -1106,7 +1329,11 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
     """This process's share of a batch: pairs ks on `workers` host threads, one HIP stream each."""
     import torch
     from concurrent.futures import ThreadPoolExecutor
-    be = kwargs.get("backend")
+    kwargs = dict(kwargs)
+    given = kwargs.pop("options", None)
+    opts = dataclasses.replace(Options.of(given), private_rng=True)
+    stated = set(given) if isinstance(given, dict) else {f.name for f in dataclasses.fields(Options) if getattr(opts, f.name) != f.default}
+    be = opts.backend
     on_gpu = be is None or getattr(be, "device", None) is None or torch.device(be.device).type == "cuda"
     if on_gpu:
         dev = nat.device(None if be is None else be.device)
@@ -1138,7 +1365,7 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
     def one(k):
         det = {"timing": True} if timings is not None else ({} if reports is not None else None)
         if not on_gpu:                       # a caller-supplied host backend (tests): no stream to set
-            out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, details=det, **kwargs)
+            out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], details=det, options=opts, **kwargs)
         else:
             want = min(need(k), budget)
             with gate:
@@ -1148,7 +1375,7 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
             try:
                 stream = nat.side_stream(dev, ("batch worker", worker_slot()))   # persistent per worker thread
                 with torch.cuda.device(dev), torch.cuda.stream(stream):
-                    out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], private_rng=True, details=det, **kwargs)
+                    out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], details=det, options=opts, **kwargs)
                     stream.synchronize()
             finally:
                 with gate:
@@ -1161,10 +1388,10 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
                           "cost_modes": [d.get("cost_mode") for d in det.get("assignment", {}).get("details", [])]}
         return out
 
-    if on_gpu and workers > 1 and len(ks) > 1 and "icp_one_launch" not in kwargs:
-        kwargs = dict(kwargs, icp_one_launch=False)       # several streams in flight: no persistent grid (perform_icp.ONE_LAUNCH)
-    if on_gpu and workers > 1 and len(ks) > 1 and "keep_cost_buffer" not in kwargs:
-        kwargs = dict(kwargs, keep_cost_buffer=False)     # (a buffer kept per worker stream would pin memory the HBM gate counts as free)
+    if on_gpu and workers > 1 and len(ks) > 1 and "icp_one_launch" not in stated:
+        opts = dataclasses.replace(opts, icp_one_launch=False)       # several streams in flight: no persistent grid (perform_icp.ONE_LAUNCH)
+    if on_gpu and workers > 1 and len(ks) > 1 and "keep_cost_buffer" not in stated:
+        opts = dataclasses.replace(opts, keep_cost_buffer=False)     # (a buffer kept per worker stream would pin memory the HBM gate counts as free)
     # largest first: the long Hungarian solves start early and the short pairs fill the gaps at the end
     cost = batch_costs([_pair_size(pairs[k]) for k in ks])
     order = [ks[i] for i in sorted(range(len(ks)), key=lambda i: (-cost[i], ks[i]))]
@@ -1213,7 +1440,7 @@ def estimate_transform_batch(pairs, workers=8, seeds=None, group=None, timings=N
         res = _run_local(pairs, mine, workers, seeds, kwargs, timings, reports)
     except Exception as e:                     # keep the collective below matched on every rank, then raise everywhere
         failure, res = e, {}
-    be = kwargs.get("backend")
+    be = Options.of(kwargs.get("options")).backend
     on_host = dist.get_backend(group) == "gloo"
     dev = torch.device("cpu") if on_host else (nat.device(None if be is None else be.device))
     table = torch.zeros((len(pairs) + 1, 40), dtype=torch.float64, device=dev)

@@ -8,7 +8,7 @@
 int pmt_bin_index(const double *nb, int n, double mean_dist, int32_t *out) {
     for (int i = 0; i < n; ++i) {
         double x = nb[3 * i], y = nb[3 * i + 1], z = nb[3 * i + 2];
-        double r_ = sqrt((x * x + y * y) + z * z);
+        double r_ = sqrt(fma(z, z, fma(y, y, x * x)));     /* the neighbour-list kernels' form: np.linalg.norm's fused chain (shape_context.py:29) */
         out[i] = pm_bin_index(x, y, z, r_, r_ / mean_dist);
     }
     return 0;

@@ -36,7 +36,7 @@ for rd in range(rounds):
             batch_exc = e
         for k, (mv, fx) in enumerate(pairs):
             try:
-                alone = P.estimate_transform(mv, fx, seed=seeds[k], private_rng=True, **kw)
+                alone = P.estimate_transform(mv, fx, seed=seeds[k], options={"private_rng": True}, **kw)
             except Exception as e:
                 alone = e
             outcomes.append(alone)

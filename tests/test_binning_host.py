@@ -29,9 +29,9 @@ def prod_bin(lib, nb, md):
     return out
 
 
-def oracle_bin(oracle, nb, md):
+def oracle_bin(oracle, nb, md, projected=False):
     with np.errstate(all="ignore"):
-        v = oracle.get_bin_index_direct(nb, md)
+        v = oracle.get_bin_index_direct(nb, md, projected=projected)
         ok = (v >= 0) & (v < 360) & (v == np.floor(v))
         return np.where(ok, np.nan_to_num(v, nan=-1), -1).astype(np.int32)
 
@@ -100,7 +100,8 @@ def prod_bin4(lib, nb, md, nframes=4):
 
 
 def oracle_bin4(oracle, nb, md):
-    return np.stack([oracle_bin(oracle, nb * np.array([sx, sy, 1.0]), md) for sx, sy in SIGNS], axis=1)
+    # (the descriptor kernels' step works on directly projected neighbours, as the oracle's shape_context_counts does)
+    return np.stack([oracle_bin(oracle, nb * np.array([sx, sy, 1.0]), md, projected=True) for sx, sy in SIGNS], axis=1)
 
 
 def test_four_frame_step_random_and_edges(host_lib, oracle, micro):

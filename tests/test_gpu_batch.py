@@ -88,7 +88,7 @@ def test_config5_at_its_stated_size_64_pairs_of_2k_to_20k(pairs):
     reports = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = P.estimate_transform_batch(batch, workers=8, seeds=seeds, reports=reports, **kw)
+    out = P.estimate_transform_batch(batch, workers=8, seeds=seeds, reports=reports, cost_mode='exact', **kw)
     torch.cuda.synchronize()
     dt_seeded = time.perf_counter() - t0
     assert sorted(reports) == list(range(64))
@@ -135,32 +135,35 @@ def test_config5_at_its_stated_size_64_pairs_of_2k_to_20k(pairs):
     dt_unseeded = time.perf_counter() - t0
     worst_u = max(np.linalg.norm(o[1] @ o[0] - A) / np.linalg.norm(A) for o, A in zip(out_u, truth))
     assert worst_u < 2e-3
-    # the opt-in relaxed cost build (solved on relaxed matrices, certified on the exact matrices' listed entries): the same batch,
-    # seeded as above — every result identical to the exact mode's, bit for bit
+    # THE DEFAULT, cost_mode='auto' (pairs below 8 192 nuclei: solved on relaxed matrices; from 8 192: through the float32 filter;
+    # both certified on the exact matrices' listed entries): the same batch, seeded as above — every result identical to the exact
+    # mode's, bit for bit
     reports_r = {}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out_r = P.estimate_transform_batch(batch, workers=8, seeds=seeds, reports=reports_r, cost_mode='relaxed', **kw)
+    out_r = P.estimate_transform_batch(batch, workers=8, seeds=seeds, reports=reports_r, **kw)
     torch.cuda.synchronize()
-    dt_relaxed = time.perf_counter() - t0
+    dt_auto = time.perf_counter() - t0
     for k in range(64):
         assert np.array_equal(out_r[k][2], out[k][2]) and np.array_equal(out_r[k][0], out[k][0]) and np.array_equal(out_r[k][1], out[k][1]), k
     modes = [m for k in range(64) for m in reports_r[k]["cost_modes"]]
-    assert len(modes) == 512 and all(m and (m.startswith("relaxed") or m.startswith("exact (rebuilt")) for m in modes)
-    # and the opt-in modes for callers who do not seed (device sampler): results must recover the ground truth as above
-    unseeded_modes = {}
-    for mode in ("relaxed", "filter"):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        out_m = P.estimate_transform_batch(batch, workers=8, cost_mode=mode, **kw)
-        torch.cuda.synchronize()
-        unseeded_modes[mode] = time.perf_counter() - t0
-        assert max(np.linalg.norm(o[1] @ o[0] - A) / np.linalg.norm(A) for o, A in zip(out_m, truth)) < 2e-3
-    print("\nconfig 5 unseeded: cost_mode='relaxed' %.2f s = %.2f registrations/s; cost_mode='filter' %.2f s = %.2f registrations/s"
-          % (unseeded_modes["relaxed"], 64 / unseeded_modes["relaxed"], unseeded_modes["filter"], 64 / unseeded_modes["filter"]))
-    print("\nconfig 5 with cost_mode='relaxed' (seeded): %.2f s = %.2f registrations/s; %d of 512 assignments certified on the relaxed build, "
-          "%d after an exact rebuild; all 64 results identical to the exact mode's"
-          % (dt_relaxed, 64 / dt_relaxed, sum(m.startswith("relaxed") for m in modes), sum(m.startswith("exact") for m in modes)))
+    assert len(modes) == 512 and all(m and (m.startswith("relaxed") or m.startswith("filter") or m.startswith("exact (")) for m in modes)
+    for k in range(64):
+        first = "filter" if sizes[k] >= P.FILTER_MIN_POINTS else "relaxed"
+        assert all(m.startswith(first) or m.startswith("exact (") for m in reports_r[k]["cost_modes"]), (k, sizes[k], reports_r[k]["cost_modes"])
+    # exact costs for callers who do not seed, for the record of what the default buys (device sampler)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out_x = P.estimate_transform_batch(batch, workers=8, cost_mode='exact', **kw)
+    torch.cuda.synchronize()
+    dt_exact_unseeded = time.perf_counter() - t0
+    assert max(np.linalg.norm(o[1] @ o[0] - A) / np.linalg.norm(A) for o, A in zip(out_x, truth)) < 2e-3
+    print("\nconfig 5, default cost_mode='auto' (seeded): %.2f s = %.2f registrations/s; of 512 assignments %d settled on the relaxed build, "
+          "%d through the filter, %d after an exact build; all 64 results identical to cost_mode='exact' (%.2f s = %.2f registrations/s)"
+          % (dt_auto, 64 / dt_auto, sum(m.startswith("relaxed") for m in modes), sum(m.startswith("filter") for m in modes),
+             sum(m.startswith("exact") for m in modes), dt_seeded, 64 / dt_seeded))
+    print("\nconfig 5 unseeded: default %.2f s = %.2f registrations/s; cost_mode='exact' %.2f s = %.2f registrations/s"
+          % (dt_unseeded, 64 / dt_unseeded, dt_exact_unseeded, 64 / dt_exact_unseeded))
     print("\nconfig 5: 64 pairs of %d..%d nuclei on one GPU: seeded (NumPy-stream draws) %.2f s = %.2f registrations/s; unseeded "
           "(device sampler) %.2f s = %.2f registrations/s; worst rel. error vs ground truth %.1e / %.1e; 512 of 512 assignments "
           "device-certified; primal - dual of the largest pair's winner %.1e"
@@ -191,7 +194,7 @@ def test_two_threads_on_one_stream_never_share_a_kept_cost_buffer(monkeypatch):
 
         def run(k):
             try:
-                got[k] = P.estimate_transform(pairs[k][0], pairs[k][1], seed=9 + k, private_rng=True, **kw)
+                got[k] = P.estimate_transform(pairs[k][0], pairs[k][1], seed=9 + k, options={"private_rng": True}, **kw)
             except BaseException as e:
                 errors.append(e)
         th = [threading.Thread(target=run, args=(k,)) for k in range(3)]

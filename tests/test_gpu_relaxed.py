@@ -53,7 +53,7 @@ def test_relaxed_mode_returns_the_exact_modes_registration(g, n, m, seed):
     mv, fx = np.ascontiguousarray(mv[:, :n]), np.ascontiguousarray(fx[:, :m])
     kw = dict(ransac_trials=400, icp_iterations=6, seed=5)
     de, dr = {}, {}
-    a = g.P.estimate_transform(mv, fx, details=de, **kw)
+    a = g.P.estimate_transform(mv, fx, details=de, cost_mode='exact', **kw)
     b = g.P.estimate_transform(mv, fx, details=dr, cost_mode='relaxed', **kw)
     for h in range(8):
         assert np.array_equal(de["lsa"][h][0], dr["lsa"][h][0]) and np.array_equal(de["lsa"][h][1], dr["lsa"][h][1]), h
@@ -159,7 +159,7 @@ def test_tied_clouds_fall_back_to_the_exact_build_and_give_the_exact_modes_answe
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", g.P.EdgeGuardWarning)
-        a = g.P.estimate_transform(mv, fx, details=de, **kw)
+        a = g.P.estimate_transform(mv, fx, details=de, cost_mode='exact', **kw)
         b = g.P.estimate_transform(mv, fx, details=dr, cost_mode='relaxed', **kw)
     for h in range(8):
         assert np.array_equal(de["lsa"][h][0], dr["lsa"][h][0]) and np.array_equal(de["lsa"][h][1], dr["lsa"][h][1]), h
@@ -198,7 +198,7 @@ def test_filter_mode_returns_the_exact_modes_registration(g, n, m, seed, monkeyp
     mv, fx = np.ascontiguousarray(mv[:, :n]), np.ascontiguousarray(fx[:, :m])
     kw = dict(ransac_trials=400, icp_iterations=6, seed=5)
     de, dr = {}, {}
-    a = g.P.estimate_transform(mv, fx, details=de, **kw)
+    a = g.P.estimate_transform(mv, fx, details=de, cost_mode='exact', **kw)
     b = g.P.estimate_transform(mv, fx, details=dr, cost_mode='filter', **kw)
     for h in range(8):
         assert np.array_equal(de["lsa"][h][0], dr["lsa"][h][0]) and np.array_equal(de["lsa"][h][1], dr["lsa"][h][1]), h
@@ -221,7 +221,7 @@ def test_filter_mode_on_tied_clouds_builds_the_pairings_exactly(g, monkeypatch):
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", g.P.EdgeGuardWarning)
-        a = g.P.estimate_transform(mv, fx, details=de, **kw)
+        a = g.P.estimate_transform(mv, fx, details=de, cost_mode='exact', **kw)
         b = g.P.estimate_transform(mv, fx, details=dr, cost_mode='filter', **kw)
     for h in range(8):
         assert np.array_equal(de["lsa"][h][0], dr["lsa"][h][0]) and np.array_equal(de["lsa"][h][1], dr["lsa"][h][1]), h
@@ -248,8 +248,8 @@ def test_streamed_filter_mode_builds_one_pairing_at_a_time_and_returns_the_exact
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", g.P.EdgeGuardWarning)
-        a = g.P.estimate_transform(mv, fx, details=de, **kw)
-        b = g.P.estimate_transform(mv, fx, details=dr, cost_mode='filter', stream_hypotheses=True, **kw)
+        a = g.P.estimate_transform(mv, fx, details=de, cost_mode='exact', **kw)
+        b = g.P.estimate_transform(mv, fx, details=dr, cost_mode='filter', options={"stream_hypotheses": True}, **kw)
     for h in range(8):
         assert np.array_equal(de["lsa"][h][0], dr["lsa"][h][0]) and np.array_equal(de["lsa"][h][1], dr["lsa"][h][1]), h
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

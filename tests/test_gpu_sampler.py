@@ -186,10 +186,10 @@ def test_seeded_calls_keep_the_numpy_stream_and_unseeded_driver_uses_the_device(
     assert np.random.get_state()[2] == state_after            # exactly one 2-word draw was consumed
     # explicit choices
     r_np = P.estimate_transform(d["moving"], d["fixed"], ransac_trials=int(d["ransac_trials"]), ransac_error=float(d["ransac_error"]),
-                                icp_iterations=2, seed=int(d["ransac_seed"]), sampler="numpy")
+                                icp_iterations=2, seed=int(d["ransac_seed"]), options={"sampler": "numpy"})
     assert np.array_equal(r_np[2], d["ransac_inliers"])
     r_dev = [P.estimate_transform(d["moving"], d["fixed"], ransac_trials=500, ransac_error=float(d["ransac_error"]), icp_iterations=2,
-                                  seed=9, sampler="device") for _ in range(2)]
+                                  seed=9, options={"sampler": "device"}) for _ in range(2)]
     assert np.array_equal(r_dev[0][2], r_dev[1][2]) and np.array_equal(r_dev[0][0], r_dev[1][0])
 
 
@@ -226,7 +226,7 @@ def test_a_caller_who_seeds_numpy_itself_gets_the_references_sets_with_sampler_n
     want = P.estimate_transform(mv, fx, seed=1234, **kw)
     state_after_seeded = np.random.get_state()[1].copy()
     np.random.seed(1234)
-    got = P.estimate_transform(mv, fx, seed=None, sampler='numpy', **kw)
+    got = P.estimate_transform(mv, fx, seed=None, options={'sampler': 'numpy'}, **kw)
     assert np.array_equal(got[2], want[2]) and np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     assert np.array_equal(np.random.get_state()[1], state_after_seeded)         # consumed exactly like the seeded call
     np.random.seed(1234)

@@ -149,6 +149,46 @@ class OracleBackend:
         return torch.as_tensor(A), parts
 
 
+def add_filter_double(be, P, spoil_pairing=None):
+    """Give the test double what cost_mode='auto' / 'filter' asks of a backend: four approximate matrices per row block (the exact
+    costs rounded to float32 — within 6e-8, inside the stated bound — as the float32 filter's storage is), the exact entries of
+    listed (row, col) pairs, and a NumPy stand-in for the dense passes over a rank's float32 block.  spoil_pairing: that pairing's
+    filter matrix breaks its bound (off by 1e-3), so its certificate must fail and the exact sharded route must take over."""
+    from test_lsap_core import HostMatrix
+    o = be.o
+    cache = {}
+
+    def exact_pairing(a1, b1, t):            # chi2(a1[i] as frame 1, frame (t + 1) derived from b1[j]) and the twin's rolled order
+        key = (a1.shape, b1.shape, float(a1.sum()), float(b1.sum()), t)
+        if key not in cache:
+            h, twin = P.PAIRINGS[t]
+            fa, fb = OracleBackend._frames_from_first(np.ascontiguousarray(a1)), OracleBackend._frames_from_first(np.ascontiguousarray(b1))
+            nat_ = o.unary_distance_matrix(fa[int(P.HYPOTHESES[h][0]) - 1], fb[int(P.HYPOTHESES[h][1]) - 1])
+            rol = o.unary_distance_matrix(fa[int(P.HYPOTHESES[twin][0]) - 1], fb[int(P.HYPOTHESES[twin][1]) - 1])
+            cache[key] = (nat_, rol)
+        return cache[key]
+
+    def filter_pair(a1, b1, t, out=None, dtype=None):
+        F = exact_pairing(a1.numpy(), b1.numpy(), t)[0].astype(np.float32)
+        if t == spoil_pairing:
+            F = F - np.float32(1e-3) * ((np.arange(F.size).reshape(F.shape) % 7) == 0)      # (too CHEAP: such entries get listed, and the premise check sees them)
+        F = torch.as_tensor(F)
+        if out is not None:
+            out.copy_(F)
+            return out
+        return F
+
+    be.chi2_filter_pair = filter_pair
+    be.chi2_filter4 = lambda a1, b1, out=None, dtype=None: torch.stack([filter_pair(a1, b1, t) for t in range(4)])
+    be.chi2_filter_delta = lambda: 1.1e-6
+    be.chi2_entries = lambda m1, f1, t, rows, cols, trusted=False: tuple(
+        x[np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)] for x in exact_pairing(m1.numpy(), f1.numpy(), t))
+    be.chi2_cost_pair = lambda sc_m, sc_f, t, out=None: torch.stack([be.chi2_cost8(sc_m, sc_f)[k] for k in P.PAIRINGS[t]])
+    be.local_matrix = lambda U2d: HostMatrix(U2d.numpy())
+    P.FILTER_MIN_POINTS = 0
+    P.SHARDED_ASSIGN_MIN_ROWS = 0
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -174,11 +214,13 @@ def _worker(rank, world, port, name, out_path):
             from test_lsap_core import HostMatrix
             P.SHARDED_ASSIGN_MIN_ROWS = 0
             be.local_matrix = lambda U2d: HostMatrix(U2d.numpy())
+        if variant.startswith("sharded_filter"):   # the default cost mode's sharded route: row blocks of the float32 filter, exact entries on the root
+            add_filter_double(be, P, spoil_pairing=2 if variant.endswith("fallback") else None)
         det = {}
         A_sc, A_icp, inl = P.estimate_transform(d["moving"], d["fixed"], ransac_trials=int(d["ransac_trials"]),
                                                 ransac_error=float(d["ransac_error"]), icp_iterations=int(d["icp_iters"]),
-                                                seed=int(d["ransac_seed"]), details=det, group=dist.group.WORLD, backend=be,
-                                                icp_shard_min_points=0)          # force the sharded ICP loop
+                                                seed=int(d["ransac_seed"]), details=det, group=dist.group.WORLD,
+                                                options={"backend": be, "icp_shard_min_points": 0})          # force the sharded ICP loop
         # descriptor gather and cost rows, checked directly too
         mov, fix = be.cloud(d["moving"]), be.cloud(d["fixed"])
         U, bn = P.build_costs(be, mov, fix, dist.group.WORLD)
@@ -187,13 +229,15 @@ def _worker(rank, world, port, name, out_path):
         amin = P.cost_row_argmins(be, mov, fix, 29, dist.group.WORLD)          # streamed in slabs, gathered
         np.savez(out_path % rank, A_sc=np.asarray(A_sc), A_icp=np.asarray(A_icp), inl=inl, residuals=det["residuals"],
                  lsa_cols=np.stack([c for _, c in det["lsa"]]), U=U.numpy(), bounds=np.array(bn), amin=amin.numpy(),
-                 sym=np.array(SYMMETRY_SEEN), routes=np.array(det.get("assignment", {}).get("routes", ["?"] * 8)))
+                 sym=np.array(SYMMETRY_SEEN), routes=np.array(det.get("assignment", {}).get("routes", ["?"] * 8)),
+                 cost_mode=np.array(det.get("assignment", {}).get("cost_mode", "?")))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("name", ["synth96x128", "insitu02_affine", "synth96x128|general", "synth96x128|sharded_lsap",
-                                  "insitu02_affine|sharded_lsap"])
+                                  "insitu02_affine|sharded_lsap", "synth96x128|sharded_filter", "insitu02_affine|sharded_filter",
+                                  "synth96x128|sharded_filter_fallback"])
 def test_two_rank_pipeline_matches_single_process(tmp_path, oracle, name):
     world = 2
     out = str(tmp_path / "rank%d.npz")
@@ -206,6 +250,15 @@ def test_two_rank_pipeline_matches_single_process(tmp_path, oracle, name):
     if variant == "sharded_lsap":            # no matrix was gathered: every hypothesis certified where it lay
         assert all(str(x).startswith("sharded device") for x in r0["routes"]), r0["routes"]
         assert np.array_equal(r0["routes"], r1["routes"])
+    if variant.startswith("sharded_filter"):
+        # the DEFAULT cost mode with a backend that has a filter build: no exact matrix was built for a pairing the filter could
+        # prove; the spoiled pairing (hypotheses 13 and 24) went the exact sharded way — and the answers below are the fixture's
+        assert str(r0["cost_mode"]) == "filter" and np.array_equal(r0["routes"], r1["routes"])
+        through = ["(filter" in str(x) for x in r0["routes"]]
+        assert all(str(x).startswith("sharded device") for x in r0["routes"]), r0["routes"]
+        assert through == ([True] * 8 if variant == "sharded_filter" else [h not in (2, 7) for h in range(8)]), r0["routes"]
+    else:
+        assert str(r0["cost_mode"]) == "exact"
     # every rank returns the same thing
     for k in ("A_sc", "A_icp", "inl", "lsa_cols", "residuals", "amin"):
         assert np.array_equal(r0[k], r1[k]), k
@@ -273,7 +326,7 @@ def _batch_worker(rank, world, port, out_path, poison):
         owner = P.batch_assignment([(p[0].shape[1], p[1].shape[1]) for p in pairs], world)
         try:
             res = P.estimate_transform_batch(pairs, workers=2, seeds=[7 + k for k in range(len(pairs))], group=dist.group.WORLD,
-                                             backend=OracleBackend(), ransac_trials=60, ransac_error=16, icp_iterations=4)
+                                             options={"backend": OracleBackend()}, ransac_trials=60, ransac_error=16, icp_iterations=4)
             np.savez(out_path % rank, owner=np.array(owner), A_sc=np.stack([r[0] for r in res]), A_icp=np.stack([r[1] for r in res]),
                      inl=np.stack([r[2] for r in res]))
         except Exception as e:                               # every rank must get here when one pair fails, none may hang
@@ -461,7 +514,7 @@ def test_a_query_that_fails_on_one_rank_is_raised_on_all_and_leaves_no_rank_behi
     assert np.array_equal(r0["c"], r1["c"]) and np.array_equal(r0["c"], scipy_lsa(r0["A"])[1])
 
 
-def _more_moving_worker(rank, world, port, out_path):
+def _more_moving_worker(rank, world, port, out_path, filtered=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -476,9 +529,11 @@ def _more_moving_worker(rank, world, port, out_path):
         be.chi2_cost_single = lambda a, b: torch.as_tensor(be.o.unary_distance_matrix(a.numpy(), b.numpy()))
         be.local_matrix = lambda U2d: HostMatrix(U2d.numpy())
         P.SHARDED_ASSIGN_MIN_ROWS = 0
+        if filtered:
+            add_filter_double(be, P)
         det = {}
         A_sc, A_icp, inl = P.estimate_transform(mov, fix, ransac_trials=200, ransac_error=8.0, icp_iterations=6, seed=4, details=det,
-                                                group=dist.group.WORLD, backend=be, stream_hypotheses=True)
+                                                group=dist.group.WORLD, options={"backend": be, "stream_hypotheses": True})
         np.savez(out_path % rank, A_sc=np.asarray(A_sc), A_icp=np.asarray(A_icp), inl=inl,
                  rows=np.stack([r for r, _ in det["lsa"]]), cols=np.stack([c for _, c in det["lsa"]]),
                  routes=np.array(det["assignment"]["routes"]))
@@ -486,19 +541,22 @@ def _more_moving_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_streamed_assignment_with_more_moving_than_fixed_points(tmp_path, oracle, world):
+@pytest.mark.parametrize("world,filtered", [(2, False), (3, False), (2, True), (3, True)])
+def test_sharded_streamed_assignment_with_more_moving_than_fixed_points(tmp_path, oracle, world, filtered):
     """VERDICT r02 missing #4: config 4's code path (hypotheses streamed two at a time, rows sharded, nothing gathered) for N > M.
     The solver needs the short side as rows, so the ranks build the TRANSPOSED matrices (chi-square is symmetric bit for bit) on
     blocks of fixed rows.  Assignments must equal SciPy's on the oracle's N x M matrices, on every rank."""
     from scipy.optimize import linear_sum_assignment as scipy_lsa
     out = str(tmp_path / "m%d.npz")
-    mp.spawn(_more_moving_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_more_moving_worker, args=(world, _free_port(), out, filtered), nprocs=world, join=True)
     res = [np.load(out % r) for r in range(world)]
     for r in res[1:]:
         for k in ("A_sc", "A_icp", "inl", "rows", "cols"):
             assert np.array_equal(r[k], res[0][k]), k
-    assert all("transposed" in str(x) for x in res[0]["routes"])
+    if filtered:         # the filter route with the FIXED rows sharded (roles swapped), one pairing's block at a time
+        assert all("(filter" in str(x) for x in res[0]["routes"]), res[0]["routes"]
+    else:
+        assert all("transposed" in str(x) for x in res[0]["routes"])
     d = load_golden("synth96x128")
     mov, fix = d["fixed"], d["moving"]
     odet = {}

@@ -39,8 +39,8 @@ streamed = os.environ.get("PM_STREAM_HYPOTHESES") == "1"       # two cost matric
 ok = True
 for shard_icp in (False, True):
     det = {}
-    got = P.estimate_transform(mv, fx, group=dist.group.WORLD, details=det, icp_shard_min_points=0 if shard_icp else 10 ** 9,
-                               stream_hypotheses=True if streamed else None, **kw)
+    got = P.estimate_transform(mv, fx, group=dist.group.WORLD, details=det, options={"icp_shard_min_points": 0 if shard_icp else 10 ** 9,
+                                                              "stream_hypotheses": True if streamed else None}, **kw)
     if rank == 0:
         ref_det = {}
         ref = P.estimate_transform(mv, fx, details=ref_det, **kw)
