@@ -142,6 +142,95 @@ def pmc_traffic(kernel_substring, n):
     return None, None
 
 
+def shader_clock_during(launch, dev, expected_ms):
+    """The shader clock WHILE `launch` runs (VERDICT r04 next #4b), measured on the product build: one extra wave on a side stream
+    (pm_clock_probe, include/platymatch_hip.h) stores (s_memtime, s_memrealtime) once a millisecond for the length of the launch
+    plus 0.4 s; clock between two samples = d s_memtime / d s_memrealtime x 100 MHz (MI355X_MICROARCH.md's in-kernel clock test).
+    -> dict: median / min / max under load (the middle 80 % of the launch), the idle clock after it, the launch's own duration."""
+    import torch
+    from platymatch_amd import _native as nat
+    n_s = int(min(4900, expected_ms + 400))
+    side = torch.cuda.Stream(dev)
+    samples = torch.zeros(2 * n_s, dtype=torch.int64, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    nat.check(nat.load().pm_clock_probe(samples.data_ptr(), n_s, 100_000, side.cuda_stream))
+    e0.record()
+    launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    st = samples.cpu().numpy().reshape(-1, 2).astype(np.float64)
+    d = np.diff(st, axis=0)
+    ghz = d[:, 0] / np.maximum(d[:, 1], 1.0) * 0.1                    # ticks of the shader clock per 10 ns -> GHz
+    load = ghz[int(0.1 * ms):max(int(0.9 * ms), int(0.1 * ms) + 1)]
+    idle = ghz[int(ms) + 100:]
+    return {"under_load_ghz": {"median": float(np.median(load)), "min": float(load.min()), "max": float(load.max()), "samples": int(load.size)},
+            "after_the_launch_ghz": float(np.median(idle)) if idle.size else None, "launch_ms_with_probe": ms,
+            "method": "pm_clock_probe: one extra wave samples (s_memtime, s_memrealtime) every millisecond beside the product kernel"}
+
+
+def rank_devices(dist, group, dev, world, rank, ident=None):
+    """Which physical device every rank drives (VERDICT r04 next #2a): name | uuid (or PCI ids), all-gathered as bytes."""
+    import torch
+    if ident is None:
+        props = torch.cuda.get_device_properties(dev)
+        ident = "%s | %s" % (props.name, str(getattr(props, "uuid", "")) or "pci %s:%s.%s" % (
+            getattr(props, "pci_domain_id", "?"), getattr(props, "pci_bus_id", "?"), getattr(props, "pci_device_id", "?")))
+    text = ident.encode()[:120]
+    mine = torch.zeros(128, dtype=torch.uint8)
+    mine[:len(text)] = torch.frombuffer(bytearray(text), dtype=torch.uint8)
+    on_host = dist.get_backend(group) == "gloo"
+    mine = mine if on_host else mine.to(dev)
+    everyone = torch.zeros(world * 128, dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(everyone, mine, group=group)
+    names = [bytes(everyone[g * 128:(g + 1) * 128].cpu().tolist()).split(b"\0", 1)[0].decode() for g in range(world)]
+    return {"backend": dist.get_backend(group), "world": world, "distinct_devices": len(set(names)), "devices": names}
+
+
+def preflight(dist, group, dev, world, timeout_s=60.0):
+    """Every collective the step and its extras use, once, on 1-KB tensors, under a watchdog (VERDICT r04 next #2c): a rendezvous
+    or transport problem becomes a clear error within timeout_s instead of a hang inside the timed region."""
+    import threading
+    import torch
+    on_host = dist.get_backend(group) == "gloo"
+    d = torch.device("cpu") if on_host else dev
+    done, err = threading.Event(), []
+
+    def run():
+        try:
+            t = torch.ones(128, dtype=torch.float64, device=d)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)                      # mean-distance piece sums
+            f = torch.zeros(1, dtype=torch.int32, device=d)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX, group=group)                      # symmetry flag, agree_max
+            out = torch.empty(world * 128, dtype=torch.float64, device=d)
+            dist.all_gather_into_tensor(out, t, group=group)                           # descriptor gather
+            dist.broadcast(t, src=0, group=group)                                      # assignment queries
+            whole = [torch.empty_like(t) for _ in range(world)] if dist.get_rank(group) == 0 else None
+            dist.gather(t, whole, dst=0, group=group)                                  # assignment answers
+            dist.barrier(group=group)
+            if not on_host:
+                torch.cuda.synchronize()
+            if float(out.sum()) != 128.0 * world * world:
+                err.append("preflight all-gather returned %r, expected %r" % (float(out.sum()), 128.0 * world * world))
+        except Exception as e:       # noqa: BLE001
+            err.append("%s: %s" % (type(e).__name__, e))
+        finally:
+            done.set()
+
+    th = threading.Thread(target=run, name="pm-bench-preflight", daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    if not done.wait(timeout_s):
+        sys.stderr.write("bench.py rank %d: collective preflight did not finish in %.0f s (backend %s, world %d): check MASTER_ADDR / "
+                         "MASTER_PORT, HSA_ENABLE_IPC_MODE_LEGACY=0, one visible device per rank\n" % (dist.get_rank(group), timeout_s, dist.get_backend(group), world))
+        sys.stderr.flush()
+        os._exit(3)
+    if err:
+        raise SystemExit("bench.py rank %d: collective preflight failed: %s" % (dist.get_rank(group), err[0]))
+    return time.perf_counter() - t0
+
+
 def spawn_ranks(n_ranks, argv):
     """`python bench.py --gpus N` started as ONE process (no WORLD_SIZE in the environment): become the launcher.  N fresh
     children of this same script are started, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
@@ -195,17 +284,21 @@ def dry_run(args):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    ranks = None
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+        pre_s = preflight(dist, dist.group.WORLD, None, world)
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         seen = float(t.item())
+        ranks = rank_devices(dist, dist.group.WORLD, None, world, rank, ident="no device (dry run), rank %d" % rank)
+        ranks["preflight_s"] = pre_s
         dist.barrier()
         dist.destroy_process_group()
     else:
         seen = 1.0
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank_plus_one": seen,
+        print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank_plus_one": seen, "ranks": ranks,
                           "spawned": os.environ.get("PM_BENCH_SPAWNED") == "1", "local_rank": int(os.environ.get("LOCAL_RANK", "0"))}), flush=True)
 
 
@@ -261,6 +354,15 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         group = dist.group.WORLD
+    ranks_record = None
+    if world > 1:
+        pre_s = preflight(dist, group, dev, world)
+        ranks_record = rank_devices(dist, group, dev, world, rank)
+        ranks_record["preflight_s"] = pre_s
+        ranks_record["rehearsal_on_one_device"] = os.environ.get("PM_BENCH_ONE_DEVICE") == "1"
+        if ranks_record["distinct_devices"] != world and not ranks_record["rehearsal_on_one_device"]:
+            raise SystemExit("bench.py: %d ranks drive only %d distinct devices (%s): one GPU per rank is what --gpus N measures "
+                             "(PM_BENCH_ONE_DEVICE=1 is the rehearsal switch)" % (world, ranks_record["distinct_devices"], ranks_record["devices"]))
 
     n = m = args.points
     mv_h, fx_h, start_h = synth(n)
@@ -356,6 +458,29 @@ def main():
     add_floor_s = 8.0 * 360.0 * rows * m / 64.0 / 1024.0 * 4.0 / 2.4e9      # the running-sum adds alone (183 ms at 50k)
     # HBM traffic of that launch: from the committed rocprofv3 PMC passes of this configuration (1 GPU, this N), else null
     traffic, traffic_src = pmc_traffic("chi2_sym_kernel" if sym else "chi2_kernel<", n) if world == 1 else (None, None)
+    traffic_why = None
+    if traffic is None:
+        traffic_why = ("no PMC pass of this configuration is committed: profiles/pmc_traffic.json holds the 1-GPU N = M = 50 000 launch"
+                       + ("; a rank's row block reads the same descriptors and writes rows/%d of the matrices (the launch is linear in "
+                          "its rows, profiles/r04_chi2_blocks.txt)" % world if world > 1 else ""))
+
+    # per-shell maxima of the integer counts behind the descriptors (what decides which shells the 94 x 94 term table can serve)
+    shell_max = None
+    if sym:
+        def shell_maxima(sc1):
+            pos = sc1[sc1 > 0]
+            tot = float(torch.round(1.0 / pos.min())) if pos.numel() else 1.0
+            return torch.round(sc1 * tot).view(-1, 30, 12).amax(dim=(0, 2)).to(torch.int64).cpu().tolist()
+        cm_, cf_ = shell_maxima(sc_m_last[0][0]), shell_maxima(sc_f_last[0][0])
+        per_ring = [[int(min(min(cm_[6 * r:6 * r + 6]), min(cf_[6 * r:6 * r + 6]))), int(max(max(cm_[6 * r:6 * r + 6]), max(cf_[6 * r:6 * r + 6])))]
+                    for r in range(5)]
+        shell_max = {"moving": cm_, "fixed": cf_, "per_ring_min_max_of_the_shell_maxima": per_ring, "table_side": table_info.get("table_size"),
+                     "note": "shell g = 6 x ring + theta sector; a shell is tabled when both clouds' largest count in it is below the table's side"}
+
+    # the shader clock while the cost kernel runs (one GPU; an extra untimed launch with a one-wave probe beside it)
+    clock = None
+    if world == 1 and sym and not args.no_assignment:
+        clock = shader_clock_during(lambda: K.chi2_cost8_frame1(sc_m_last[0][0], sc_f_last[0][0], out=U), dev, chi2_ms)
 
     # the other two stages: their compulsory HBM traffic is O(N) against O(N^2) work, so HBM is not what binds
     sc_bytes = (24.0 * n + 2880.0 * 2 * (r1 - r0)) + (24.0 * m + 2880.0 * 4 * (bm[rank + 1] - bm[rank]))
@@ -401,9 +526,36 @@ def main():
                       "note": "scipy.optimize.linear_sum_assignment's answer for the eight N x M matrices (_dock_widget.py:604-611) by a sparse "
                               "core solved on the host and priced + certified against every entry on the device (DESIGN.md §4.3); not in `value`"}
 
-    # Second extra, OUTSIDE the timed region and never the headline: the relaxed-rounding cost build (opt-in experiment,
-    # pm_chi2_cost8_relaxed / estimate_transform(cost_mode='relaxed'): no bit identity, every entry within delta of the exact one,
-    # used only behind a certificate against the exact matrix's listed entries).  Launch time by HIP events on the launching stream.
+    if world > 1 and not args.no_assignment:
+        # the eight assignments by the DEFAULT route of a sharded registration (cost_mode='auto': row blocks of the float32 filter on
+        # their ranks, the root's queries answered by every rank, exact costs on the root; pipeline.assign_sharded_filtered) — or,
+        # where the frames do not permute, by the exact sharded route on the row blocks of the timed build.  Untimed extra.
+        fence()
+        t_as = time.perf_counter()
+        a_info = {}
+        try:
+            if symmetric[0]:
+                lsa = P.assign_sharded_filtered(be, sc_m_last[0], sc_f_last[0], bn, group, info=a_info)
+            else:
+                lsa = P.assign(U, bn, group, info=a_info)
+            err = None
+        except Exception as e:      # noqa: BLE001 — an extra must not cost the headline line
+            lsa, err = None, "%s: %s" % (type(e).__name__, str(e)[:300])
+        fence()
+        t_as = time.perf_counter() - t_as
+        if world > 1:
+            t = torch.tensor([t_as], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            t_as = float(t.item())
+        assignment = {"seconds": t_as, "route": "sharded filter (cost_mode='auto')" if symmetric[0] else "sharded exact", "error": err,
+                      "routes": a_info.get("routes"), "mode": a_info.get("mode"),
+                      "perfect_matchings": None if lsa is None else [bool(len(set(c.tolist())) == len(c)) for _, c in lsa],
+                      "note": "the protocol of lsap_sharded.py timed at %d ranks: every query of the root's sparse-core solver is a broadcast + "
+                              "gather round; max over ranks, four pairings one after the other; not in `value`" % world}
+
+    # Second extra, OUTSIDE the timed region and never the headline: the relaxed-rounding cost build (what cost_mode='auto' starts
+    # from between 1 024 and 8 192 nuclei; pm_chi2_cost8_relaxed: no bit identity, every entry within delta of the exact one, used
+    # only behind a certificate against the exact matrix's listed entries).  Launch time by HIP events on the launching stream.
     relaxed_extra = filter_extra = None
     if world == 1 and symmetric[0] and not args.no_assignment:
         ts = []
@@ -433,7 +585,7 @@ def main():
                          "assignment_seconds": t_rs, "hypotheses_certified_on_exact_entries": int(sum(on_relaxed)),
                          "equal_to_exact_matrices_assignments": [bool(ok and x is not None and y is not None and np.array_equal(x[1], y[1]))
                                                                  for ok, x, y in zip(on_relaxed, lsa_r, lsa)],
-                         "note": "opt-in experiment, NOT the product default and NOT in `value`: U = 0.5 (sum a + sum b) - 2 sum ab/(a+b), "
+                         "note": "NOT in `value` (the headline stays the exact build).  What estimate_transform's default cost_mode='auto' starts from below 8 192 nuclei: U = 0.5 (sum a + sum b) - 2 sum ab/(a+b), "
                                  "v_rcp_f64 + one Newton step, four running sums per row (the twins coincide); an assignment solved on "
                                  "these matrices counts only once it is proven to be the exact matrix's unique optimum from the exact "
                                  "values of its matched and near-tight entries (a few N of them, evaluated by a small kernel), else that "
@@ -462,7 +614,7 @@ def main():
                         "hypotheses_settled_without_an_exact_matrix": int(sum(through)),
                         "equal_to_exact_matrices_assignments": [bool(x is not None and y is not None and np.array_equal(x[1], y[1]))
                                                                 for x, y in zip(lsa_f, lsa)],
-                        "note": "opt-in, NOT the product default and NOT in `value`: four matrices in packed float32 arithmetic only select "
+                        "note": "NOT in `value` (the headline stays the exact build).  What estimate_transform's default cost_mode='auto' does at this size: four matrices in packed float32 arithmetic only select "
                                 "entries for the assignment solver, whose costs and certificate are evaluated exactly "
                                 "(lsap.FilteredMatrix; profiles/r04_e2e.txt)"}
         K.chi2_cost8_frame1(sc_m_last[0][0], sc_f_last[0][0], out=U)          # leave the exact matrices behind
@@ -490,9 +642,10 @@ def main():
                          "attainable_note": "the eight running sums of a pair take 8 x 360 dependent float64 adds: %.0f ms per launch at 4 "
                                             "cycles per wave-instruction on 1 024 SIMDs at 2.4 GHz, against %.1f ms for the bytes at 8 TB/s "
                                             "(every term free)" % (add_floor_s * 1e3, algo_bytes / (HBM_PEAK_GBS * 1e9) * 1e3),
-                         "traffic": traffic, "traffic_unit": "GB per launch", "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_unit": "GB per launch", "traffic_source": traffic_src, "traffic_why_null": traffic_why,
                          "algorithmic_bytes": algo_bytes,
-                         "tabled_shells": tabled if sym else None,
+                         "tabled_shells": tabled if sym else None, "shell_count_maxima": shell_max,
+                         "rows_of_this_rank": rows,
                          "note": "hbm_achieved = compulsory bytes / measured launch time.  The >=70 %-of-HBM target of north_star is NOT reachable "
                                  "with bit-identical float64 costs: 360 correctly rounded divisions per pair and matrix need ~70x "
                                  "more float64-VALU time than the 20 ms the bytes need.  Round 2 takes the terms of the sparsely "
@@ -502,6 +655,9 @@ def main():
             "fp64_valu": {"achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
                           "ns_per_wave_instruction_per_simd": ns_per_instr,
                           "issue_bound_ms": issue_bound_ms, "frac_of_issue_bound": issue_bound_ms / chi2_ms,
+                          "shader_clock": clock,
+                          "issue_bound_ms_at_measured_clock": (issue_cycles / (clock["under_load_ghz"]["median"] * 1e9) * 1e3) if clock else None,
+                          "frac_of_issue_bound_at_measured_clock": (issue_cycles / (clock["under_load_ghz"]["median"] * 1e9) * 1e3 / chi2_ms) if clock else None,
                           "algorithmic_flop_view": {"flop_per_pair_and_matrix": 1800, "tflops": 1800.0 * 8 * rows * m / (chi2_ms * 1e-3) / 1e12,
                                                     "frac": 1800.0 * 8 * rows * m / (chi2_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS},
                           "note": "`achieved` counts EXECUTED flops of the launch (68 per divided (pair, bin) for all eight matrices, the Newton "
@@ -511,11 +667,12 @@ def main():
                                   "(fma/mul/add), ~6.9 ns (rcp); tools/microbench/fp64_issue.hip"},
             "icp_residual_first_last": [float(res[0]), float(res[-1])] if args.icp_iters else None,
             "icp_affine_finite": bool(np.isfinite(final).all()),
+            "ranks": ranks_record,
             "assignment_extra": assignment,
             "relaxed_cost_build_extra": relaxed_extra,
             "filter_cost_build_extra": filter_extra,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:           # (rank 0, whatever the world: a SCALE line carries its baseline too, VERDICT r04 next #2b)
             # the chi-square leg of the CPU baseline runs on the real clouds' descriptors (the GPU's, verified equal to the oracle's
             # by the parity tests): >= 1 % of the N x M pairs of every matrix
             r_rows = max(1, min(n, (n + 99) // 100 + 12))

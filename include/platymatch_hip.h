@@ -49,6 +49,14 @@ int pm_version(void);
 const char *pm_error_string(int code);
 int pm_last_hip_error(void); /* hipError_t of the calling thread's most recent PM_ERR_LAUNCH */
 
+/* Measurement aid (bench.py; nothing of the path calls it): ONE wave that samples the shader clock while other work runs on the
+ * device.  Every period_ticks ticks of the constant 100 MHz counter (s_memrealtime) it stores the pair (s_memtime, s_memrealtime)
+ * — samples[2k], samples[2k + 1], k < n_samples — and sleeps in between; the clock between two samples is
+ * (d s_memtime / d s_memrealtime) x 100 MHz (MI355X_MICROARCH.md: the in-kernel clock test).  Launch it on a stream of its own
+ * BEFORE the kernel of interest: it ends by itself after n_samples x period_ticks ticks (bounded here: at most 65 536 samples
+ * and 5 s in all).  samples: device memory, 16 n_samples bytes. */
+int pm_clock_probe(unsigned long long *samples, int n_samples, unsigned long long period_ticks, void *stream);
+
 /* ---- cloud statistics --------------------------------------------------------------------- */
 
 /* get_centroid (utils/utils.py:48-56): out[3] = mean of each coordinate row, in NumPy's own summation order (np.mean over

@@ -18,6 +18,13 @@ def register(moving, fixed, **kwargs):
     return run(moving, fixed, **kwargs)
 
 
+def reserve(n, m=None, cost_mode='auto', device=None):
+    """Allocate the cost buffer for registrations of n x m nuclei ahead of the first call (pipeline.reserve): a fresh process
+    otherwise pays that allocation inside its first estimate_transform (README: cold and warm numbers)."""
+    from .pipeline import reserve as run
+    return run(n, m, cost_mode=cost_mode, device=device)
+
+
 def install_as_platymatch():
     """Register this package's modules under the reference's import paths
     (platymatch.estimate_transform.{shape_context,find_transform,apply_transform,perform_icp},

@@ -25,6 +25,7 @@ SIGNATURES = {
     "pm_version": (_c_int, []),
     "pm_error_string": (ctypes.c_char_p, [_c_int]),
     "pm_last_hip_error": (_c_int, []),
+    "pm_clock_probe": (_c_int, [_c_void_p, _c_int, ctypes.c_ulonglong, _c_void_p]),
     "pm_centroid_workspace": (_c_size_t, [_c_int]),
     "pm_centroid": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_centroid_sequential": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),

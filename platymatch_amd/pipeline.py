@@ -96,6 +96,70 @@ def release_cost_buffers():
             del _COST_CACHE[key]
 
 
+class _EarlyLease:
+    """The kept cost buffer asked for on a helper thread AT THE START of a registration: a fresh process pays
+    ~22 ms per GB for the buffer's first allocation (0.9 s for the default mode's 40 GB at 50 000 nuclei, 3.5 s for the exact
+    mode's 160 GB), and until the cost kernel needs it the host is busy with other first-call costs — self-check, code-object
+    loads, statistics, descriptors.  result() -> the lease, or None (another registration holds the buffer / allocation failed:
+    the caller goes the ordinary way).  A buffer that already exists is leased on the spot, without a thread."""
+
+    def __init__(self, device, nbytes):
+        import torch
+        self.lease, self.thread, self.nbytes = None, None, int(nbytes)
+        stream = torch.cuda.current_stream(device)
+        elems = (int(nbytes) + 7) // 8
+        if kept_cost_bytes(device) >= 8 * elems:
+            self.lease = cost_buffer(device, (elems,))
+            return
+
+        def work():
+            try:
+                with torch.cuda.device(device), torch.cuda.stream(stream):      # (the buffer is kept per (device, stream))
+                    self.lease = cost_buffer(device, (elems,))
+            except Exception:       # noqa: BLE001 — out of memory here is not an error: the caller decides again with what is free
+                self.lease = None
+
+        self.thread = threading.Thread(target=work, name="pm-cost-buffer")
+        self.thread.start()
+
+    def result(self):
+        if self.thread is not None:
+            self.thread.join()
+            self.thread = None
+        return self.lease
+
+    def cancel(self):
+        lease = self.result()
+        if lease is not None:
+            lease.release()
+        self.lease = None
+
+
+def kept_bytes_wanted(mode, n, m):
+    """Bytes a one-GPU registration of N x M nuclei writes into the kept cost buffer when everything is resident: the four float32
+    filter matrices (16 N M), or eight float64 matrices (64 N M)."""
+    return filter_bytes(n, m)[0] if mode == 'filter' else 64.0 * n * m
+
+
+def reserve(n, m=None, cost_mode='auto', device=None):
+    """Make the kept cost buffer of this (device, current stream) large enough for registrations of n x m nuclei AHEAD of the first
+    call — for callers who know their sizes (a widget that has loaded its detections, a batch driver): the first
+    estimate_transform then starts from a warm buffer (50 000 nuclei: ~0.9 s of allocation for the default mode, ~3.5 s for
+    cost_mode='exact', paid here instead).  Nothing is allocated below COST_CACHE_MIN_BYTES (8 GiB; such buffers go through
+    torch's allocator).  -> bytes now kept.  release_cost_buffers() gives the memory back."""
+    m = n if m is None else m
+    dev = nat.device(device)
+    mode = resolve_cost_mode(cost_mode, n, m, 1, GpuBackend)
+    want = kept_bytes_wanted(mode, n, m)
+    if want >= COST_CACHE_MIN_BYTES:
+        import torch
+        with torch.cuda.device(dev):
+            lease = cost_buffer(dev, ((int(want) + 7) // 8,))
+            if lease is not None:
+                lease.release()
+    return kept_cost_bytes(dev)
+
+
 RELAXED_VARIANT = 2            # pm_chi2_cost8_relaxed: 0 all computed, 1 94 x 94 term table, 2 64 x 64 table at three waves per SIMD (fastest at 50k)
 
 
@@ -916,7 +980,7 @@ def _decide_streamed(be, need, opts, group, device):
     return bool(agree_max(1 if streamed else 0, group, device))
 
 
-def correspondences_one_gpu(be, mov, fix, sc_m, sc_f, bn, mode, opts, a_info, mark=None):
+def correspondences_one_gpu(be, mov, fix, sc_m, sc_f, bn, mode, opts, a_info, mark=None, early=None):
     """The eight assignments (_dock_widget.py:547-611) on one GPU from the descriptors -> list of (row_ind, col_ind).
     mode: resolve_cost_mode's answer (already 'exact' where the frames do not permute)."""
     import torch
@@ -929,14 +993,18 @@ def correspondences_one_gpu(be, mov, fix, sc_m, sc_f, bn, mode, opts, a_info, ma
         need = f_bytes + x_bytes
     else:
         f_bytes, need = 0.0, full
-    streamed = _decide_streamed(be, need, opts, None, mov.device)
-    lease = None
+    want = kept_bytes_wanted(mode, n, m)                                   # (bytes actually written into the kept buffer)
+    lease = early.result() if early is not None else None
+    if lease is not None and (lease.view.numel() * 8 < want or opts.stream_hypotheses):
+        lease.release()                                                      # (asked for before the descriptors said which build it would be)
+        lease = None
+    # with the buffer already in hand the matrices are resident by construction; otherwise: do they fit?
+    streamed = False if lease is not None else _decide_streamed(be, need, opts, None, mov.device)
     U = relaxed_delta = None
     try:
         if not streamed:
-            want = f_bytes if mode == 'filter' else 64.0 * n * m           # (bytes actually written into the kept buffer)
-            if opts.keep_cost_buffer and on_gpu and want >= COST_CACHE_MIN_BYTES:
-                lease = cost_buffer(mov.device, (int(want) // 8,))           # None: another registration holds it
+            if lease is None and opts.keep_cost_buffer and on_gpu and want >= COST_CACHE_MIN_BYTES:
+                lease = cost_buffer(mov.device, ((int(want) + 7) // 8,))     # None: another registration holds it
             if mode == 'filter':
                 # the filter matrices with the SHORT side as rows (N > M: the descriptors' roles swapped — the terms are symmetric
                 # and every pairing's bin map is an involution, so that is the transposed filter to within its bound), carved
@@ -1097,7 +1165,36 @@ def assignments(moving, fixed, *, cost_mode='auto', group=None, options=None, de
     return _correspondences(be, mov, fix, moving, fixed, cost_mode, opts, group, info, details)
 
 
-def _correspondences(be, mov, fix, moving, fixed, cost_mode, opts, group, a_info, details, mark=None):
+def _start_early_lease(be, mov, fix, cost_mode, opts, group):
+    """Ask for the kept cost buffer NOW, on a helper thread, while the first-call costs, statistics and descriptors run (one GPU,
+    buffers of at least COST_CACHE_MIN_BYTES that fit) -> _EarlyLease or None."""
+    _, world = _world(group)
+    if not (getattr(be, "device_sampler", False) and world == 1 and opts.keep_cost_buffer and opts.stream_hypotheses is None
+            and getattr(mov, "is_cuda", False)):
+        return None
+    n_, m_ = mov.shape[1], fix.shape[1]
+    mode0 = resolve_cost_mode(cost_mode, n_, m_, 1, be)
+    want0 = kept_bytes_wanted(mode0, n_, m_)
+    if want0 < COST_CACHE_MIN_BYTES:
+        return None
+    extra = filter_bytes(n_, m_)[1] if mode0 == 'filter' else (cost_bytes(n_, n_, m_, 1) - 64.0 * n_ * m_)
+    if want0 + extra > 0.85 * be.free_bytes():
+        return None
+    return _EarlyLease(mov.device, want0)
+
+
+def _correspondences(be, mov, fix, moving, fixed, cost_mode, opts, group, a_info, details, mark=None, early=None):
+    if early is None:
+        early = _start_early_lease(be, mov, fix, cost_mode, opts, group)
+    try:
+        return _correspondences_with(be, mov, fix, moving, fixed, cost_mode, opts, group, a_info, details, mark, early)
+    except BaseException:
+        if early is not None:
+            early.cancel()
+        raise
+
+
+def _correspondences_with(be, mov, fix, moving, fixed, cost_mode, opts, group, a_info, details, mark, early):
     rank, world = _world(group)
     gpu = bool(getattr(be, "device_sampler", False))
     guards = [] if gpu else None          # (the GPU backend: its descriptor launches count the neighbours on bin boundaries)
@@ -1117,7 +1214,7 @@ def _correspondences(be, mov, fix, moving, fixed, cost_mode, opts, group, a_info
         a_info["cost_mode"] = mode
     try:
         if world == 1:
-            lsa = correspondences_one_gpu(be, mov, fix, sc_m, sc_f, bn, mode, opts, a_info, mark)
+            lsa = correspondences_one_gpu(be, mov, fix, sc_m, sc_f, bn, mode, opts, a_info, mark, early)
         else:
             lsa = correspondences_sharded(be, mov, fix, sc_m, sc_f, bn, mode, opts, group, a_info, mark)
     finally:
@@ -1246,14 +1343,23 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     import torch
     opts = Options.of(options)
     be = opts.backend or GpuBackend()
-    if opts.backend is None:
-        from . import self_check
-        self_check()                          # once per process: does this host's NumPy / BLAS round as the kernels restate it?
     if opts.sampler not in ('auto', 'numpy', 'device'):
         raise ValueError("sampler must be 'auto', 'numpy' or 'device'")
     if cost_mode not in COST_MODES:
         raise ValueError("cost_mode must be one of %s" % (COST_MODES,))
+    if mode not in ('unsupervised', 'supervised'):
+        raise ValueError("mode must be 'unsupervised' or 'supervised'")
     mov, fix = be.cloud(moving), be.cloud(fixed)
+    # a fresh process allocates its cost buffer while everything else of a first call happens (_EarlyLease)
+    early = _start_early_lease(be, mov, fix, cost_mode, opts, group) if mode == 'unsupervised' else None
+    if opts.backend is None:
+        from . import self_check
+        try:
+            self_check()                      # once per process: does this host's NumPy / BLAS round as the kernels restate it?
+        except BaseException:
+            if early is not None:
+                early.cancel()
+            raise
     inliers = np.zeros(8, dtype=np.int64)
     timing = {} if (details is not None and details.get("timing")) else None     # details={"timing": True}: wall-clock split
     clock = [time.perf_counter()]
@@ -1274,7 +1380,7 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
                              seed, opts.private_rng)
         a_info = None if details is None else details.setdefault("assignment", {})
         try:
-            lsa = _correspondences(be, mov, fix, moving, fixed, cost_mode, opts, group, a_info, details, mark)
+            lsa = _correspondences(be, mov, fix, moving, fixed, cost_mode, opts, group, a_info, details, mark, early)
         except BaseException:
             draws.thread.join()
             raise

@@ -27,7 +27,9 @@ def test_two_ranks_are_spawned_and_rendezvous_over_gloo():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = _json_lines(p.stdout)
     assert len(lines) == 1, p.stdout                       # rank 0 only
+    ranks = lines[0].pop("ranks")
     assert lines[0] == {"dry_run": True, "n_gpus": 2, "max_rank_plus_one": 2.0, "spawned": True, "local_rank": 0}
+    assert ranks["backend"] == "gloo" and ranks["world"] == 2 and ranks["distinct_devices"] == 2 and len(ranks["devices"]) == 2
 
 
 def test_eight_ranks_are_spawned_and_rendezvous_over_gloo():
@@ -37,7 +39,31 @@ def test_eight_ranks_are_spawned_and_rendezvous_over_gloo():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = _json_lines(p.stdout)
     assert len(lines) == 1, p.stdout
+    ranks = lines[0].pop("ranks")
     assert lines[0] == {"dry_run": True, "n_gpus": 8, "max_rank_plus_one": 8.0, "spawned": True, "local_rank": 0}
+    # the self-proving record of a multi-rank line: which backend carried the collectives, how many DISTINCT
+    # devices the ranks drive (all-gathered identities), and that every collective of the step passed the 60 s preflight
+    assert ranks["backend"] == "gloo" and ranks["world"] == 8 and ranks["distinct_devices"] == 8
+    assert ranks["devices"] == ["no device (dry run), rank %d" % r for r in range(8)] and 0.0 < ranks["preflight_s"] < 60.0
+
+
+def test_preflight_turns_a_missing_rank_into_an_error_not_a_hang():
+    """One of two ranks never arrives: the other's collective preflight gives up after its timeout with a message naming the
+    rendezvous variables (here 3 s; 60 s in a real run) instead of waiting inside the timed region."""
+    code = ("import os, sys, time\nsys.path.insert(0, %r)\nimport bench\nimport torch.distributed as dist\n"
+            "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[2])\n"
+            "rank = int(sys.argv[1])\ndist.init_process_group('gloo', rank=rank, world_size=2)\n"
+            "if rank == 1:\n    time.sleep(20)\n    os._exit(0)\n"
+            "bench.preflight(dist, dist.group.WORLD, None, 2, timeout_s=3.0)\n" % ROOT)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    late = subprocess.Popen([sys.executable, "-c", code, "1", port], env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    p = subprocess.run([sys.executable, "-c", code, "0", port], env=_clean_env(), capture_output=True, text=True, timeout=120)
+    late.kill()
+    late.wait()
+    assert p.returncode == 3 and "collective preflight did not finish" in p.stderr and "MASTER_ADDR" in p.stderr
 
 
 def test_launcher_does_not_import_torch():

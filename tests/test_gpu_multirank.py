@@ -46,6 +46,29 @@ def test_ranks_sharing_the_gpu_reproduce_the_one_process_registration(world, n, 
     assert len(lines) == 2 and all(l.endswith("OK") for l in lines), p.stdout[-2500:]
 
 
+@pytest.mark.parametrize("world,n,m,streamed", [(2, 2500, 2700, False), (3, 2700, 2500, False), (3, 2400, 2400, True)])
+def test_sharded_filter_route_on_ranks_sharing_the_gpu(world, n, m, streamed):
+    """The DEFAULT cost mode on several ranks (VERDICT r04 next #1b): every rank builds its row block of the float32 filter
+    (pm_chi2_filter4_f32 on its rows; N > M: its block of FIXED rows, roles swapped), the root's solver is answered from the blocks
+    (float32 dense passes of lsap.DeviceMatrix) and evaluates exact entries itself (pm_chi2_entries_sym on the gathered frame-1
+    descriptors).  Threshold lowered to rehearsal size; yardstick: the one-process registration on the EXACT matrices."""
+    p = _ranks(world, [n, m], PM_FILTER_FROM="1024", **({"PM_STREAM_HYPOTHESES": "1"} if streamed else {}))
+    assert p.returncode == 0, (p.stdout[-2500:], p.stderr[-2500:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("ICP ")]
+    assert len(lines) == 2 and all(l.endswith("OK") for l in lines), p.stdout[-2500:]
+    assert "cost mode: filter" in p.stdout and "sharded device (filter" in p.stdout and "'gathered'" not in p.stdout, p.stdout[-2500:]
+
+
+def test_sharded_filter_route_on_a_lattice_cloud_builds_exactly_what_it_cannot_prove():
+    """Case 29 again (exact ties everywhere) through the default mode's sharded filter route: no pairing can be certified on listed
+    entries, each gets its exact row blocks and goes the exact sharded way — the answers stay the one-process exact run's."""
+    p = _ranks(3, [2600, 2600, 29], PM_SOAK_CASE="1", PM_FILTER_FROM="1024")
+    assert p.returncode == 0, (p.stdout[-2500:], p.stderr[-2500:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("ICP ")]
+    assert len(lines) == 2 and all(l.endswith("OK") for l in lines), p.stdout[-2500:]
+    assert "cost mode: filter" in p.stdout or "cost mode: exact" in p.stdout      # (exact from the start where the frames do not permute)
+
+
 def test_sharded_run_on_a_lattice_cloud_gathers_what_ties_leave_uncertified():
     """tests/soak_cases.py case 29: a coarse lattice with duplicates — exact ties in every cost matrix.  Streamed over three
     ranks the sharded solve cannot certify a unique optimum; the pairing's blocks then go to the hypothesis's owner and SciPy's
@@ -79,3 +102,15 @@ def test_bench_step_on_two_ranks_sharing_the_gpu():
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["config"]["sharding"] == "rows/2" and d["value"] > 0 and d["scaling"] == "strong"
     assert set(d["stage_ms"]) == {"statistics", "shape_context", "chi2_cost8", "icp"}
+    # the line proves what ran: backend, world, and that BOTH ranks sat on one device — flagged as the rehearsal
+    # it is (without the switch bench.py refuses repeated devices)
+    r = d["ranks"]
+    assert r["backend"] == "gloo" and r["world"] == 2 and r["distinct_devices"] == 1 and r["rehearsal_on_one_device"] is True
+    assert len(r["devices"]) == 2 and r["devices"][0] == r["devices"][1] and 0.0 < r["preflight_s"] < 60.0
+    # a sharded line carries its roofline (rank 0's row block; counter traffic explicitly null with the reason) ...
+    rf = d["roofline"]
+    assert rf["rows_of_this_rank"] == 3000 and rf["algorithmic_bytes"] > 0 and rf["traffic"] is None and rf["traffic_why_null"]
+    # ... and the eight assignments by the sharded default route (row blocks of the float32 filter), timed over both ranks
+    a = d["assignment_extra"]
+    assert a["error"] is None and a["route"].startswith("sharded filter") and a["seconds"] > 0 and all(a["perfect_matchings"])
+    assert all("(filter" in str(x) for x in a["routes"]), a["routes"]

@@ -43,6 +43,15 @@ for JOB in "$@"; do
       timeout -k 10 $(( ${SOAK_SECONDS:-240} + 120 )) python tests/probes/soak_parity.py ${SOAK_SECONDS:-240} ${SOAK_POINTS:-500} ${SOAK_SEED:-0} 2>&1 | grep -v amdgpu.ids > $O/${TAG}_soak_parity.txt || true; tail -6 $O/${TAG}_soak_parity.txt ;;
     rsoak)      # cost_mode='relaxed' against the exact mode on random registrations for SOAK_SECONDS (tools/relaxed_soak.py)
       timeout -k 10 $(( ${SOAK_SECONDS:-240} + 120 )) python tools/relaxed_soak.py ${SOAK_SECONDS:-240} ${SOAK_POINTS:-3000} ${SOAK_SEED:-0} ${SOAK_MODE:-relaxed} 2>&1 | grep --line-buffered -v amdgpu.ids > $O/${TAG}_relaxed_soak.txt || true; tail -8 $O/${TAG}_relaxed_soak.txt ;;
+    asoak)      # the gate of cost_mode='auto' as the default: assignment vectors against cost_mode='exact' on adversarial registrations (tools/auto_soak.py)
+      timeout -k 10 $(( ${SOAK_SECONDS:-600} + 240 )) python tools/auto_soak.py --seconds ${SOAK_SECONDS:-600} --seed0 ${SOAK_SEED:-0} --workers ${SOAK_WORKERS:-4} --filter-from ${SOAK_FILTER_FROM:-8192} --max-points ${SOAK_POINTS:-20000} 2>&1 | grep --line-buffered -v amdgpu.ids > $O/${TAG}_auto_soak_${SOAK_FILTER_FROM:-8192}_seed${SOAK_SEED:-0}.txt || true; tail -12 $O/${TAG}_auto_soak_${SOAK_FILTER_FROM:-8192}_seed${SOAK_SEED:-0}.txt ;;
+    cold)       # the first registration of a fresh process against the following ones, default mode and exact, with and without reserve()
+      : > $O/${TAG}_cold_start.txt
+      for mode in auto exact; do timeout -k 10 300 python tools/cold_start.py ${COLD_N:-50000} $mode 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_cold_start.txt; echo >> $O/${TAG}_cold_start.txt; done
+      timeout -k 10 300 python tools/cold_start.py ${COLD_N:-50000} auto --reserve 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_cold_start.txt
+      grep -E "registration 1|registration 3|reserve" $O/${TAG}_cold_start.txt | cut -c1-260 ;;
+    alloc)      # where a large fresh allocation's time goes
+      timeout -k 10 300 python tools/alloc_probe.py ${ALLOC_GB:-40} 2>&1 | grep -v amdgpu.ids > $O/${TAG}_alloc_probe.txt; cat $O/${TAG}_alloc_probe.txt ;;
     icp)        # ICP per-iteration timing and phase stamps (diagnostic build)
       for n in 5000 20000 50000; do timeout -k 10 200 python tools/icp_profile.py $n 2>&1 | grep -v amdgpu.ids; done > $O/${TAG}_icp_timing.txt; tail -6 $O/${TAG}_icp_timing.txt ;;
     *) echo "unknown job $JOB"; exit 2 ;;

@@ -34,6 +34,8 @@ if os.environ.get("PM_SOAK_CASE") == "1":            # a case of tests/soak_case
 else:
     mv, fx, _ = synth_pair(max(n, m), seed, m=m)
     mv = np.ascontiguousarray(mv[:, :n])
+if os.environ.get("PM_FILTER_FROM"):                 # the default cost mode's sharded FILTER route at rehearsal sizes (8 192 points in production)
+    P.FILTER_MIN_POINTS = int(os.environ["PM_FILTER_FROM"])
 kw = dict(ransac_trials=500, ransac_error=8.0, icp_iterations=12, seed=4)
 streamed = os.environ.get("PM_STREAM_HYPOTHESES") == "1"       # two cost matrices resident at a time on every rank (config 4's mode)
 ok = True
@@ -43,14 +45,14 @@ for shard_icp in (False, True):
                                                               "stream_hypotheses": True if streamed else None}, **kw)
     if rank == 0:
         ref_det = {}
-        ref = P.estimate_transform(mv, fx, details=ref_det, **kw)
+        ref = P.estimate_transform(mv, fx, details=ref_det, cost_mode='exact', **kw)      # one process, exact matrices: the yardstick
         same_lsa = all(np.array_equal(a[1], b[1]) for a, b in zip(det["lsa"], ref_det["lsa"]))
         err_sc = np.linalg.norm(got[0] - ref[0]) / np.linalg.norm(ref[0])
         err_f = np.linalg.norm(got[1] @ got[0] - ref[1] @ ref[0]) / np.linalg.norm(ref[1] @ ref[0])
         res = np.abs(det["residuals"] - ref_det["residuals"]).max()
         good = same_lsa and np.array_equal(got[2], ref[2]) and err_sc == 0.0 and err_f < 1e-9 and res < 1e-9
         ok &= good
-        print("assignment routes:", det.get("assignment", {}).get("routes"), flush=True)
+        print("cost mode:", det.get("assignment", {}).get("cost_mode"), "| assignment routes:", det.get("assignment", {}).get("routes"), flush=True)
         print("ICP %s: assignments identical %s, inliers identical %s, A_sc identical %s, final rel. diff %.1e, residual diff %.1e -> %s"
               % ("sharded" if shard_icp else "replicated", same_lsa, np.array_equal(got[2], ref[2]), err_sc == 0.0, err_f, res,
                  "OK" if good else "MISMATCH"), flush=True)
