@@ -1241,7 +1241,7 @@ def _report_edge_guard(guards, details):
                       "clouds, duplicates).  What this call returns is self-consistent (the direct projection's histograms, "
                       "their exact costs and optimal assignments) and the final 4 x 4 normally agrees with the reference's to "
                       "ICP's tolerance — it is refitted on nearest neighbours, not on the descriptors; details['edge_guard'] "
-                      "has the counts" % (int(gm.sum()), int(gf.sum())), EdgeGuardWarning, stacklevel=4)
+                      "has the counts" % (int(gm.sum()), int(gf.sum())), EdgeGuardWarning, stacklevel=5)
 
 
 def _ransac_stage(be, mov, fix, lsa, sets, on_device, transform, ransac_samples, ransac_trials, ransac_error, seed, group, details):

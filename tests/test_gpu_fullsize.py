@@ -284,11 +284,19 @@ def test_repeated_large_registrations_keep_their_cost_buffer_and_do_not_run_out_
         assert inl.max() > 0.8 * min(n, m)                                      # the right hypothesis was found every time
         torch.cuda.synchronize()
         used.append((P.kept_cost_bytes(dev), torch.cuda.memory_reserved(dev)))
-    assert all(k == 64 * N * N for k, _ in used)                                # allocated once, for the largest pair
+    want = int(P.kept_bytes_wanted(P.resolve_cost_mode('auto', N, N, 1, P.GpuBackend), N, N))
+    assert want == 16 * N * N                                                   # the default mode at this size: four float32 filter matrices
+    assert all(k == want for k, _ in used)                                      # allocated once, for the largest pair
     assert abs(used[3][1] - used[1][1]) < (8 << 30)                             # N <= M runs: no second 160 GB block, no growth
     # (the N > M run works on transposed copies made on the four pairing streams — 8 N M bytes each, cached per stream by torch:
     #  reserved memory grows by those once; the run after it must still fit, which the loop above has shown)
     assert used[5][1] <= torch.cuda.get_device_properties(dev).total_memory
+    # cost_mode='exact' grows the kept buffer to its eight float64 matrices once; a default-mode call afterwards carves its filter
+    # matrices out of the same buffer
+    for mode in ("exact", "auto"):
+        A_sc, A_icp, inl = P.estimate_transform(mv, fx, cost_mode=mode, **kw)
+        torch.cuda.synchronize()
+        assert inl.max() > 0.8 * N and P.kept_cost_bytes(dev) == 64 * N * N, mode
     P.release_cost_buffers()
     torch.cuda.empty_cache()
     assert P.kept_cost_bytes(dev) == 0

@@ -1,9 +1,9 @@
-"""The relaxed-rounding cost build (opt-in experiment: pm_chi2_cost8_relaxed, estimate_transform(cost_mode='relaxed'); VERDICT r03
-next #3).  Never the default.  Statements: every relaxed entry lies within the stated bound of the exact one (the exact one being
-the reference's bits, shape_context.py:88-99); the twins coincide; and a registration in relaxed mode returns the SAME assignment
-vectors, inlier counts and A_sc as the exact mode — by proof: the assignment solved on the relaxed matrix is certified against the
-EXACT matrix on its matched and near-tight entries (pm_chi2_entries_sym, lsap.certify_listed: the exact mode's own margins); a
-pairing that does not certify is rebuilt exactly."""
+"""The builds cost_mode='auto' (THE DEFAULT since round 5) starts from instead of the eight exact matrices: the relaxed-rounding
+float64 build (pm_chi2_cost8_relaxed; 1 024..8 191 nuclei) and the packed-float32 filter (pm_chi2_filter4; from 8 192).  Statements:
+every relaxed / filter entry lies within the stated bound of the exact one (the exact one being the reference's bits,
+shape_context.py:88-99); the twins coincide; and a registration through either returns the SAME assignment vectors, inlier counts
+and A_sc as cost_mode='exact' — by proof: the assignment is certified against the EXACT matrix on its matched and near-tight
+entries (pm_chi2_entries_sym, lsap.certify_listed: the exact mode's own margins); a pairing that does not certify is built exactly."""
 import numpy as np
 import pytest
 
@@ -285,3 +285,35 @@ def test_float32_storage_of_the_filter_and_the_float32_passes_agree_with_the_flo
     ka = np.lexsort((ra[2][:, 1], ra[2][:, 0]))
     kb = np.lexsort((rb[2][:, 1], rb[2][:, 0]))
     assert np.array_equal(ra[2][ka], rb[2][kb]) and np.array_equal(ra[3][ka], rb[3][kb])
+
+
+def test_filter_mode_leases_what_it_writes_and_stays_resident_where_only_that_fits(g, monkeypatch):
+    """the filter route needs four float32 matrices + (at the worst) one pairing's two exact ones — half the
+    exact mode's eight float64 matrices — and must lease exactly what it writes.  With the device's free memory made to look like
+    the window where that half fits and the eight matrices do not (62k..87k nuclei on a 288 GB device; here 9 000 nuclei against a
+    pretended 3.5 GB), the registration stays resident (no streaming, no out-of-memory), keeps a 16 N M-byte buffer and returns
+    the exact mode's registration."""
+    n = 9000
+    mv, fx, _ = synth_pair(n, 21)
+    monkeypatch.setattr(g.P, "COST_CACHE_MIN_BYTES", 1 << 20)
+    g.P.release_cost_buffers()
+    kw = dict(ransac_trials=300, icp_iterations=5, seed=3)
+    de, dr = {}, {}
+    a = g.P.estimate_transform(mv, fx, details=de, cost_mode='exact', options={"keep_cost_buffer": False}, **kw)
+    pretended = 3.5e9
+    assert 32.0 * n * n <= 0.85 * pretended < 64.0 * n * n
+    monkeypatch.setattr(g.P.GpuBackend, "free_bytes", lambda self: pretended)
+    b = g.P.estimate_transform(mv, fx, details=dr, **kw)
+    assert dr["assignment"]["cost_mode"] == "filter" and "streamed" not in str(dr["assignment"].get("mode", ""))
+    assert g.P.kept_cost_bytes(g.t.device("cuda", g.t.cuda.current_device())) == 16 * n * n
+    for h in range(8):
+        assert np.array_equal(de["lsa"][h][1], dr["lsa"][h][1]), h
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # and below the window even the filter streams, pairing by pairing, with the same answer
+    monkeypatch.setattr(g.P.GpuBackend, "free_bytes", lambda self: 2.0e9)
+    g.P.release_cost_buffers()
+    ds = {}
+    c = g.P.estimate_transform(mv, fx, details=ds, **kw)
+    assert "streamed" in str(ds["assignment"].get("mode", "")), ds["assignment"].get("mode")
+    assert np.array_equal(a[2], c[2]) and np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    g.P.release_cost_buffers()

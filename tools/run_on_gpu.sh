@@ -14,7 +14,7 @@ for JOB in "$@"; do
   echo "[$TAG] $JOB"
   case $JOB in
     suite)      # the GPU parity suite as the driver runs it
-      timeout -k 10 900 python -m pytest tests -m gpu -x -q -s > $O/${TAG}_gpu_suite.log 2>&1; tail -3 $O/${TAG}_gpu_suite.log ;;
+      timeout -k 10 1000 python -m pytest tests -m gpu ${PYTEST_STOP:---maxfail=6} -q -s > $O/${TAG}_gpu_suite.log 2>&1; tail -3 $O/${TAG}_gpu_suite.log ;;
     smoke)
       timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
     bench)      # the headline line (N = M = 50 000) with the CPU baseline and both extras
