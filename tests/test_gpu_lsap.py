@@ -231,8 +231,8 @@ def test_streamed_hypotheses_give_the_same_registration(dev):
     kw = dict(ransac_trials=400, ransac_error=16, icp_iterations=10, seed=2)
     for fixed in (fx[:, :1650], fx):                                            # N > M and N == M
         d0, d1 = {}, {}
-        a = P.estimate_transform(mv, fixed, details=d0, stream_hypotheses=False, **kw)
-        b = P.estimate_transform(mv, fixed, details=d1, stream_hypotheses=True, **kw)
+        a = P.estimate_transform(mv, fixed, details=d0, cost_mode='exact', options={"stream_hypotheses": False}, **kw)
+        b = P.estimate_transform(mv, fixed, details=d1, options={"stream_hypotheses": True}, **kw)        # (the default cost mode)
         assert d1["assignment"]["mode"].startswith("streamed")
         for h in range(8):
             assert np.array_equal(d0["lsa"][h][0], d1["lsa"][h][0]) and np.array_equal(d0["lsa"][h][1], d1["lsa"][h][1]), h
