@@ -11,7 +11,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libplatymatch_hip.so")
+# PM_LIB_PATH: another build of the same library (the sanitized host build of platymatch_amd.build.build_sanitized; diagnostic builds)
+LIB_PATH = os.environ.get("PM_LIB_PATH") or os.path.join(_HERE, "libplatymatch_hip.so")
 NBINS = 360
 ABI_VERSION = 2
 ICP_NSUMS = 24

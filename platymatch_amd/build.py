@@ -38,6 +38,51 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+SANITIZE_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+ASAN_LIB = os.path.join(HERE, "_sanitized", "libplatymatch_hip.so")
+
+
+def sanitizer_runtimes():
+    """The shared sanitizer runtimes of the host compiler (to be LD_PRELOADed into an interpreter that loads ASAN_LIB)."""
+    gxx = shutil.which("g++") or "g++"
+    libs = [subprocess.run([gxx, "-print-file-name=" + n], capture_output=True, text=True).stdout.strip() for n in ("libasan.so", "libubsan.so")]
+    return [x for x in libs if os.path.isabs(x) and os.path.exists(x)]
+
+
+def build_sanitized(verbose=False):
+    """SURVEY.md §5's sanitizer build of the HOST C++ (VERDICT r04 next #7a): the solver / RNG units (pm_lsap.cpp, pm_lsap_core.cpp,
+    pm_host_rng.cpp — pointer-heavy code no GPU tool looks at) compiled with -fsanitize=address,undefined and linked, with the
+    product's own device objects, into a SECOND library (platymatch_amd/_sanitized/; the product library is untouched).  Use:
+    PM_LIB_PATH=<that file> LD_PRELOAD=<sanitizer_runtimes()> python -m pytest tests/test_lsap_core.py ...
+    (tests/test_host_sanitizers.py does exactly that).  GPU AddressSanitizer is not available on this pool: host code only.
+    Also reached by  PM_HOST_SANITIZE=1 python -m platymatch_amd.build."""
+    build_native()
+    out_dir = os.path.dirname(ASAN_LIB)
+    os.makedirs(out_dir, exist_ok=True)
+    gxx = shutil.which("g++") or "g++"
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "platymatch_hip.h")]
+    objs = []
+    for src in SOURCES:
+        plain = os.path.join(OBJ, src.replace(".hip", ".o").replace(".cpp", ".o"))
+        if not src.endswith(".cpp"):
+            objs.append(plain)
+            continue
+        s, o = os.path.join(CSRC, src), os.path.join(out_dir, src.replace(".cpp", ".o"))
+        objs.append(o)
+        if _stale(o, [s] + headers):
+            cmd = [gxx] + SANITIZE_FLAGS + ["-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("g++ (sanitized) failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    if _stale(ASAN_LIB, objs):
+        r = subprocess.run([_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", ASAN_LIB] + objs, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link (sanitized) failed:\n%s" % r.stderr)
+    return ASAN_LIB
+
+
 def build_native(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
@@ -75,3 +120,6 @@ def build_native(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build_native(force="--force" in sys.argv, verbose=True))
+    if os.environ.get("PM_HOST_SANITIZE") == "1":
+        print(build_sanitized(verbose=True))
+        print("LD_PRELOAD=" + ":".join(sanitizer_runtimes()))
