@@ -310,6 +310,7 @@ def main():
     ap.add_argument("--points", type=int, default=50000, help="points per cloud (default: the BASELINE 50k configuration)")
     ap.add_argument("--icp-iters", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-config2", action="store_true", help="skip the fully timed host run of BASELINE config 2 (5 000 nuclei, ~1 min of CPU)")
     ap.add_argument("--no-assignment", action="store_true", help="skip the untimed extra leg (eight assignments of the same build)")
     ap.add_argument("--dry-run", action="store_true", help="launcher + rendezvous only (gloo, no GPU): what the CPU test-suite runs")
     args = ap.parse_args()
@@ -678,6 +679,26 @@ def main():
             r_rows = max(1, min(n, (n + 99) // 100 + 12))
             real = (sc_m_last[0][:, :r_rows].cpu().numpy(), (sc_f_last[0] if sc_f_last[0].shape[0] == 4 else P.expand_frames(sc_f_last[0][0], 4)).cpu().numpy())
             out["cpu_baseline"] = cpu_baseline(mv_h, fx_h, start_h, args.icp_iters, real=real)
+            if not args.no_cpu_config2:
+                # BASELINE config 2 complete on the host, TIMED (tools/cpu_config2.py), beside the same pair through the product
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import cpu_config2
+                c2 = cpu_config2.run(5000)
+                from conftest import synth_pair
+                from platymatch_amd.estimate_transform import perform_icp as pi
+                pi.VERBOSE = False
+                mv2, fx2, _ = synth_pair(5000, 42)
+                gpu_s = []
+                for _ in range(4):
+                    torch.cuda.synchronize()
+                    t_g = time.perf_counter()
+                    P.estimate_transform(mv2, fx2, ransac_trials=8000, ransac_error=16, icp_iterations=50, seed=0)
+                    torch.cuda.synchronize()
+                    gpu_s.append(time.perf_counter() - t_g)
+                out["cpu_baseline"]["config2_timed_s"] = c2["seconds"]
+                out["cpu_baseline"]["config2"] = dict(c2, gpu_same_pair_s={"first_call": gpu_s[0], "median_of_next_three": float(np.median(gpu_s[1:]))},
+                                                      note="a complete 5 000-nucleus registration (seeded: the reference's RANSAC index sets), host oracle against "
+                                                           "the product on this GPU; host arrays in, host arrays out")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(group=group)
