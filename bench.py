@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector float64 spec peak
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector float32 spec peak (packed: two lanes' worth per instruction)
 
 A_GT = np.array([[9.08173020e-01, -2.58092254e-01, 2.21387350e-01, 4.98532315e+00],
                  [-2.85490902e-02, 5.66865806e-01, 7.60292965e-01, -2.13218259e+02],
@@ -612,6 +613,13 @@ def main():
         through = [str(d.get("cost_mode", "")).startswith("filter") for d in f_info.get("details", [])]
         filter_extra = {"kernel": "pm::filter4_kernel<-1, float>", "launch_ms": min(ts), "exact_launch_ms": chi2_ms, "speedup": chi2_ms / min(ts),
                         "per_entry_error_bound": K.chi2_filter_delta(), "assignment_seconds": t_fs,
+                        # its own roofline: packed-float32 VALU against the vector peak, counting the ALGORITHMIC
+                        # 5 flop per (pair, bin, pairing) — add, multiply, reciprocal, fused multiply-add — whether a term was computed
+                        # or read from the 94 x 94 float32 table; and the write rate of its 16 N M bytes
+                        "roofline": {"bound": "fp32_packed_valu", "achieved": 5.0 * 4 * 360 * n * m / (min(ts) * 1e-3) / 1e12, "peak": FP32_VALU_PEAK_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": 5.0 * 4 * 360 * n * m / (min(ts) * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                                     "hbm_achieved": 16.0 * n * m / (min(ts) * 1e-3) / 1e9, "hbm_unit": "GB/s",
+                                     "hbm_frac": 16.0 * n * m / (min(ts) * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": 16.0 * n * m + 2880.0 * (n + m)},
                         "hypotheses_settled_without_an_exact_matrix": int(sum(through)),
                         "equal_to_exact_matrices_assignments": [bool(x is not None and y is not None and np.array_equal(x[1], y[1]))
                                                                 for x, y in zip(lsa_f, lsa)],

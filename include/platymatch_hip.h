@@ -204,7 +204,8 @@ int pm_chi2_cost8_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, 
 int pm_chi2_cost_pair_sym(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, double *out2, size_t ld,
                           size_t matrix_stride, void *stream);
 
-/* OPT-IN EXPERIMENT, never the default (round 4): the same eight matrices in RELAXED float64 arithmetic — no bit identity with
+/* What estimate_transform's default cost_mode='auto' starts from between 1 024 and 8 191 nuclei (round 4: opt-in; round 5: the
+ * default route, always behind the exact matrix's certificate): the same eight matrices in RELAXED float64 arithmetic — no bit identity with
  * the reference's scalar loop (shape_context.py:88-99), every entry within pm_chi2_relaxed_delta() (absolute) of it.
  * U = 0.5 (sum a + sum b) - 2 sum_k a_k b_k / (a_k + b_k): four running sums per row instead of eight (the twins U11/U22,
  * U12/U21, U13/U24, U14/U23 coincide once the order of summation is free and are written twice), v_rcp_f64 + one Newton step
@@ -216,9 +217,11 @@ size_t pm_chi2_relaxed_workspace_bytes(int nM, int nF);
 double pm_chi2_relaxed_delta(void);
 int pm_chi2_cost8_relaxed(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld,
                           size_t matrix_stride, void *ws, size_t ws_bytes, int variant, void *stream);
-/* OPT-IN (round 4): the FILTER build — the four pairings' matrices (out4 + t * matrix_stride, t = 0..3: U11/U22, U12/U21, U13/U24,
+/* The FILTER build (what cost_mode='auto' starts from at 8 192 nuclei and above; sharded runs: a rank's row block of it) — the
+ * four pairings' matrices (out4 + t * matrix_stride, t = 0..3: U11/U22, U12/U21, U13/U24,
  * U14/U23, each pair one matrix) in packed float32 arithmetic, written as float64; every entry within pm_chi2_filter_delta()
- * (absolute, 1.1e-6) of the exact cost.  3.2x faster than the exact eight-matrix launch, half its output.  Not the reference's
+ * (absolute, 1.1e-6) of the exact cost.  Shells whose integer counts stay below 94 take their terms from a 94 x 94 float32 table
+ * in LDS (round 5).  3.2x+ faster than the exact eight-matrix launch, half its output.  Not the reference's
  * values and never handed out as such: the matrices only tell the assignment solver WHICH entries can matter, every cost it uses
  * is evaluated exactly by pm_chi2_entries_sym (the Python mirror: lsap.FilteredMatrix, estimate_transform(cost_mode='filter')).
  * ws: pm_chi2_filter_workspace_bytes of 16-byte aligned device memory.  Same precondition as pm_chi2_cost8_sym (symmetry flag 0). */
@@ -238,6 +241,9 @@ int pm_chi2_filter4_f32(const double *sc_m1, int nM, const double *sc_f1, int nF
                         void *ws, size_t ws_bytes, void *stream);
 int pm_chi2_filter_pair_f32(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, float *out1, size_t ld,
                             void *ws, size_t ws_bytes, void *stream);
+/* tools / tests: pm_chi2_filter4_f32 with the term table off (variant 0: every shell computed, round 4's kernel) or on (1: the product's) */
+int pm_chi2_filter4_f32_variant(const double *sc_m1, int nM, const double *sc_f1, int nF, float *out4, size_t ld, size_t matrix_stride,
+                                void *ws, size_t ws_bytes, int variant, void *stream);
 int pm_lsap_row_select_f32(const float *U, int nr, int nc, size_t ld, const double *v, int k, int32_t *out_col, double *out_cost,
                            int32_t *nonfinite1, void *stream);
 int pm_lsap_col_min_f32(const float *U, int nr, int nc, size_t ld, double *v, void *ws, size_t ws_bytes, void *stream);

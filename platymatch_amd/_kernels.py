@@ -30,12 +30,14 @@ def _cloud(x, name="cloud"):
 
 
 def _here(x, name):
-    """Kernels are enqueued on the current stream of the CURRENT device: operands must live there (a launch on another
-    GPU's stream against foreign memory faults).  Wrap the call in torch.cuda.device(x.device) to work on another GPU."""
+    """Kernels are enqueued on the current stream of the CURRENT device, and operands must live there (a launch on another GPU's
+    stream against foreign memory faults).  Every public wrapper of this module runs under the device of its first GPU operand
+    (_on_operand_device below: SURVEY.md §8b "set its device per call"), so this only fires when operands of ONE call live on
+    different devices."""
     cur = _t().cuda.current_device()
     if x.device.index != cur:
-        raise ValueError("%s lives on cuda:%s but the current device is cuda:%d (use `with torch.cuda.device(%s):`)"
-                         % (name, x.device.index, cur, "tensor.device"))
+        raise ValueError("%s lives on cuda:%s but the call's other operands (and its stream) are on cuda:%d: all operands of one call "
+                         "must live on one device" % (name, x.device.index, cur))
 
 
 def _vec(x, n, name):
@@ -345,7 +347,7 @@ def chi2_relaxed_delta():
     return float(nat.load().pm_chi2_relaxed_delta())
 
 
-def chi2_filter4(sc_m1, sc_f1, out=None, dtype=None):
+def chi2_filter4(sc_m1, sc_f1, out=None, dtype=None, variant=None):
     """OPT-IN: the four pairings' cost matrices in packed float32 arithmetic -> [4, nM, nF] float64 (or float32: dtype / out's),
     every entry within chi2_filter_delta() of the exact cost (pm_chi2_filter4 / _f32).  A FILTER for the assignment solver
     (lsap.FilteredMatrix), never a result: matrix t stands for hypothesis PAIRINGS[t][0] and for its twin."""
@@ -359,6 +361,12 @@ def chi2_filter4(sc_m1, sc_f1, out=None, dtype=None):
         raise ValueError("out must be a float64 or float32 tensor [4, nM, nF] on the descriptors' device with unit column stride")
     lib = nat.load()
     ws = torch.empty(int(lib.pm_chi2_filter_workspace_bytes(nM, nF)), dtype=torch.uint8, device=a.device)
+    if variant is not None:               # tools / tests: 0 = every shell computed, 1 = sparsely filled shells from the term table (the product's)
+        if out.dtype != torch.float32:
+            raise ValueError("variant is offered for float32 storage only")
+        check(lib.pm_chi2_filter4_f32_variant(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(), int(variant),
+                                              nat.stream_ptr()))
+        return out
     fn = lib.pm_chi2_filter4_f32 if out.dtype == torch.float32 else lib.pm_chi2_filter4
     check(fn(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(), nat.stream_ptr()))
     return out
@@ -809,3 +817,33 @@ def similar_apply(A, mov, fix=None, nn=None, want_residual=True, ws=None):
                                ptr(nn) if want_residual else None, ptr(res), ptr(ws) if want_residual else None,
                                ws.numel() if want_residual else 0, nat.stream_ptr()))
     return res
+
+
+# ---- every public wrapper runs on the device of its first GPU operand -------------------------------------------------------------
+def _on_operand_device(fn):
+    """The binding sets the device per call (VERDICT r04 missing #5): a napari worker thread — or any caller on a
+    multi-GPU host — need not have made the tensors' device current.  No-op (one integer comparison) when it already is."""
+    import functools
+
+    @functools.wraps(fn)
+    def run(*args, **kw):
+        dev = None
+        for a in args:
+            if nat.is_torch(a) and a.is_cuda:
+                dev = a.device
+                break
+        if dev is None:
+            return fn(*args, **kw)
+        cuda = _t().cuda
+        if dev.index == cuda.current_device():
+            return fn(*args, **kw)
+        with cuda.device(dev):
+            return fn(*args, **kw)
+    return run
+
+
+for _name, _fn in list(globals().items()):
+    if not _name.startswith("_") and getattr(_fn, "__module__", None) == __name__ and type(_fn).__name__ == "function":
+        globals()[_name] = _on_operand_device(_fn)
+del _name, _fn
+

@@ -657,7 +657,7 @@ ROW_REDUCTION_ROUNDS = 0
 
 # eps-scaling auction over the sparse core before the first shortest-path solve: (eps0, eps_min) in units of the core's width,
 # the scaling factor, how many auction + pricing rounds, the bid budget.  None = off.  Measured on chi-square matrices
-# (tools/lsap_probe.py): eight assignments at 20 000 x 20 000 nuclei 0.56 s -> 0.13 s, at 50 000 x 50 000 2.65 s -> 0.65 s.
+# (round 2 probe, git history): eight assignments at 20 000 x 20 000 nuclei 0.56 s -> 0.13 s, at 50 000 x 50 000 2.65 s -> 0.65 s.
 # max_free_columns: the largest share of spare columns (nc - nr) / nc for which the auction runs (1.0: always).  With spare
 # columns, rows freed after the auction strand their columns below the dual a free column must carry; each of those is put
 # right by a search from the column side (pm_lsap_core.cpp: reverse_augment), a few steps each.
@@ -1061,7 +1061,7 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
     (Measured at 50 000 nuclei, twice: no gain.  Before the auction warm start the three wrong-frame hypotheses needed the same
     ~2.8 s each, so the last one built decided (4.5 s against 4.0 s); with it the solves are short but made of dense passes
     that queue behind the cost kernel (2.2 s against 1.8 s).  Round 3 gave the solver's streams priority over the cost
-    kernel's (PIPELINED_PRIORITY, tools/pipelined_assign_probe.py): no change, 2.14-2.32 s against 1.61-1.98 s back to back
+    kernel's (PIPELINED_PRIORITY; round-3 probe, git history): no change, 2.14-2.32 s against 1.61-1.98 s back to back
     (profiles/r03_pipelined_probe.txt) — the cost kernel's resident workgroups hold every CU for the length of a pairing.
     The driver does not use it.)"""
     torch = nat.torch_mod()

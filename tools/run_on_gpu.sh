@@ -35,14 +35,10 @@ for JOB in "$@"; do
       timeout -k 10 400 python tools/batch_throughput.py --pairs 64 --workers 8 --unseeded --json $O/${TAG}_batch64_unseeded.json 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-300 ;;
     rankshare)  # one rank's share of the multi-GPU runs (prediction for the driver's SCALE curve)
       timeout -k 10 500 python tools/rank_share.py $O/${TAG}_rank_share.json 2>&1 | grep -v amdgpu.ids | tail -8 ;;
-    relaxed)    # the relaxed-rounding cost build beside the exact one
-      timeout -k 10 500 python tools/chi2_relaxed_probe.py 50000 2>&1 | grep -v amdgpu.ids > $O/${TAG}_chi2_relaxed.txt; tail -14 $O/${TAG}_chi2_relaxed.txt ;;
     big)        # 100 000 x 100 000 on one GPU (hypotheses streamed two matrices at a time)
       timeout -k 10 600 python tools/big_registration.py 100000 8000 50 2>&1 | grep -v amdgpu.ids > $O/${TAG}_registration_100k.txt; tail -4 $O/${TAG}_registration_100k.txt | cut -c1-400 ;;
     soak)       # random registrations against the oracle for SOAK_SECONDS (tests/probes/soak_parity.py; PM_SOAK_LOPSIDED=1 for the lopsided family)
       timeout -k 10 $(( ${SOAK_SECONDS:-240} + 120 )) python tests/probes/soak_parity.py ${SOAK_SECONDS:-240} ${SOAK_POINTS:-500} ${SOAK_SEED:-0} 2>&1 | grep -v amdgpu.ids > $O/${TAG}_soak_parity.txt || true; tail -6 $O/${TAG}_soak_parity.txt ;;
-    rsoak)      # cost_mode='relaxed' against the exact mode on random registrations for SOAK_SECONDS (tools/relaxed_soak.py)
-      timeout -k 10 $(( ${SOAK_SECONDS:-240} + 120 )) python tools/relaxed_soak.py ${SOAK_SECONDS:-240} ${SOAK_POINTS:-3000} ${SOAK_SEED:-0} ${SOAK_MODE:-relaxed} 2>&1 | grep --line-buffered -v amdgpu.ids > $O/${TAG}_relaxed_soak.txt || true; tail -8 $O/${TAG}_relaxed_soak.txt ;;
     asoak)      # the gate of cost_mode='auto' as the default: assignment vectors against cost_mode='exact' on adversarial registrations (tools/auto_soak.py)
       timeout -k 10 $(( ${SOAK_SECONDS:-600} + 240 )) python tools/auto_soak.py --seconds ${SOAK_SECONDS:-600} --seed0 ${SOAK_SEED:-0} --workers ${SOAK_WORKERS:-4} --filter-from ${SOAK_FILTER_FROM:-8192} --max-points ${SOAK_POINTS:-20000} 2>&1 | grep --line-buffered -v amdgpu.ids > $O/${TAG}_auto_soak_${SOAK_FILTER_FROM:-8192}_seed${SOAK_SEED:-0}.txt || true; tail -12 $O/${TAG}_auto_soak_${SOAK_FILTER_FROM:-8192}_seed${SOAK_SEED:-0}.txt ;;
     cold)       # the first registration of a fresh process against the following ones, default mode and exact, with and without reserve()
@@ -50,6 +46,8 @@ for JOB in "$@"; do
       for mode in auto exact; do timeout -k 10 300 python tools/cold_start.py ${COLD_N:-50000} $mode 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_cold_start.txt; echo >> $O/${TAG}_cold_start.txt; done
       timeout -k 10 300 python tools/cold_start.py ${COLD_N:-50000} auto --reserve 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_cold_start.txt
       grep -E "registration 1|registration 3|reserve" $O/${TAG}_cold_start.txt | cut -c1-260 ;;
+    ftable)     # the float32 filter build with and without its term table
+      timeout -k 10 400 python tools/filter_table_probe.py ${FT_N:-50000} 2>&1 | grep -v amdgpu.ids > $O/${TAG}_filter_table.txt; cat $O/${TAG}_filter_table.txt | cut -c1-420 ;;
     alloc)      # where a large fresh allocation's time goes
       timeout -k 10 300 python tools/alloc_probe.py ${ALLOC_GB:-40} 2>&1 | grep -v amdgpu.ids > $O/${TAG}_alloc_probe.txt; cat $O/${TAG}_alloc_probe.txt ;;
     icp)        # ICP per-iteration timing and phase stamps (diagnostic build)
