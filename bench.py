@@ -200,6 +200,8 @@ def preflight(dist, group, dev, world, timeout_s=60.0):
 
     def run():
         try:
+            if not on_host:
+                torch.cuda.set_device(dev)                # (a new thread starts on device 0: barrier and synchronize go by the current device)
             t = torch.ones(128, dtype=torch.float64, device=d)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)                      # mean-distance piece sums
             f = torch.zeros(1, dtype=torch.int32, device=d)
@@ -211,8 +213,8 @@ def preflight(dist, group, dev, world, timeout_s=60.0):
             dist.gather(t, whole, dst=0, group=group)                                  # assignment answers
             dist.barrier(group=group)
             if not on_host:
-                torch.cuda.synchronize()
-            if float(out.sum()) != 128.0 * world * world:
+                torch.cuda.synchronize(dev)
+            if float(out.sum()) != 128.0 * world * world:          # (ones, summed over the ranks, gathered from every rank)
                 err.append("preflight all-gather returned %r, expected %r" % (float(out.sum()), 128.0 * world * world))
         except Exception as e:       # noqa: BLE001
             err.append("%s: %s" % (type(e).__name__, e))

@@ -137,7 +137,8 @@ def worker(slot):
                 c["cases"] += 1
                 c["relaxed"] += sum(x.startswith("relaxed") for x in modes)
                 c["filter"] += sum(x.startswith("filter") for x in modes)
-                c["exact"] += sum(x.startswith("exact") for x in modes) + (8 if (got is not None and not modes) else 0)
+                settled = sum(x.startswith(("relaxed", "filter")) for x in modes)
+                c["exact"] += (8 - settled) if got is not None else 0       # (incl. pairs exact from the start: small, or frames that do not permute)
                 c["raised"] += int(want is None)
                 c["largest"] = max(c["largest"], min(mv.shape[1], fx.shape[1]))
                 state["done"] += 1
