@@ -107,6 +107,21 @@ def main():
                                          and np.array_equal(c_h, scipy_lsa(U8[0].cpu().numpy())[1])
                                          and np.array_equal(c_t, scipy_lsa(U8[5].cpu().numpy())[1]))
 
+    # round 5: the default mode's sharded FILTER route through RCCL (world of one: the whole row range is this rank's block) — float32
+    # dense passes of DeviceMatrix answering a FilteredMatrix over the ShardedMatrix, exact entries on the root: the exact matrices'
+    # eight assignments; and bench.py's self-proving record (uint8 all-gather of the device identity, the threaded preflight)
+    sc_m, sc_f, bn2 = P.build_descriptors(be, be.cloud(mv), be.cloud(fx2))
+    finfo = {}
+    lsa_f = P.assign_sharded_filtered(be, sc_m, sc_f[:1].contiguous(), bn2, g, info=finfo)
+    out["sharded_filter_route"] = bool(all(np.array_equal(lsa_f[h][1], scipy_lsa(U8[h].cpu().numpy())[1]) for h in range(8))
+                                       and all("(filter" in str(r) for r in finfo["routes"]))
+    lsa_s = P.assign_sharded_filtered(be, sc_m, sc_f[:1].contiguous(), bn2, g, streamed=True)
+    out["sharded_filter_route_streamed"] = bool(all(np.array_equal(lsa_s[h][1], lsa_f[h][1]) for h in range(8)))
+    import bench
+    rec = bench.rank_devices(dist, g, dev, 1, 0)
+    out["rank_devices"] = bool(rec["backend"] == "nccl" and rec["distinct_devices"] == 1 and len(rec["devices"][0]) > 3)
+    out["preflight_s"] = float(bench.preflight(dist, g, dev, 1, timeout_s=120.0))
+
     # the headless driver with group=WORLD against the reference fixture (tests/golden/synth128.npz)
     fx = np.load(os.path.join(ROOT, "tests", "golden", "synth128.npz"))
     det = {}

@@ -38,9 +38,14 @@ def test_backend_is_rccl(report):
 
 
 @pytest.mark.parametrize("what", ["all_reduce_sum_f64", "all_reduce_max_i32", "all_reduce_max_f64", "all_gather_f64", "all_gather_i32",
-                                  "gather_f64", "broadcast_i64", "all_gather_into_tensor_f64", "all_gather_into_tensor_i32", "sharded_query_protocol", "all_gather_rows", "sharded_mean_distance_bits"])
+                                  "gather_f64", "broadcast_i64", "all_gather_into_tensor_f64", "all_gather_into_tensor_i32", "sharded_query_protocol", "all_gather_rows", "sharded_mean_distance_bits",
+                                  "sharded_filter_route", "sharded_filter_route_streamed", "rank_devices"])
 def test_collective_of_the_sharded_pipeline_through_rccl(report, what):
     assert report[what] is True
+
+
+def test_collective_preflight_passes_through_rccl(report):
+    assert 0.0 < report["preflight_s"] < 120.0
 
 
 def test_driver_with_group_world_reproduces_the_reference_fixture(report):
