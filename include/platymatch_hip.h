@@ -241,7 +241,8 @@ int pm_chi2_filter4_f32(const double *sc_m1, int nM, const double *sc_f1, int nF
                         void *ws, size_t ws_bytes, void *stream);
 int pm_chi2_filter_pair_f32(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, float *out1, size_t ld,
                             void *ws, size_t ws_bytes, void *stream);
-/* tools / tests: pm_chi2_filter4_f32 with the term table off (variant 0: every shell computed, round 4's kernel) or on (1: the product's) */
+/* tools / tests: pm_chi2_filter4_f32 with the term table off (variant 0: every shell computed, round 4's kernel) or on (1: the product's);
+ * 2 / 3: the table kernel held to 128 registers, with / without its table (measurement only) */
 int pm_chi2_filter4_f32_variant(const double *sc_m1, int nM, const double *sc_f1, int nF, float *out4, size_t ld, size_t matrix_stride,
                                 void *ws, size_t ws_bytes, int variant, void *stream);
 int pm_lsap_row_select_f32(const float *U, int nr, int nc, size_t ld, const double *v, int k, int32_t *out_col, double *out_cost,

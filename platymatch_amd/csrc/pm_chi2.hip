@@ -485,8 +485,8 @@ typedef float pm_f2 __attribute__((ext_vector_type(2)));
 // and 1) take their terms a b / (a + b) from a TL x TL FLOAT32 table in LDS (35 KB for TL = 94; entries computed in float64 and
 // rounded once: closer to the exact term than the computed path's 8 x 2^-24, so PM_CHI2_FILTER_DELTA stands) — one ds_read_b32, one
 // address add and one float add per term instead of v_rcp_f32 + 1.5 packed operations.
-template <int TSEL, typename OUT, int TL = 0>      // -1: the four pairings -> out + t * mstride; t: pairing t alone -> out.  OUT: float64 or float32 storage.  TL: table side (0: none)
-__global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__restrict__ scA, int nA, const double *__restrict__ scB, int nB,
+template <int TSEL, typename OUT, int TL = 0, int MINW = 2>      // -1: the four pairings -> out + t * mstride; t: pairing t alone -> out.  OUT: float64 or float32 storage.  TL: table side (0: none).  MINW: waves per SIMD the register allocator must leave room for
+__global__ __launch_bounds__(CH_THREADS, MINW) void filter4_kernel(const double *__restrict__ scA, int nA, const double *__restrict__ scB, int nB,
                                                                 OUT *__restrict__ out, size_t ld, size_t mstride, int nTi,
                                                                 unsigned int nblocks, const double *__restrict__ sumA,
                                                                 const double *__restrict__ sumB,
@@ -569,21 +569,32 @@ __global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__
 #pragma unroll
                 for (int k = 0; k < CH_K; ++k) cb4[k] = ((wb[k >> 2] >> (8 * (k & 3))) & 255u) << 2;
                 const char *tbase = reinterpret_cast<const char *>(tabf);
+                // (row, pairing) groups of twelve lookups, software-pipelined by hand as in chi2_sym_kernel: the reads of group i + 1 are
+                // issued before the additions of group i, so that an LDS round trip hides behind them (left to the scheduler the loop
+                // waited 88 times per 192 reads and the tabled shells cost what the computed ones do: profiles/r05_filter_table.txt)
+                constexpr int NG = RI * NT;
+                float Tc[CH_K], Tn[CH_K];
+                auto lookups = [&](int i, float (&T)[CH_K]) {
+                    const int r = i / NT, t = (TSEL < 0) ? i % NT : TSEL;
 #pragma unroll
-                for (int r = 0; r < RI; ++r) {
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) {
-                        const int t = TSEL < 0 ? tt : TSEL;
-                        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                        for (int p = 0; p < CH_K; ++p) {
-                            const int q = (t == 0) ? p : (t == 1) ? (p + 6) % 12 : (t == 2) ? 11 - p : (17 - p) % 12;
-                            const unsigned int row = ((wa[r][p >> 2] >> (8 * (p & 3))) & 255u) * (unsigned int)(TL * 4);     // scalar
-                            const float T = *reinterpret_cast<const float *>(tbase + row + cb4[q]);
-                            if (p & 1) s1 += T; else s0 += T;
-                        }
-                        acc[r][tt] += (double)(s0 + s1);
+                    for (int p = 0; p < CH_K; ++p) {
+                        const int q = (t == 0) ? p : (t == 1) ? (p + 6) % 12 : (t == 2) ? 11 - p : (17 - p) % 12;
+                        const unsigned int row = ((wa[r][p >> 2] >> (8 * (p & 3))) & 255u) * (unsigned int)(TL * 4);     // scalar
+                        T[p] = *reinterpret_cast<const float *>(tbase + row + cb4[q]);
                     }
+                };
+                lookups(0, Tc);
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    if (i + 1 < NG) lookups(i + 1, Tn);
+                    __builtin_amdgcn_sched_barrier(0);
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int p = 0; p < CH_K; p += 2) { s0 += Tc[p]; s1 += Tc[p + 1]; }
+                    acc[i / NT][i % NT] += (double)(s0 + s1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int p = 0; p < CH_K; ++p) Tc[p] = Tn[p];
                 }
                 continue;                 // uniform over the workgroup: nothing staged, no barrier
             }
@@ -883,7 +894,7 @@ constexpr int FILTER_TL = 94;
 
 template <typename OUT>
 static int filter_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, OUT *out, size_t ld, size_t matrix_stride,
-                         void *ws, size_t ws_bytes, void *stream, bool table = true) {
+                         void *ws, size_t ws_bytes, void *stream, bool table = true, int probe = 0) {
     if (!sc_m1 || !sc_f1 || !out || nM <= 0 || nF <= 0 || ld < (size_t)nF || (pairing < 0 && matrix_stride < (size_t)nM * ld))
         return PM_ERR_INVALID_ARG;
     if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < pm_chi2_filter_workspace_bytes(nM, nF)) return PM_ERR_WORKSPACE;
@@ -901,6 +912,11 @@ static int filter_launch(const double *sc_m1, int nM, const double *sc_f1, int n
         char *tws = (char *)ws + align_up((size_t)nM * 8, 256) + align_up((size_t)nF * 8, 256);
         const int rc = sym_prepare(sc_m1, nM, sc_f1, nF, tws, pm_chi2_sym_workspace_bytes(nM, nF), s, w);
         if (rc != PM_OK) return rc;
+        if (probe == 2 || probe == 3) {
+            if (probe == 3 && hipMemsetAsync(&w.meta->bad, 1, 1, s) != hipSuccess) return launch_status();
+            filter4_kernel<-1, OUT, FILTER_TL, 4><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, (int)nTi, grid, sumA, sumB, w.cntA, w.cntB, w.meta);
+            return launch_status();
+        }
         switch (pairing) {
             case -1: filter4_kernel<-1, OUT, FILTER_TL><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, (int)nTi, grid, sumA, sumB, w.cntA, w.cntB, w.meta); break;
             case 0: filter4_kernel<0, OUT, FILTER_TL><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB, w.cntA, w.cntB, w.meta); break;
@@ -937,6 +953,11 @@ extern "C" int pm_chi2_filter4_f32(const double *sc_m1, int nM, const double *sc
 // tools / tests: variant 0 = every shell computed (round 4's kernel), 1 = the product's (term table for sparsely filled shells)
 extern "C" int pm_chi2_filter4_f32_variant(const double *sc_m1, int nM, const double *sc_f1, int nF, float *out4, size_t ld, size_t matrix_stride,
                                            void *ws, size_t ws_bytes, int variant, void *stream) {
+    if (variant == 2 || variant == 3) {
+        // measurement only: the table kernel held to 128 registers (four waves per SIMD instead of three), with (2) and without (3) its table
+        const int rc = pm::filter_launch(sc_m1, nM, sc_f1, nF, -1, out4, ld, matrix_stride, ws, ws_bytes, stream, true, variant);
+        return rc;
+    }
     if (variant != 0 && variant != 1) return PM_ERR_INVALID_ARG;
     return pm::filter_launch(sc_m1, nM, sc_f1, nF, -1, out4, ld, matrix_stride, ws, ws_bytes, stream, variant == 1);
 }
