@@ -1049,6 +1049,68 @@ def _resolved(W, sol, info, out, slot, n, m):
 PIPELINED_PRIORITY = -1
 
 
+# ---- where the four pairings' solver threads run ------------------------------------------------------------------------------------
+# The host core of a 50 000-nucleus hypothesis walks ~20 MB (core edges, column records) in cache-hostile order.  Measured on the GPU
+# box (EPYC 9575F: 16 CCDs of 8 cores with 32 MB of L3 each; profiles/r05_filter_phases.txt): one pairing alone 0.27-0.34 s of auction +
+# shortest paths, the same four side by side 0.39-0.60 s each — threads started from one parent land on one CCD and share its L3.
+# pin_solver_thread(slot) gives each of the four its own L3 domain (same NUMA node as the caller where possible).
+PIN_SOLVER_THREADS = os.environ.get("PM_LSAP_PIN", "1") != "0"
+_L3_DOMAINS = None
+
+
+def _l3_domains():
+    """The L3 domains (lists of logical CPUs) this process may run on, the caller's own first, then its NUMA node's, then the rest."""
+    global _L3_DOMAINS
+    if _L3_DOMAINS is not None:
+        return _L3_DOMAINS
+    doms = []
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen = {}
+        for c in sorted(allowed):
+            try:
+                with open("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list" % c) as f:
+                    key = f.read().strip()
+            except OSError:
+                key = "all"
+            seen.setdefault(key, []).append(c)
+        here = None
+        try:
+            here = os.sched_getcpu() if hasattr(os, "sched_getcpu") else None
+        except OSError:
+            here = None
+
+        def node_of(c):
+            try:
+                for name in os.listdir("/sys/devices/system/cpu/cpu%d" % c):
+                    if name.startswith("node"):
+                        return int(name[4:])
+            except (OSError, ValueError):
+                pass
+            return 0
+        home = node_of(here) if here is not None else 0
+        doms = sorted(seen.values(), key=lambda cpus: (0 if (here in cpus) else 1 if node_of(cpus[0]) == home else 2, cpus[0]))
+    except (AttributeError, OSError):
+        doms = []
+    _L3_DOMAINS = doms
+    return doms
+
+
+def pin_solver_thread(slot):
+    """Restrict the CALLING thread to the slot-th L3 domain (no-op with fewer than two domains, off Linux, or PM_LSAP_PIN=0)."""
+    if not PIN_SOLVER_THREADS:
+        return None
+    doms = _l3_domains()
+    if len(doms) < 2:
+        return None
+    cpus = doms[slot % len(doms)]
+    try:
+        os.sched_setaffinity(0, cpus)            # (Linux: pid 0 = the calling THREAD)
+    except OSError:
+        return None
+    return cpus
+
+
 def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False, ready=None, min_eps=0.0, exact_rebuild=None,
                           exact_entries=None, cost_delta=0.0):
     """The widget's eight assignments (_dock_widget.py:604-611) for U8 [8, N, M] on the GPU: hypotheses 11, 12, 13, 14 are
@@ -1082,6 +1144,7 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
     caller = torch.cuda.current_stream(U8.device).cuda_stream          # (concurrent callers, e.g. batch workers, keep apart)
 
     def pair(h):
+        pin_solver_thread(h)
         twin = [t for t, s in TWINS.items() if s == h][0]
         # persistent: the allocator's cache is per stream; pipelined behind the cost build the dense passes must get in front of it
         stream = nat.side_stream(U8.device, ("pair", caller, h), priority=PIPELINED_PRIORITY if ready is not None else 0)
@@ -1160,6 +1223,7 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
     exact_turn = threading.Lock()
 
     def pair(t):
+        pin_solver_thread(t)
         h, twin = pairs[t]
         stream = nat.side_stream(device, ("pair", caller, h))
         with torch.cuda.device(device), torch.cuda.stream(stream):

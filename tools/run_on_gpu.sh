@@ -49,8 +49,12 @@ for JOB in "$@"; do
     ftable)     # the float32 filter build with and without its term table
       timeout -k 10 400 python tools/filter_table_probe.py ${FT_N:-50000} 2>&1 | grep -v amdgpu.ids > $O/${TAG}_filter_table.txt; cat $O/${TAG}_filter_table.txt | cut -c1-420 ;;
     fphase)     # the default mode's filtered solves, query by query, side by side and alone
-      timeout -k 10 300 python tools/filter_phase_probe.py ${FP_N:-50000} 2>&1 | grep -v amdgpu.ids > $O/${TAG}_filter_phases.txt
-      timeout -k 10 300 python tools/filter_phase_probe.py ${FP_N:-50000} --alone 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_filter_phases.txt; cut -c1-200 $O/${TAG}_filter_phases.txt | head -90 ;;
+      echo "== solver threads pinned to one L3 domain each (the default)" > $O/${TAG}_filter_phases.txt
+      timeout -k 10 300 python tools/filter_phase_probe.py ${FP_N:-50000} 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_filter_phases.txt
+      echo "== PM_LSAP_PIN=0: placement left to the scheduler" >> $O/${TAG}_filter_phases.txt
+      PM_LSAP_PIN=0 timeout -k 10 300 python tools/filter_phase_probe.py ${FP_N:-50000} 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_filter_phases.txt
+      echo "== one pairing after the other" >> $O/${TAG}_filter_phases.txt
+      timeout -k 10 300 python tools/filter_phase_probe.py ${FP_N:-50000} --alone 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_filter_phases.txt; grep -E "^==|registration|pairing [0-9]" $O/${TAG}_filter_phases.txt | cut -c1-330 ;;
     alloc)      # where a large fresh allocation's time goes
       timeout -k 10 300 python tools/alloc_probe.py ${ALLOC_GB:-40} 2>&1 | grep -v amdgpu.ids > $O/${TAG}_alloc_probe.txt; cat $O/${TAG}_alloc_probe.txt ;;
     icp)        # ICP per-iteration timing and phase stamps (diagnostic build)
