@@ -220,8 +220,9 @@ int pm_chi2_cost8_relaxed(const double *sc_m1, int nM, const double *sc_f1, int 
 /* The FILTER build (what cost_mode='auto' starts from at 8 192 nuclei and above; sharded runs: a rank's row block of it) — the
  * four pairings' matrices (out4 + t * matrix_stride, t = 0..3: U11/U22, U12/U21, U13/U24,
  * U14/U23, each pair one matrix) in packed float32 arithmetic, written as float64; every entry within pm_chi2_filter_delta()
- * (absolute, 1.1e-6) of the exact cost.  Shells whose integer counts stay below 94 take their terms from a 94 x 94 float32 table
- * in LDS (round 5).  3.2x+ faster than the exact eight-matrix launch, half its output.  Not the reference's
+ * (absolute, 1.1e-6) of the exact cost.  3.0x faster than the exact eight-matrix launch, a quarter of its output as float32.  (A
+ * 94 x 94 float32 term table for the sparsely filled shells, as the exact kernel has, was built and measured in round 5: no gain —
+ * one LDS gather per term costs what the packed arithmetic does; profiles/r05_filter_table.txt.)  Not the reference's
  * values and never handed out as such: the matrices only tell the assignment solver WHICH entries can matter, every cost it uses
  * is evaluated exactly by pm_chi2_entries_sym (the Python mirror: lsap.FilteredMatrix, estimate_transform(cost_mode='filter')).
  * ws: pm_chi2_filter_workspace_bytes of 16-byte aligned device memory.  Same precondition as pm_chi2_cost8_sym (symmetry flag 0). */
@@ -241,10 +242,6 @@ int pm_chi2_filter4_f32(const double *sc_m1, int nM, const double *sc_f1, int nF
                         void *ws, size_t ws_bytes, void *stream);
 int pm_chi2_filter_pair_f32(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, float *out1, size_t ld,
                             void *ws, size_t ws_bytes, void *stream);
-/* tools / tests: pm_chi2_filter4_f32 with the term table off (variant 0: every shell computed, round 4's kernel) or on (1: the product's);
- * 2 / 3: the table kernel held to 128 registers, with / without its table (measurement only) */
-int pm_chi2_filter4_f32_variant(const double *sc_m1, int nM, const double *sc_f1, int nF, float *out4, size_t ld, size_t matrix_stride,
-                                void *ws, size_t ws_bytes, int variant, void *stream);
 int pm_lsap_row_select_f32(const float *U, int nr, int nc, size_t ld, const double *v, int k, int32_t *out_col, double *out_cost,
                            int32_t *nonfinite1, void *stream);
 int pm_lsap_col_min_f32(const float *U, int nr, int nc, size_t ld, double *v, void *ws, size_t ws_bytes, void *stream);

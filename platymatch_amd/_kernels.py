@@ -347,7 +347,7 @@ def chi2_relaxed_delta():
     return float(nat.load().pm_chi2_relaxed_delta())
 
 
-def chi2_filter4(sc_m1, sc_f1, out=None, dtype=None, variant=None):
+def chi2_filter4(sc_m1, sc_f1, out=None, dtype=None):
     """OPT-IN: the four pairings' cost matrices in packed float32 arithmetic -> [4, nM, nF] float64 (or float32: dtype / out's),
     every entry within chi2_filter_delta() of the exact cost (pm_chi2_filter4 / _f32).  A FILTER for the assignment solver
     (lsap.FilteredMatrix), never a result: matrix t stands for hypothesis PAIRINGS[t][0] and for its twin."""
@@ -361,12 +361,6 @@ def chi2_filter4(sc_m1, sc_f1, out=None, dtype=None, variant=None):
         raise ValueError("out must be a float64 or float32 tensor [4, nM, nF] on the descriptors' device with unit column stride")
     lib = nat.load()
     ws = torch.empty(int(lib.pm_chi2_filter_workspace_bytes(nM, nF)), dtype=torch.uint8, device=a.device)
-    if variant is not None:               # tools / tests: 0 = every shell computed, 1 = sparsely filled shells from the term table (the product's)
-        if out.dtype != torch.float32:
-            raise ValueError("variant is offered for float32 storage only")
-        check(lib.pm_chi2_filter4_f32_variant(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(), int(variant),
-                                              nat.stream_ptr()))
-        return out
     fn = lib.pm_chi2_filter4_f32 if out.dtype == torch.float32 else lib.pm_chi2_filter4
     check(fn(ptr(a), nM, ptr(b), nF, ptr(out), out.stride(1), out.stride(0), ptr(ws), ws.numel(), nat.stream_ptr()))
     return out

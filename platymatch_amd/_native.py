@@ -49,7 +49,6 @@ SIGNATURES = {
     "pm_lsap_col_min_f32": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_chi2_filter4_f32": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_size_t, _c_size_t, _c_void_p, _c_size_t, _c_void_p]),
     "pm_chi2_filter_pair_f32": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p, _c_size_t, _c_void_p]),
-    "pm_chi2_filter4_f32_variant": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_size_t, _c_size_t, _c_void_p, _c_size_t, _c_int, _c_void_p]),
     "pm_lsap_col_min": (_c_int, [_c_void_p, _c_int, _c_int, _c_size_t, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_lsap_core_init_duals": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "pm_lsap_core_init_state": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p]),

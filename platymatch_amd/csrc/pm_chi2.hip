@@ -481,22 +481,14 @@ __global__ __launch_bounds__(256) void entries_sym_kernel(const double *__restri
 #define PM_CHI2_FILTER_DELTA 1.1e-6
 typedef float pm_f2 __attribute__((ext_vector_type(2)));
 
-// Round 5: like the exact kernel, the shells whose integer counts stay below TL in both clouds (12 of 30 at 50 000 nuclei: rings 0
-// and 1) take their terms a b / (a + b) from a TL x TL FLOAT32 table in LDS (35 KB for TL = 94; entries computed in float64 and
-// rounded once: closer to the exact term than the computed path's 8 x 2^-24, so PM_CHI2_FILTER_DELTA stands) — one ds_read_b32, one
-// address add and one float add per term instead of v_rcp_f32 + 1.5 packed operations.
-template <int TSEL, typename OUT, int TL = 0, int MINW = 2>      // -1: the four pairings -> out + t * mstride; t: pairing t alone -> out.  OUT: float64 or float32 storage.  TL: table side (0: none).  MINW: waves per SIMD the register allocator must leave room for
-__global__ __launch_bounds__(CH_THREADS, MINW) void filter4_kernel(const double *__restrict__ scA, int nA, const double *__restrict__ scB, int nB,
+template <int TSEL, typename OUT>      // -1: the four pairings -> out + t * mstride; t: pairing t alone -> out.  OUT: float64 or float32 storage
+__global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__restrict__ scA, int nA, const double *__restrict__ scB, int nB,
                                                                 OUT *__restrict__ out, size_t ld, size_t mstride, int nTi,
                                                                 unsigned int nblocks, const double *__restrict__ sumA,
-                                                                const double *__restrict__ sumB,
-                                                                const unsigned char *__restrict__ cntA = nullptr,
-                                                                const unsigned char *__restrict__ cntB = nullptr,
-                                                                const SymMeta *__restrict__ meta = nullptr) {
+                                                                const double *__restrict__ sumB) {
     constexpr int RI = 4, TI = 4 * RI;
     __shared__ __attribute__((aligned(16))) float A_s[TI][CH_K];
     __shared__ __attribute__((aligned(16))) float B_s[CH_TJ][CH_K + 2];
-    __shared__ __attribute__((aligned(16))) float tabf[TL > 0 ? TL * TL : 1];
     unsigned int bid = blockIdx.x;
     const unsigned int full = nblocks / 8u * 8u;
     if (bid < full) bid = (bid % 8u) * (full / 8u) + bid / 8u;
@@ -511,94 +503,7 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void filter4_kernel(const double 
     for (int r = 0; r < RI; ++r)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[r][t] = 0.0;
-
-    unsigned int tabmask = 0;             // shells served from the table (uniform over the launch)
-    unsigned int nb[3] = {0, 0, 0}, na[RI][3];
-#pragma unroll
-    for (int r = 0; r < RI; ++r) na[r][0] = na[r][1] = na[r][2] = 0;
-    const unsigned int *pb0 = nullptr, *pa0[RI];
-    if constexpr (TL > 0) {
-        if (meta->bad == 0) {
-            for (int g = 0; g < CH_STAGES; ++g)
-                if (meta->maxc[0][g] < TL && meta->maxc[1][g] < TL) tabmask |= 1u << g;
-        }
-        tabmask = __builtin_amdgcn_readfirstlane(tabmask);
-        if (tabmask) {
-            const double totA = meta->tot[0], totB = meta->tot[1];
-            for (int e = tid; e < TL * TL; e += CH_THREADS) {
-                const int ca = e / TL, cb = e - ca * TL;
-                const double a = (double)ca / totA, b = (double)cb / totB;
-                tabf[e] = (ca && cb) ? (float)((a * b) / (a + b)) : 0.f;       // an empty bin contributes nothing
-            }
-            __syncthreads();
-            // counts of the first tabled shell; every tabled shell fetches the next one's before it starts (an L2 round trip)
-            pb0 = reinterpret_cast<const unsigned int *>(cntB + (size_t)min(j0 + lane, nB - 1) * PM_NBINS);
-#pragma unroll
-            for (int r = 0; r < RI; ++r)
-                pa0[r] = reinterpret_cast<const unsigned int *>(cntA + (size_t)min(i0 + wave * RI + r, nA - 1) * PM_NBINS);
-            const int g0 = __builtin_ctz(tabmask);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) nb[k] = pb0[g0 * 3 + k];
-#pragma unroll
-            for (int r = 0; r < RI; ++r)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) na[r][k] = pa0[r][g0 * 3 + k];
-        }
-    }
-
     for (int g = 0; g < CH_STAGES; ++g) {
-        if constexpr (TL > 0) {
-            if ((tabmask >> g) & 1u) {
-                const unsigned int wb[3] = {nb[0], nb[1], nb[2]};
-                unsigned int wa[RI][3];
-#pragma unroll
-                for (int r = 0; r < RI; ++r)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) wa[r][k] = __builtin_amdgcn_readfirstlane(na[r][k]);
-                const unsigned int later = tabmask >> g >> 1;
-                if (later) {
-                    const int gn = g + 1 + __builtin_ctz(later);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) nb[k] = pb0[gn * 3 + k];
-#pragma unroll
-                    for (int r = 0; r < RI; ++r)
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) na[r][k] = pa0[r][gn * 3 + k];
-                }
-                unsigned int cb4[CH_K];           // this lane's twelve fixed counts as byte offsets into a table row
-#pragma unroll
-                for (int k = 0; k < CH_K; ++k) cb4[k] = ((wb[k >> 2] >> (8 * (k & 3))) & 255u) << 2;
-                const char *tbase = reinterpret_cast<const char *>(tabf);
-                // (row, pairing) groups of twelve lookups, software-pipelined by hand as in chi2_sym_kernel: the reads of group i + 1 are
-                // issued before the additions of group i, so that an LDS round trip hides behind them (left to the scheduler the loop
-                // waited 88 times per 192 reads and the tabled shells cost what the computed ones do: profiles/r05_filter_table.txt)
-                constexpr int NG = RI * NT;
-                float Tc[CH_K], Tn[CH_K];
-                auto lookups = [&](int i, float (&T)[CH_K]) {
-                    const int r = i / NT, t = (TSEL < 0) ? i % NT : TSEL;
-#pragma unroll
-                    for (int p = 0; p < CH_K; ++p) {
-                        const int q = (t == 0) ? p : (t == 1) ? (p + 6) % 12 : (t == 2) ? 11 - p : (17 - p) % 12;
-                        const unsigned int row = ((wa[r][p >> 2] >> (8 * (p & 3))) & 255u) * (unsigned int)(TL * 4);     // scalar
-                        T[p] = *reinterpret_cast<const float *>(tbase + row + cb4[q]);
-                    }
-                };
-                lookups(0, Tc);
-#pragma unroll
-                for (int i = 0; i < NG; ++i) {
-                    if (i + 1 < NG) lookups(i + 1, Tn);
-                    __builtin_amdgcn_sched_barrier(0);
-                    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                    for (int p = 0; p < CH_K; p += 2) { s0 += Tc[p]; s1 += Tc[p + 1]; }
-                    acc[i / NT][i % NT] += (double)(s0 + s1);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int p = 0; p < CH_K; ++p) Tc[p] = Tn[p];
-                }
-                continue;                 // uniform over the workgroup: nothing staged, no barrier
-            }
-        }
         __syncthreads();
         if (tid < TI * CH_K) {
             const int r = tid / CH_K, k = tid - r * CH_K;
@@ -880,21 +785,18 @@ extern "C" int pm_chi2_cost8_relaxed(const double *sc_m1, int nM, const double *
     return pm::chi2_sym_launch<4, 2, -1, pm::CH_TL, true>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, s, w.cntA, w.cntB, w.meta, sumA, sumB);
 }
 
-// The filter build (see filter4_kernel).  Workspace: pm_chi2_filter_workspace_bytes = the two row-sum vectors + the term table's
-// workspace (the integer counts behind the descriptor values, pm_chi2_sym_workspace_bytes).
+// The filter build (see filter4_kernel).  Workspace: pm_chi2_filter_workspace_bytes = the two row-sum vectors.
 extern "C" size_t pm_chi2_filter_workspace_bytes(int nM, int nF) {
     if (nM <= 0 || nF <= 0) return 0;
-    return pm::align_up((size_t)nM * 8, 256) + pm::align_up((size_t)nF * 8, 256) + pm::align_up(pm_chi2_sym_workspace_bytes(nM, nF), 256);
+    return pm::align_up((size_t)nM * 8, 256) + pm::align_up((size_t)nF * 8, 256);
 }
 
 extern "C" double pm_chi2_filter_delta(void) { return PM_CHI2_FILTER_DELTA; }
 
 namespace pm {
-constexpr int FILTER_TL = 94;
-
 template <typename OUT>
 static int filter_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, OUT *out, size_t ld, size_t matrix_stride,
-                         void *ws, size_t ws_bytes, void *stream, bool table = true, int probe = 0) {
+                         void *ws, size_t ws_bytes, void *stream) {
     if (!sc_m1 || !sc_f1 || !out || nM <= 0 || nF <= 0 || ld < (size_t)nF || (pairing < 0 && matrix_stride < (size_t)nM * ld))
         return PM_ERR_INVALID_ARG;
     if (!ws || ((uintptr_t)ws & 15) != 0 || ws_bytes < pm_chi2_filter_workspace_bytes(nM, nF)) return PM_ERR_WORKSPACE;
@@ -907,26 +809,6 @@ static int filter_launch(const double *sc_m1, int nM, const double *sc_f1, int n
     const long nblocks = nTi * nTj;
     if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
     const unsigned int grid = (unsigned int)nblocks;
-    if (table && ((uintptr_t)sc_m1 & 15) == 0 && ((uintptr_t)sc_f1 & 15) == 0) {
-        SymWs w;
-        char *tws = (char *)ws + align_up((size_t)nM * 8, 256) + align_up((size_t)nF * 8, 256);
-        const int rc = sym_prepare(sc_m1, nM, sc_f1, nF, tws, pm_chi2_sym_workspace_bytes(nM, nF), s, w);
-        if (rc != PM_OK) return rc;
-        if (probe == 2 || probe == 3) {
-            if (probe == 3 && hipMemsetAsync(&w.meta->bad, 1, 1, s) != hipSuccess) return launch_status();
-            filter4_kernel<-1, OUT, FILTER_TL, 4><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, (int)nTi, grid, sumA, sumB, w.cntA, w.cntB, w.meta);
-            return launch_status();
-        }
-        switch (pairing) {
-            case -1: filter4_kernel<-1, OUT, FILTER_TL><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, (int)nTi, grid, sumA, sumB, w.cntA, w.cntB, w.meta); break;
-            case 0: filter4_kernel<0, OUT, FILTER_TL><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB, w.cntA, w.cntB, w.meta); break;
-            case 1: filter4_kernel<1, OUT, FILTER_TL><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB, w.cntA, w.cntB, w.meta); break;
-            case 2: filter4_kernel<2, OUT, FILTER_TL><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB, w.cntA, w.cntB, w.meta); break;
-            case 3: filter4_kernel<3, OUT, FILTER_TL><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB, w.cntA, w.cntB, w.meta); break;
-            default: return PM_ERR_INVALID_ARG;
-        }
-        return launch_status();
-    }
     switch (pairing) {
         case -1: filter4_kernel<-1, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, (int)nTi, grid, sumA, sumB); break;
         case 0: filter4_kernel<0, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
@@ -948,18 +830,6 @@ extern "C" int pm_chi2_filter4(const double *sc_m1, int nM, const double *sc_f1,
 extern "C" int pm_chi2_filter4_f32(const double *sc_m1, int nM, const double *sc_f1, int nF, float *out4, size_t ld, size_t matrix_stride,
                                    void *ws, size_t ws_bytes, void *stream) {
     return pm::filter_launch(sc_m1, nM, sc_f1, nF, -1, out4, ld, matrix_stride, ws, ws_bytes, stream);
-}
-
-// tools / tests: variant 0 = every shell computed (round 4's kernel), 1 = the product's (term table for sparsely filled shells)
-extern "C" int pm_chi2_filter4_f32_variant(const double *sc_m1, int nM, const double *sc_f1, int nF, float *out4, size_t ld, size_t matrix_stride,
-                                           void *ws, size_t ws_bytes, int variant, void *stream) {
-    if (variant == 2 || variant == 3) {
-        // measurement only: the table kernel held to 128 registers (four waves per SIMD instead of three), with (2) and without (3) its table
-        const int rc = pm::filter_launch(sc_m1, nM, sc_f1, nF, -1, out4, ld, matrix_stride, ws, ws_bytes, stream, true, variant);
-        return rc;
-    }
-    if (variant != 0 && variant != 1) return PM_ERR_INVALID_ARG;
-    return pm::filter_launch(sc_m1, nM, sc_f1, nF, -1, out4, ld, matrix_stride, ws, ws_bytes, stream, variant == 1);
 }
 
 extern "C" int pm_chi2_filter_pair_f32(const double *sc_m1, int nM, const double *sc_f1, int nF, int pairing, float *out1, size_t ld,

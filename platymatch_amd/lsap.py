@@ -1076,8 +1076,10 @@ def _l3_domains():
             seen.setdefault(key, []).append(c)
         here = None
         try:
-            here = os.sched_getcpu() if hasattr(os, "sched_getcpu") else None
-        except OSError:
+            here = os.sched_getcpu() if hasattr(os, "sched_getcpu") else int(ctypes.CDLL(None).sched_getcpu())
+            if here < 0:
+                here = None
+        except (OSError, AttributeError):
             here = None
 
         def node_of(c):
@@ -1089,11 +1091,29 @@ def _l3_domains():
                 pass
             return 0
         home = node_of(here) if here is not None else 0
-        doms = sorted(seen.values(), key=lambda cpus: (0 if (here in cpus) else 1 if node_of(cpus[0]) == home else 2, cpus[0]))
+        mine = next((k for k, cpus in enumerate(sorted(seen.values(), key=lambda c: c[0])) if here in cpus), 0)
+        order = sorted(seen.values(), key=lambda c: c[0])
+        # the caller's own domain first (the scheduler put it somewhere sensible), then its neighbours on the same NUMA node, then the rest
+        doms = sorted(order, key=lambda cpus: (0 if (here in cpus) else 1 if node_of(cpus[0]) == home else 2,
+                                               (order.index(cpus) - mine) % max(len(order), 1)))
     except (AttributeError, OSError):
         doms = []
     _L3_DOMAINS = doms
     return doms
+
+
+_PIN_LOCAL = threading.local()
+
+
+def set_pin_base(base):
+    """For callers that run several registrations side by side (pipeline.estimate_transform_batch's workers): the solver threads
+    started from THIS thread take the L3 domains base, base + 1, ... instead of 0, 1, ... — workers then spread over the socket
+    instead of piling onto four domains."""
+    _PIN_LOCAL.base = int(base)
+
+
+def _pin_base():
+    return int(getattr(_PIN_LOCAL, "base", 0))
 
 
 def pin_solver_thread(slot):
@@ -1143,8 +1163,10 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
 
     caller = torch.cuda.current_stream(U8.device).cuda_stream          # (concurrent callers, e.g. batch workers, keep apart)
 
+    pin_base = _pin_base()
+
     def pair(h):
-        pin_solver_thread(h)
+        pin_solver_thread(pin_base + h)
         twin = [t for t, s in TWINS.items() if s == h][0]
         # persistent: the allocator's cache is per stream; pipelined behind the cost build the dense passes must get in front of it
         stream = nat.side_stream(U8.device, ("pair", caller, h), priority=PIPELINED_PRIORITY if ready is not None else 0)
@@ -1222,8 +1244,10 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
     caller = torch.cuda.current_stream(device).cuda_stream
     exact_turn = threading.Lock()
 
+    pin_base = _pin_base()
+
     def pair(t):
-        pin_solver_thread(t)
+        pin_solver_thread(pin_base + t)
         h, twin = pairs[t]
         stream = nat.side_stream(device, ("pair", caller, h))
         with torch.cuda.device(device), torch.cuda.stream(stream):

@@ -1479,6 +1479,8 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
                     gate.wait()
                 in_flight[0] += want
             try:
+                from . import lsap
+                lsap.set_pin_base(4 * worker_slot())                             # this worker's solver threads: L3 domains of their own
                 stream = nat.side_stream(dev, ("batch worker", worker_slot()))   # persistent per worker thread
                 with torch.cuda.device(dev), torch.cuda.stream(stream):
                     out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], details=det, options=opts, **kwargs)

@@ -184,16 +184,12 @@ def test_filter_build_is_within_its_bound_of_both_orders_of_every_pairing(g, n, 
             worst = max(worst, float((F[t] - exact[k]).abs().max()))
     print("%d x %d: largest |filter - exact| = %.2e (bound %.1e)" % (n, m, worst, delta))
     assert worst <= delta
-    # float32 storage, with the term table of round 5 (the product's kernel) and without (every shell computed): both within the bound,
-    # the pairing-by-pairing launches give the four-matrix launch's values, and the table really served some shells
-    f32 = g.t.float32
-    F1, F0 = g.K.chi2_filter4(sc_m[0], sc_f[0], dtype=f32, variant=1), g.K.chi2_filter4(sc_m[0], sc_f[0], dtype=f32, variant=0)
-    assert g.t.equal(F1, g.K.chi2_filter4(sc_m[0], sc_f[0], dtype=f32))
+    # float32 storage (the product's): within the bound too, and the pairing-by-pairing launches give the four-matrix launch's values
+    F32 = g.K.chi2_filter4(sc_m[0], sc_f[0], dtype=g.t.float32)
     for t, (h, twin) in enumerate(g.K.PAIRINGS):
         for k in (h, twin):
-            assert float((F1[t].double() - exact[k]).abs().max()) <= delta and float((F0[t].double() - exact[k]).abs().max()) <= delta
-        assert g.t.equal(g.K.chi2_filter_pair(sc_m[0], sc_f[0], t, dtype=f32), F1[t]), t
-    assert not g.t.equal(F1, F0)                     # (different arithmetic in the tabled shells: the table was used)
+            assert float((F32[t].double() - exact[k]).abs().max()) <= delta
+        assert g.t.equal(g.K.chi2_filter_pair(sc_m[0], sc_f[0], t, dtype=g.t.float32), F32[t]), t
 
 
 @pytest.mark.parametrize("n,m,seed", [(3000, 2900, 77), (5000, 5000, 42), (2400, 2600, 3), (1200, 1200, 9), (600, 650, 1), (9000, 8400, 4)])

@@ -46,8 +46,6 @@ for JOB in "$@"; do
       for mode in auto exact; do timeout -k 10 300 python tools/cold_start.py ${COLD_N:-50000} $mode 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_cold_start.txt; echo >> $O/${TAG}_cold_start.txt; done
       timeout -k 10 300 python tools/cold_start.py ${COLD_N:-50000} auto --reserve 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_cold_start.txt
       grep -E "registration 1|registration 3|reserve" $O/${TAG}_cold_start.txt | cut -c1-260 ;;
-    ftable)     # the float32 filter build with and without its term table
-      timeout -k 10 400 python tools/filter_table_probe.py ${FT_N:-50000} 2>&1 | grep -v amdgpu.ids > $O/${TAG}_filter_table.txt; cat $O/${TAG}_filter_table.txt | cut -c1-420 ;;
     fphase)     # the default mode's filtered solves, query by query, side by side and alone
       echo "== solver threads pinned to one L3 domain each (the default)" > $O/${TAG}_filter_phases.txt
       timeout -k 10 300 python tools/filter_phase_probe.py ${FP_N:-50000} 2>&1 | grep -v amdgpu.ids >> $O/${TAG}_filter_phases.txt
