@@ -1107,18 +1107,21 @@ _PIN_LOCAL = threading.local()
 
 def set_pin_base(base):
     """For callers that run several registrations side by side (pipeline.estimate_transform_batch's workers): the solver threads
-    started from THIS thread take the L3 domains base, base + 1, ... instead of 0, 1, ... — workers then spread over the socket
-    instead of piling onto four domains."""
-    _PIN_LOCAL.base = int(base)
+    started from THIS thread take the L3 domains base, base + 1, ... instead of 0, 1, ...; None = do not pin them at all.
+    (Measured on BASELINE config 5, eight workers x four solver threads on a 16-CPU quota: pinned with spread bases 15.4
+    registrations/s unseeded, unpinned 17.9 — the pairs are small enough for any cache and the scheduler balances 32 threads better
+    than a fixed map; the batch driver passes None.)"""
+    _PIN_LOCAL.base = None if base is None else int(base)
 
 
 def _pin_base():
-    return int(getattr(_PIN_LOCAL, "base", 0))
+    return getattr(_PIN_LOCAL, "base", 0)
 
 
 def pin_solver_thread(slot):
-    """Restrict the CALLING thread to the slot-th L3 domain (no-op with fewer than two domains, off Linux, or PM_LSAP_PIN=0)."""
-    if not PIN_SOLVER_THREADS:
+    """Restrict the CALLING thread to the slot-th L3 domain (no-op for slot None, with fewer than two domains, off Linux, or
+    PM_LSAP_PIN=0)."""
+    if not PIN_SOLVER_THREADS or slot is None:
         return None
     doms = _l3_domains()
     if len(doms) < 2:
@@ -1166,7 +1169,7 @@ def solve_eight_on_device(U8, info=None, allow_host=True, accept_near_ties=False
     pin_base = _pin_base()
 
     def pair(h):
-        pin_solver_thread(pin_base + h)
+        pin_solver_thread(None if pin_base is None else pin_base + h)
         twin = [t for t, s in TWINS.items() if s == h][0]
         # persistent: the allocator's cache is per stream; pipelined behind the cost build the dense passes must get in front of it
         stream = nat.side_stream(U8.device, ("pair", caller, h), priority=PIPELINED_PRIORITY if ready is not None else 0)
@@ -1247,7 +1250,7 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
     pin_base = _pin_base()
 
     def pair(t):
-        pin_solver_thread(pin_base + t)
+        pin_solver_thread(None if pin_base is None else pin_base + t)
         h, twin = pairs[t]
         stream = nat.side_stream(device, ("pair", caller, h))
         with torch.cuda.device(device), torch.cuda.stream(stream):

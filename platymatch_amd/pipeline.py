@@ -1480,7 +1480,7 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
                 in_flight[0] += want
             try:
                 from . import lsap
-                lsap.set_pin_base(4 * worker_slot())                             # this worker's solver threads: L3 domains of their own
+                lsap.set_pin_base(None if (workers > 1 and len(ks) > 1) else 0)     # several registrations side by side: placement left to the scheduler (measured)
                 stream = nat.side_stream(dev, ("batch worker", worker_slot()))   # persistent per worker thread
                 with torch.cuda.device(dev), torch.cuda.stream(stream):
                     out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], details=det, options=opts, **kwargs)
