@@ -516,6 +516,7 @@ def main():
     # 160 GB of cost matrices still resident in HBM (device-resident route only: bounded, a hypothesis that cannot be certified
     # is reported, never handed to the hours-long dense solver).  One GPU only (sharded runs hold row blocks, not matrices).
     assignment = None
+    extra_hung = [False]
     if world == 1 and not args.no_assignment:
         from platymatch_amd import lsap as L
         torch.cuda.synchronize()
@@ -534,24 +535,38 @@ def main():
         # the eight assignments by the DEFAULT route of a sharded registration (cost_mode='auto': row blocks of the float32 filter on
         # their ranks, the root's queries answered by every rank, exact costs on the root; pipeline.assign_sharded_filtered) — or,
         # where the frames do not permute, by the exact sharded route on the row blocks of the timed build.  Untimed extra.
-        fence()
-        t_as = time.perf_counter()
-        a_info = {}
-        try:
-            if symmetric[0]:
-                lsa = P.assign_sharded_filtered(be, sc_m_last[0], sc_f_last[0], bn, group, info=a_info)
-            else:
-                lsa = P.assign(U, bn, group, info=a_info)
-            err = None
-        except Exception as e:      # noqa: BLE001 — an extra must not cost the headline line
-            lsa, err = None, "%s: %s" % (type(e).__name__, str(e)[:300])
-        fence()
-        t_as = time.perf_counter() - t_as
-        if world > 1:
-            t = torch.tensor([t_as], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-            t_as = float(t.item())
-        assignment = {"seconds": t_as, "route": "sharded filter (cost_mode='auto')" if symmetric[0] else "sharded exact", "error": err,
+        # Run under a WATCHDOG: this protocol has never met more than one real device under RCCL before the driver's scaling run; a
+        # collective that does not return must cost this extra, not the headline line — on a timeout every rank reports, rank 0 prints
+        # its line, and the process leaves without the closing barrier (PM_BENCH_EXTRA_TIMEOUT_S, default 300).
+        import threading
+        box = {}
+
+        def sharded_extra():
+            try:
+                torch.cuda.set_device(dev)
+                fence()
+                t0_ = time.perf_counter()
+                info_ = {}
+                if symmetric[0]:
+                    lsa_ = P.assign_sharded_filtered(be, sc_m_last[0], sc_f_last[0], bn, group, info=info_)
+                else:
+                    lsa_ = P.assign(U, bn, group, info=info_)
+                fence()
+                t_ = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=dev)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX, group=group)
+                box.update(seconds=float(t_.item()), lsa=lsa_, info=info_, error=None)
+            except Exception as e:      # noqa: BLE001 — an extra must not cost the headline line
+                box.update(seconds=None, lsa=None, info={}, error="%s: %s" % (type(e).__name__, str(e)[:300]))
+
+        th = threading.Thread(target=sharded_extra, name="pm-bench-sharded-extra", daemon=True)
+        th.start()
+        th.join(float(os.environ.get("PM_BENCH_EXTRA_TIMEOUT_S", "300")))
+        if th.is_alive():
+            extra_hung[0] = True
+            box.update(seconds=None, lsa=None, info={}, error="timed out after %s s (watchdog): the line is printed without this extra and the "
+                                                               "process exits without the closing barrier" % os.environ.get("PM_BENCH_EXTRA_TIMEOUT_S", "300"))
+        lsa, a_info = box.get("lsa"), box.get("info", {})
+        assignment = {"seconds": box.get("seconds"), "route": "sharded filter (cost_mode='auto')" if symmetric[0] else "sharded exact", "error": box.get("error"),
                       "routes": a_info.get("routes"), "mode": a_info.get("mode"),
                       "perfect_matchings": None if lsa is None else [bool(len(set(c.tolist())) == len(c)) for _, c in lsa],
                       "note": "the protocol of lsap_sharded.py timed at %d ranks: every query of the root's sparse-core solver is a broadcast + "
@@ -683,7 +698,9 @@ def main():
             "relaxed_cost_build_extra": relaxed_extra,
             "filter_cost_build_extra": filter_extra,
         }
-        if not args.no_cpu_baseline:           # (rank 0, whatever the world: a SCALE line carries its baseline too, VERDICT r04 next #2b)
+        if extra_hung[0]:
+            out["cpu_baseline"] = {"skipped": "the sharded extra's watchdog fired: nothing further touches the device in this process"}
+        elif not args.no_cpu_baseline:         # (rank 0, whatever the world: a SCALE line carries its baseline too, VERDICT r04 next #2b)
             # the chi-square leg of the CPU baseline runs on the real clouds' descriptors (the GPU's, verified equal to the oracle's
             # by the parity tests): >= 1 % of the N x M pairs of every matrix
             r_rows = max(1, min(n, (n + 99) // 100 + 12))
@@ -710,6 +727,9 @@ def main():
                                                       note="a complete 5 000-nucleus registration (seeded: the reference's RANSAC index sets), host oracle against "
                                                            "the product on this GPU; host arrays in, host arrays out")
         print(json.dumps(out), flush=True)
+    if extra_hung[0]:
+        sys.stdout.flush()
+        os._exit(0)                      # a collective of the extra never returned: no barrier can be trusted any more
     if world > 1:
         dist.barrier(group=group)
         dist.destroy_process_group()
