@@ -556,14 +556,25 @@ def certify_listed(M, u, v, col4row, exact_entries, cost_delta, infos=None):
 RESOLVE_MAX_BLOCK_ROWS = 4096      # largest set of rows (all near-tied groups together) settled by the dense algorithm on their block
 
 
-def _cyclic_groups(edges, owner):
+_F = -1        # the node "free columns / dummy rows" of the near-tie digraph (pm_lsap_unique's F)
+
+
+def _cyclic_groups(edges, owner, releasable=()):
     """Rows that lie on an alternating cycle of the digraph i -> owner(col) over the near-tight entries (row, col): the strongly
-    connected components with more than one row (iterative Tarjan over the rows that appear at all) -> list of sorted row arrays."""
+    connected components with more than one node (iterative Tarjan over the nodes that appear at all).  With spare columns the
+    digraph has one more node F (-1): i -> F for a near-tight entry into a column nobody holds, F -> i for every row in
+    `releasable` (rows whose held column is priced like a free one: a dummy row could take it at no cost) — a cycle through F is
+    an alternating PATH from a column that gets released to a column that gets taken.
+    -> list of (sorted row array, passes through F)."""
     succ = {}
     for i, j in edges:
         o = int(owner[int(j)])
         if o >= 0 and o != int(i):
             succ.setdefault(int(i), []).append(o)
+        elif o < 0 and len(releasable):
+            succ.setdefault(int(i), []).append(_F)
+    if len(releasable) and any(_F in nxt for nxt in succ.values()):
+        succ[_F] = [int(i) for i in releasable]
     index, low, on, order, groups = {}, {}, set(), [], []
     for root in list(succ):
         if root in index:
@@ -596,7 +607,7 @@ def _cyclic_groups(edges, owner):
                     if w == node:
                         break
                 if len(comp) > 1:
-                    groups.append(np.array(sorted(comp), dtype=np.int64))
+                    groups.append((np.array(sorted(x for x in comp if x != _F), dtype=np.int64), _F in comp))
     return groups
 
 
@@ -608,43 +619,50 @@ def resolve_near_ties(M, sol, info):
     spliced in: the answer where the reference always answers (_dock_widget.py:604-611), optimal to the certificate's bound, with
     the near-tie settled by the reference's solver on the entries that decide it.  (For an EXACT tie inside a block SciPy's pick on
     the block need not be its pick on the whole matrix: its tie-breaking follows the order of its augmentations.)
-    -> col4row, or None if it does not apply (no edges kept, an alternative through a spare column of a rectangular problem, groups beyond
-    RESOLVE_MAX_BLOCK_ROWS rows in all, a block the dense solver refuses)."""
+    Spare columns (nr < nc; round 5): an alternative may also RELEASE a held column that is priced like a free one and TAKE a
+    column nobody holds — an alternating path, a cycle through the node F of the digraph.  The rows on such cycles get a rectangular
+    block: their rows x (the columns they hold + the free columns they are near-tight on).
+    -> col4row, or None if it does not apply (no edges kept, groups beyond RESOLVE_MAX_BLOCK_ROWS rows in all, a block the dense
+    solver refuses)."""
     import math
     nr, nc = M.shape
     edges = info.get("_tight_edges")
     if edges is None or len(edges) == 0 or not hasattr(M, "entries"):
         return None
+    edges = np.asarray(edges)
     c4r = np.array(sol[2], dtype=np.int64, copy=True)
     owner = np.full(nc, -1, dtype=np.int64)
     owner[c4r] = np.arange(nr)
+    releasable = ()
     if nr < nc:
-        # spare columns: an alternative may also run through a column nobody holds (a near-tight entry into one, or a held column
-        # whose dual is within eps of the free columns' level: certify / pm_lsap_unique's node F) — those are not settled here
         v = np.asarray(sol[1])
         v_free = float(v[owner < 0].min())
-        into_free = bool((owner[np.asarray(edges)[:, 1]] < 0).any())                    # some row is near-tight on a column nobody holds
-        out_of_free = bool((v_free - v[owner >= 0] <= float(info.get("eps", 0.0))).any())   # some held column is priced like a free one
-        if into_free and out_of_free:                      # only then can a cycle pass through F
-            return None
-    groups = _cyclic_groups(np.asarray(edges), owner)
-    total = int(sum(len(g) for g in groups))
+        releasable = np.flatnonzero(v_free - v[c4r] <= float(info.get("eps", 0.0)))      # rows whose column a dummy row could take
+    groups = _cyclic_groups(edges, owner, releasable)
+    total = int(sum(len(g) for g, _ in groups))
     if not groups or total > RESOLVE_MAX_BLOCK_ROWS:
         return None
     changed = 0
-    for rows in groups:
-        cols = c4r[rows]
-        k = len(rows)
-        S = np.asarray(M.entries(np.repeat(rows, k), np.tile(cols, k)), dtype=np.float64).reshape(k, k)
+    for rows, through_free in groups:
+        held = c4r[rows]
+        cols = held
+        if through_free:
+            mine = np.isin(edges[:, 0], rows) & (owner[edges[:, 1]] < 0)
+            cols = np.concatenate([held, np.unique(edges[mine, 1]).astype(np.int64)])
+        k, kc = len(rows), len(cols)
+        S = np.asarray(M.entries(np.repeat(rows, kc), np.tile(cols, k)), dtype=np.float64).reshape(k, kc)
         try:
             r, c = linear_sum_assignment(S)
         except ValueError:
             return None
-        if math.fsum(S[r, c]) > math.fsum(np.diag(S)) + abs(info.get("eps", 0.0)) * k:      # cannot happen for a certified optimum
+        if math.fsum(S[r, c]) > math.fsum(S[np.arange(k), np.arange(k)]) + abs(info.get("eps", 0.0)) * k:      # cannot happen for a certified optimum
             return None
         changed += int((c != np.arange(k)).sum())
         c4r[rows[r]] = cols[c]
-    info["resolved_groups"] = [int(len(g)) for g in groups]
+    if len(np.unique(c4r)) != nr:                          # (two groups sharing a free column: not settled block by block)
+        return None
+    info["resolved_groups"] = [int(len(g)) for g, _ in groups]
+    info["resolved_through_spare_columns"] = int(sum(1 for _, f in groups if f))
     info["resolved_rows_moved"] = changed
     return c4r.astype(np.int32)
 

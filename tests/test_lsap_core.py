@@ -357,7 +357,34 @@ def test_near_ties_are_settled_on_their_blocks_by_the_dense_algorithm():
     sol = L.solve_core(M, info)
     assert not L.certify(M, *sol, info=info) and info["optimal"]
     got = L.resolve_near_ties(M, sol, info)
-    assert got is None or (info["resolved_groups"] == [2] and np.array_equal(got, scipy_lsa(R2)[1]))
+    assert got is not None and 2 in info["resolved_groups"] and np.array_equal(got, scipy_lsa(R2)[1])
+    # round 5: an alternative THROUGH a spare column — a row whose own column is priced like a free one (a dummy row could take it
+    # at no cost) is also near-tight on a column nobody holds: releasing one and taking the other is an alternating path, a cycle
+    # through the digraph's node F.  The row gets a rectangular block (its column + the free column) and SciPy's algorithm decides.
+    settled = 0
+    for seed in range(40):
+        rg = np.random.default_rng(500 + seed)
+        R = rg.random((40, 50)) + 0.5
+        u, v, c = L.solve_core(HostMatrix(R))
+        free = np.setdiff1d(np.arange(50), c)
+        v_free = v[free].min()
+        cand = [i for i in range(40) if v[c[i]] == v_free]          # rows holding a column at the free columns' level
+        if not cand:
+            continue
+        for sign in (+1.0, -1.0):
+            R3 = R.copy()
+            i, f = cand[0], int(free[seed % len(free)])
+            R3[i, f] = (u[i] + v[f]) + sign * 1e-14                  # row i is indifferent (to 1e-14) between its column and the free one
+            M = HostMatrix(R3)
+            info = {}
+            sol = L.solve_core(M, info)
+            if sol is None or L.certify(M, *sol, info=info) or not info.get("optimal"):
+                continue
+            got = L.resolve_near_ties(M, sol, info)
+            assert got is not None, (seed, sign, info)
+            assert np.array_equal(got, scipy_lsa(R3)[1]), (seed, sign)
+            settled += int(info.get("resolved_through_spare_columns", 0) > 0)
+    assert settled >= 5                                              # the spare-column route was really exercised
 
 
 @pytest.mark.parametrize("shape", [(300, 300), (257, 300), (300, 257), (900, 900)])
