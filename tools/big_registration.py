@@ -21,7 +21,7 @@ from platymatch_amd.estimate_transform import perform_icp as pi  # noqa: E402
 n = int(sys.argv[1])
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 8000
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-cost_mode = sys.argv[4] if len(sys.argv) > 4 else "exact"
+cost_mode = sys.argv[4] if len(sys.argv) > 4 else "auto"
 pi.VERBOSE = False
 t_start = time.perf_counter()
 stop = threading.Event()
