@@ -267,6 +267,28 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
         }
     }
 
+    // PREFETCH (the exact kernels at two waves per SIMD): a thread's share of a computed stage's staging — one double of the tile's
+    // moving rows (threads 0..191), one or two double2 of its fixed rows — travels through registers one computed stage ahead
+    constexpr bool PF = !RELAX && MINW == 2 && SY_RI == 4;
+    static_assert(!PF || (SY_TI * CH_K <= CH_THREADS && CH_TJ * (CH_K / 2) <= 2 * CH_THREADS), "one A value and at most two B pairs per thread");
+    double pf_a = 0.0;
+    double2 pf_b0 = {0.0, 0.0}, pf_b1 = {0.0, 0.0};
+    const int pf_ia = (tid < SY_TI * CH_K) ? tid : -1;                                   // flat index into A_s[SY_TI][CH_K]
+    const int pf_j0 = tid / (CH_K / 2), pf_k0 = 2 * (tid - pf_j0 * (CH_K / 2));
+    const int pf_e1 = tid + CH_THREADS;
+    const int pf_j1 = (pf_e1 < CH_TJ * (CH_K / 2)) ? pf_e1 / (CH_K / 2) : -1;
+    const int pf_k1 = (pf_j1 >= 0) ? 2 * (pf_e1 - pf_j1 * (CH_K / 2)) : 0;
+    auto prefetch = [&](int gs) {
+        if (pf_ia >= 0) pf_a = scA[(size_t)min(i0 + pf_ia / CH_K, nA - 1) * PM_NBINS + gs * CH_K + (pf_ia % CH_K)];
+        pf_b0 = *reinterpret_cast<const double2 *>(scB + (size_t)min(j0 + pf_j0, nB - 1) * PM_NBINS + gs * CH_K + pf_k0);
+        if (pf_j1 >= 0) pf_b1 = *reinterpret_cast<const double2 *>(scB + (size_t)min(j0 + pf_j1, nB - 1) * PM_NBINS + gs * CH_K + pf_k1);
+    };
+    if constexpr (PF) {
+        int g0 = 0;
+        while (g0 < CH_STAGES && ((tabmask >> g0) & 1u)) ++g0;
+        if (g0 < CH_STAGES) prefetch(g0);
+    }
+
     for (int g = 0; g < CH_STAGES; ++g) {
         if constexpr (TL > 0) {
             if ((tabmask >> g) & 1u) {
@@ -338,19 +360,44 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
                 continue;                 // uniform over the workgroup: nothing staged, no barrier
             }
         }
-        __syncthreads();
-        for (int e = tid; e < SY_TI * CH_K; e += CH_THREADS) {
-            const int r = e / CH_K, k = e - r * CH_K;
-            A_s[r][k] = scA[(size_t)min(i0 + r, nA - 1) * PM_NBINS + g * CH_K + k];
+        if constexpr (PF) {
+            // this stage's values were fetched into registers while the previous computed stage ran (or before the loop): park them
+            // in LDS between two barriers, then start the NEXT computed stage's fetch — its L2 / HBM round trip runs under this
+            // stage's ~10 000 cycles of arithmetic instead of in front of them (round 5: both workgroups of a CU used to meet their
+            // load phases with nothing to issue; same values, same operations, same bits)
+            __syncthreads();
+            if (pf_ia >= 0) A_s[pf_ia / CH_K][pf_ia % CH_K] = pf_a;
+            {
+                double2 v = pf_b0;
+                v.x = (v.x == 0.0) ? CH_TINY : v.x;
+                v.y = (v.y == 0.0) ? CH_TINY : v.y;
+                *reinterpret_cast<double2 *>(&B_s[pf_j0][pf_k0]) = v;
+                if (pf_j1 >= 0) {
+                    v = pf_b1;
+                    v.x = (v.x == 0.0) ? CH_TINY : v.x;
+                    v.y = (v.y == 0.0) ? CH_TINY : v.y;
+                    *reinterpret_cast<double2 *>(&B_s[pf_j1][pf_k1]) = v;
+                }
+            }
+            __syncthreads();
+            int gn = g + 1;
+            while (gn < CH_STAGES && ((tabmask >> gn) & 1u)) ++gn;
+            if (gn < CH_STAGES) prefetch(gn);
+        } else {
+            __syncthreads();
+            for (int e = tid; e < SY_TI * CH_K; e += CH_THREADS) {
+                const int r = e / CH_K, k = e - r * CH_K;
+                A_s[r][k] = scA[(size_t)min(i0 + r, nA - 1) * PM_NBINS + g * CH_K + k];
+            }
+            for (int e = tid; e < CH_TJ * (CH_K / 2); e += CH_THREADS) {
+                const int j = e / (CH_K / 2), kk = e - j * (CH_K / 2);
+                double2 v = *reinterpret_cast<const double2 *>(scB + (size_t)min(j0 + j, nB - 1) * PM_NBINS + g * CH_K + 2 * kk);
+                v.x = (v.x == 0.0) ? CH_TINY : v.x;
+                v.y = (v.y == 0.0) ? CH_TINY : v.y;
+                *reinterpret_cast<double2 *>(&B_s[j][2 * kk]) = v;
+            }
+            __syncthreads();
         }
-        for (int e = tid; e < CH_TJ * (CH_K / 2); e += CH_THREADS) {
-            const int j = e / (CH_K / 2), kk = e - j * (CH_K / 2);
-            double2 v = *reinterpret_cast<const double2 *>(scB + (size_t)min(j0 + j, nB - 1) * PM_NBINS + g * CH_K + 2 * kk);
-            v.x = (v.x == 0.0) ? CH_TINY : v.x;
-            v.y = (v.y == 0.0) ? CH_TINY : v.y;
-            *reinterpret_cast<double2 *>(&B_s[j][2 * kk]) = v;
-        }
-        __syncthreads();
         double b[CH_K];
 #pragma unroll
         for (int k = 0; k < CH_K; k += 2) {
