@@ -104,23 +104,34 @@ def _message(words):
     return raw.split(b"\0", 1)[0].decode("utf-8", "replace")
 
 
-def _query(wire, locals_, request=None):
+def _header_of(request):
+    """(op, which, arguments) -> the five integers every rank needs to shape the query's buffers."""
+    op, which, args = request
+    return (int(op), int(which), int(args.get("k", args.get("cap", 0))), int(len(args["rows"])) if "rows" in args else 0,
+            1 if args.get("v") is not None else 0)
+
+
+def _query(wire, locals_, request=None, header=None):
     """One query, executed by EVERY rank: the root passes request = (op, which, dict of arguments), the workers None.
+    header: the query's five integers when every rank knows them already (the multiplexed driver below exchanges the headers of
+    all pairings in one all-reduce); None: the root broadcasts them first.
     -> ("stop", None) / (op, gathered answer on the root | None elsewhere).  All collectives of the query complete on every rank
     before the root raises a rank's failure."""
     torch = _torch()
     i64, i32, f64 = torch.int64, torch.int32, torch.float64
     args = {}
     if wire.is_root:
-        op, which, args = request
-        h = np.zeros(8, dtype=np.int64)
-        h[:5] = (op, which, int(args.get("k", args.get("cap", 0))), int(len(args["rows"])) if "rows" in args else 0,
-                 1 if args.get("v") is not None else 0)
-        hdr = wire.tensor(h, i64)
-    else:
-        hdr = wire.empty(8, i64)
-    wire.bcast(hdr)
-    op, which, a, n_listed, has_v = (int(x) for x in _host(hdr)[:5])
+        args = request[2]
+    if header is None:
+        if wire.is_root:
+            h = np.zeros(8, dtype=np.int64)
+            h[:5] = _header_of(request)
+            hdr = wire.tensor(h, i64)
+        else:
+            hdr = wire.empty(8, i64)
+        wire.bcast(hdr)
+        header = tuple(int(x) for x in _host(hdr)[:5])
+    op, which, a, n_listed, has_v = header
     if op == OP_STOP:
         return "stop", None
     nr, nc, rows, row0, big = wire.nr, wire.nc, wire.rows, wire.row0, wire.biggest
@@ -410,3 +421,156 @@ def solve_pair_sharded_filtered(local_filter, exact_entries, cost_delta, bounds,
     else:
         serve(locals_, wire)
     return _share_result(wire, out, root)
+
+
+# ---- several pairings at once over ONE ordered sequence of collectives (round 5) ----------------------------------------------------
+# solve_pair_sharded(_filtered) settles one pairing at a time: its root's host solver (0.3-0.4 s at 50 000 nuclei) runs while every
+# other rank waits for the next query, and the four pairings of a registration follow one another — a sharded 50k registration then
+# costs 4 x the one-GPU critical path.  Here the roots (pairing t -> rank t mod G) run their host solvers CONCURRENTLY, each on a
+# thread of its own rank, and one loop on every rank serves all of them: per round ONE all-reduce carries the pending query headers
+# of all pairings (a root with nothing to ask contributes zeros), then the pending queries are answered in pairing order with
+# exactly the collectives of _query.  Every rank issues the same collectives in the same order on one communicator — no second
+# communicator, no tags — and a root waits at most one round (~0.1 ms) for its turn.
+class _Channel:
+    """Between a root's solver thread and the serving loop of its rank."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.asked = threading.Event()
+        self.answered = threading.Event()
+        self.request = None              # (op, which, args) | "done"
+        self.answer = None               # the gathered answer | an exception to raise in the solver
+
+    def ask(self, request):              # solver thread
+        with self.lock:
+            self.request = request
+            self.answered.clear()
+            self.asked.set()
+        self.answered.wait()
+        ans, self.answer = self.answer, None
+        if isinstance(ans, BaseException):
+            raise ans
+        return ans
+
+    def pending(self):                   # serving loop: the request waiting for service, or None
+        return self.request if self.asked.is_set() else None
+
+    def deliver(self, answer):           # serving loop
+        with self.lock:
+            self.request = None
+            self.asked.clear()
+            self.answer = answer
+            self.answered.set()
+
+    def finish(self):                    # solver thread: nothing more to ask
+        with self.lock:
+            self.request = "done"
+            self.asked.set()
+
+
+class MultiplexedMatrix(ShardedMatrix):
+    """ShardedMatrix whose queries go through the serving loop of solve_pairs_sharded_filtered instead of straight onto the wire."""
+
+    def __init__(self, locals_, which, wire, channel):
+        super().__init__(locals_, which, wire)
+        self.channel = channel
+
+    def _ask(self, op, **args):
+        return self.channel.ask((op, self.which, args))
+
+
+def solve_pairs_sharded_filtered(jobs, group, cost_delta, poll_s=1e-4):
+    """Several pairings from row blocks of their filter matrices, the roots' host solvers running concurrently.
+    jobs: list of dicts {local: this rank's block of the pairing's filter matrix, exact_entries: (rows, cols) -> (exact hypothesis
+    values, exact twin values) — called on the pairing's root only —, bounds, n_cols, root, info (dict or None), device / stream
+    (optional: the GPU and stream the root's exact evaluations belong to — a new thread would start on device 0's default stream)}.
+    -> list of (col4row, col4row) | (None, None) per job, on every rank (as solve_pair_sharded_filtered)."""
+    import threading
+    import time
+    torch, dist = _torch(), _dist()
+    wires = [_Wire(j["bounds"], j["n_cols"], group, j["root"]) for j in jobs]
+    n_jobs = len(jobs)
+    outs = [[None, None, None] for _ in jobs]
+    channels = [(_Channel() if w.is_root else None) for w in wires]
+    threads = []
+    my_roots = [k for k, w in enumerate(wires) if w.is_root]
+    pin_base = lsap._pin_base()
+
+    def solver(k, slot):
+        job = jobs[k]
+        dev, stream = job.get("device"), job.get("stream")
+        if dev is not None:                                   # the root's exact evaluations run on the caller's device and stream
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                return solver_body(k, slot)
+        return solver_body(k, slot)
+
+    def solver_body(k, slot):
+        lsap.pin_solver_thread(None if pin_base is None else pin_base + slot)
+        job, out, ch = jobs[k], outs[k], channels[k]
+        try:
+            info = job["info"] if job.get("info") is not None else {}
+            tinfo = info["twin"] = {}
+            M = lsap.FilteredMatrix(MultiplexedMatrix([job["local"]], 0, wires[k], ch), job["exact_entries"], cost_delta)
+            sol = lsap.solve_core(M, info)
+            if sol is not None:
+                ok = lsap.certify_listed(M, *sol, exact_entries=job["exact_entries"], cost_delta=cost_delta, infos=[info, tinfo])
+                if len(ok) == 2 and all(ok):
+                    out[0] = out[1] = sol[2]
+                    info["exact_evaluated"] = M.exact_evaluated
+        except Exception as e:           # noqa: BLE001 — travels to every rank through _share_result
+            out[2] = "%s: %s" % (type(e).__name__, e)
+        finally:
+            ch.finish()
+
+    for slot, k in enumerate(my_roots):
+        th = threading.Thread(target=solver, args=(k, slot), name="pm-sharded-root-%d" % k, daemon=True)
+        th.start()
+        threads.append(th)
+    w0 = wires[0]
+    active = set(range(n_jobs))
+    results = [None] * n_jobs
+    failure = None
+    while active:
+        h = np.zeros((n_jobs, 8), dtype=np.int64)
+        asked = {}
+        for k in my_roots:
+            if k not in active:
+                continue
+            req = channels[k].pending()
+            if req is None:
+                continue
+            asked[k] = req
+            h[k, 0] = 1
+            h[k, 1:6] = (OP_STOP, 0, 0, 0, 0) if req == "done" else _header_of(req)
+        hdr = w0.tensor(h, torch.int64)
+        dist.all_reduce(hdr, op=dist.ReduceOp.SUM, group=group)
+        hh = _host(hdr)
+        if not hh[:, 0].any():
+            time.sleep(poll_s)               # every root is in its host phase: do not spin on the wire
+            continue
+        for k in sorted(active):
+            if not hh[k, 0]:
+                continue
+            header = tuple(int(x) for x in hh[k, 1:6])
+            if header[0] == OP_STOP:
+                try:
+                    results[k] = _share_result(wires[k], outs[k], jobs[k]["root"])
+                except RuntimeError as e:     # the root's solver failed: raised on every rank, after the other pairings are through
+                    failure = failure or e
+                    results[k] = (None, None)
+                active.discard(k)
+                continue
+            try:
+                _, ans = _query(wires[k], [jobs[k]["local"]], asked.get(k), header=header)
+                if wires[k].is_root:
+                    channels[k].deliver(ans)
+            except RuntimeError as e:         # a rank's share failed: every collective of the query has completed everywhere
+                if wires[k].is_root:
+                    channels[k].deliver(e)
+    for th in threads:
+        th.join()
+    if failure is not None:
+        raise failure
+    return results
+

@@ -661,6 +661,9 @@ def cost_row_argmins(be, mov, fix, rows_per_block=None, group=None):
     return all_gather_rows(idx, bn, 1, group)
 
 
+# the four pairings of a sharded filter-route registration with their roots' host solvers side by side (round 5); PM_SHARDED_SEQUENTIAL=1:
+# one pairing after the other (round 5's first form; the A/B switch)
+SHARDED_PAIRINGS_CONCURRENT = os.environ.get("PM_SHARDED_SEQUENTIAL") != "1"
 SHARDED_ASSIGN_MIN_ROWS = 1024     # below this the gather + dense host solve is quicker than the sharded solve's round trips
 
 
@@ -1121,17 +1124,35 @@ def assign_sharded_filtered(be, sc_m, sc_f, bounds, group, streamed=False, info=
     buf = None
     out, routes, details = [None] * 8, [None] * 8, [dict() for _ in range(8)]
     fallback = []
-    for t, (h, twin) in enumerate(PAIRINGS):
-        if F4 is not None:
-            Ft = F4[t]
-        else:
-            Ft = buf = be.chi2_filter_pair(a_loc, b_all, t, out=buf, dtype=_filter_dtype())
 
-        def fetch(rows, cols, t=t):         # (root only) exact entries of the SHORT-side-by-long-side problem the solver sees
+    def fetcher(t):
+        def fetch(rows, cols):              # (root only) exact entries of the SHORT-side-by-long-side problem the solver sees
             r, c = (rows, cols) if n <= m else (cols, rows)
             return tuple(np.asarray(x.cpu().numpy() if nat.is_torch(x) else x, dtype=np.float64) for x in be.chi2_entries(sc_m1_full, sc_f1, t, r, c))
-        pinfo = {}
-        c_h, c_t = solve_pair_sharded_filtered(lm(Ft), fetch, delta, rb, max(n, m), group, t % world, pinfo)
+        return fetch
+
+    together = None
+    pinfos = [dict() for _ in range(4)]
+    if F4 is not None and SHARDED_PAIRINGS_CONCURRENT:
+        # all four pairings at once: the roots' host solvers run concurrently (pairing t on rank t mod G, a thread each), one serving
+        # loop per rank answers their queries in turn (lsap_sharded.solve_pairs_sharded_filtered)
+        from .lsap_sharded import solve_pairs_sharded_filtered
+        on_gpu = bool(getattr(sc_f1, "is_cuda", False))
+        import torch
+        jobs = [dict(local=lm(F4[t]), exact_entries=fetcher(t), bounds=rb, n_cols=max(n, m), root=t % world, info=pinfos[t],
+                     device=sc_f1.device if on_gpu else None, stream=torch.cuda.current_stream(sc_f1.device) if on_gpu else None)
+                for t in range(4)]
+        together = solve_pairs_sharded_filtered(jobs, group, delta)
+    for t, (h, twin) in enumerate(PAIRINGS):
+        pinfo = pinfos[t]
+        if together is not None:
+            c_h, c_t = together[t]
+        else:
+            if F4 is not None:
+                Ft = F4[t]
+            else:
+                Ft = buf = be.chi2_filter_pair(a_loc, b_all, t, out=buf, dtype=_filter_dtype())
+            c_h, c_t = solve_pair_sharded_filtered(lm(Ft), fetcher(t), delta, rb, max(n, m), group, t % world, pinfo)
         if c_h is None or c_t is None:
             fallback.append(t)
             continue
@@ -1151,7 +1172,8 @@ def assign_sharded_filtered(be, sc_m, sc_f, bounds, group, streamed=False, info=
                 details[k]["cost_mode"] = "exact (built: the filtered solve did not certify)"
     if info is not None:
         info["routes"], info["details"] = routes, details
-        info["mode"] = "sharded filter: %s" % ("one pairing's row block resident at a time" if streamed else "four row blocks resident")
+        info["mode"] = "sharded filter: %s" % ("one pairing's row block resident at a time" if streamed else
+                                               "four row blocks resident" + (", roots' solvers side by side" if together is not None else ""))
     return out
 
 

@@ -436,7 +436,14 @@ def _pair_worker(rank, world, port, out_path):
         res["AB"] = solve_pair_sharded(blk(A), blk(B), b, m, dist.group.WORLD, 1, info)
         if rank == 1:
             assert info["twin"]["route"] == "own core" and info["near_tie"] == []
-        res["AT"] = solve_pair_sharded(blk(A), blk(T), b, m, dist.group.WORLD, 0)
+        # the twin's near-tie is SETTLED on its 2 x 2 block (lsap.resolve_near_ties; round 5: also with spare columns in play) ...
+        info = {}
+        res["AT"] = solve_pair_sharded(blk(A), blk(T), b, m, dist.group.WORLD, 0, info)
+        if rank == 0:
+            assert info["near_tie"] == [] and "settled" in info["twin"].get("route", "") + str(info.get("route", "")) or res["AT"][1] is not None
+        # ... and where it cannot be (block size limit lowered to nothing): refused by default, accepted as the certified optimum on request
+        L.RESOLVE_MAX_BLOCK_ROWS = 0
+        res["AT_refused"] = solve_pair_sharded(blk(A), blk(T), b, m, dist.group.WORLD, 0)
         info = {}
         res["AT_accept"] = solve_pair_sharded(blk(A), blk(T), b, m, dist.group.WORLD, 0, info, accept_near_ties=True)
         if rank == 0:
@@ -456,7 +463,10 @@ def test_sharded_pair_solves_an_unrelated_twin_on_its_own_core_and_flags_near_ti
         assert np.array_equal(r0[k], r1[k]), k                                  # every rank holds the same answers
     A, B, T = r0["A"], r0["B"], r0["T"]
     assert np.array_equal(r0["AB0"], scipy_lsa(A)[1]) and np.array_equal(r0["AB1"], scipy_lsa(B)[1])
-    assert np.array_equal(r0["AT0"], scipy_lsa(A)[1]) and np.array_equal(r0["AT1"], [-1])       # near-tie: refused by default
+    rows = np.arange(A.shape[0])
+    assert np.array_equal(r0["AT0"], scipy_lsa(A)[1])
+    assert abs(T[rows, r0["AT1"]].sum() - T[scipy_lsa(T)].sum()) < 1e-12 * len(rows)             # near-tie: settled on its block
+    assert np.array_equal(r0["AT_refused0"], scipy_lsa(A)[1]) and np.array_equal(r0["AT_refused1"], [-1])    # cannot be settled: refused by default
     rows = np.arange(A.shape[0])
     assert abs(T[rows, r0["AT_accept1"]].sum() - T[scipy_lsa(T)].sum()) < 1e-12 * len(rows)      # accepted: optimal to rounding
 
@@ -514,7 +524,68 @@ def test_a_query_that_fails_on_one_rank_is_raised_on_all_and_leaves_no_rank_behi
     assert np.array_equal(r0["c"], r1["c"]) and np.array_equal(r0["c"], scipy_lsa(r0["A"])[1])
 
 
-def _more_moving_worker(rank, world, port, out_path, filtered=False):
+def _multiplexed_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from platymatch_amd import pipeline as P
+        from platymatch_amd.lsap_sharded import solve_pairs_sharded_filtered
+        from test_lsap_core import HostMatrix
+
+        class Breaks(HostMatrix):
+            def __init__(self, X, broken):
+                super().__init__(X)
+                self.broken = broken
+
+            def certificate(self, *a):
+                if self.broken:
+                    raise MemoryError("no room for the listing pass")
+                return super().certificate(*a)
+
+        rng = np.random.default_rng(29)
+        n, m = 130, 150
+        C = [rng.random((n, m)) + 0.5 for _ in range(3)]                      # three unrelated "pairings", exact matrices
+        F = [c.astype(np.float32).astype(np.float64) for c in C]              # their filters: float32 roundings (within 6e-8)
+        b = P.shard_bounds(n, world)
+        msgs = []
+
+        def jobs(broken):
+            return [dict(local=Breaks(F[k][b[rank]:b[rank + 1]], broken == (k, rank)), exact_entries=(lambda rows, cols, k=k: (C[k][rows, cols], C[k][rows, cols] + 0.0)),
+                         bounds=b, n_cols=m, root=k % world, info={}) for k in range(3)]
+        good = solve_pairs_sharded_filtered(jobs(None), dist.group.WORLD, 1.2e-7)
+        try:                                                                   # pairing 1 (root: rank 1): rank 0's share of its listing pass fails
+            solve_pairs_sharded_filtered(jobs((1, 0)), dist.group.WORLD, 1.2e-7)
+            msgs.append("no error")
+        except RuntimeError as e:
+            msgs.append(str(e))
+        again = solve_pairs_sharded_filtered(jobs(None), dist.group.WORLD, 1.2e-7)   # the group is still usable
+        np.savez(out_path % rank, msgs=np.array(msgs), C=np.stack(C), good=np.stack([g[0] for g in good]), twin=np.stack([g[1] for g in good]),
+                 again=np.stack([g[0] for g in again]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multiplexed_roots_solve_side_by_side_and_a_failing_share_is_raised_on_all(tmp_path):
+    """lsap_sharded.solve_pairs_sharded_filtered (round 5): three pairings whose roots' host solvers run concurrently on two ranks
+    (rank 0 roots two of them on two threads), every query served in turn over ONE sequence of collectives: SciPy's answers on the
+    exact matrices; a share that fails inside one pairing's query reaches that pairing's root, comes back as an error on EVERY rank
+    after the other pairings have finished, and leaves the group usable."""
+    from scipy.optimize import linear_sum_assignment as scipy_lsa
+    out = str(tmp_path / "x%d.npz")
+    mp.spawn(_multiplexed_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    for k in ("good", "twin", "again", "msgs"):
+        assert np.array_equal(r0[k], r1[k]), k
+    for k in range(3):
+        want = scipy_lsa(r0["C"][k])[1]
+        assert np.array_equal(r0["good"][k], want) and np.array_equal(r0["twin"][k], want) and np.array_equal(r0["again"][k], want), k
+    assert "MemoryError" in str(r0["msgs"][0]) and "rank 0" in str(r0["msgs"][0])
+
+
+def _more_moving_worker(rank, world, port, out_path, filtered=False, streamed=True):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -533,28 +604,30 @@ def _more_moving_worker(rank, world, port, out_path, filtered=False):
             add_filter_double(be, P)
         det = {}
         A_sc, A_icp, inl = P.estimate_transform(mov, fix, ransac_trials=200, ransac_error=8.0, icp_iterations=6, seed=4, details=det,
-                                                group=dist.group.WORLD, options={"backend": be, "stream_hypotheses": True})
+                                                group=dist.group.WORLD, options={"backend": be, "stream_hypotheses": streamed})
         np.savez(out_path % rank, A_sc=np.asarray(A_sc), A_icp=np.asarray(A_icp), inl=inl,
                  rows=np.stack([r for r, _ in det["lsa"]]), cols=np.stack([c for _, c in det["lsa"]]),
-                 routes=np.array(det["assignment"]["routes"]))
+                 routes=np.array(det["assignment"]["routes"]), mode=np.array(str(det["assignment"].get("mode"))))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,filtered", [(2, False), (3, False), (2, True), (3, True)])
-def test_sharded_streamed_assignment_with_more_moving_than_fixed_points(tmp_path, oracle, world, filtered):
+@pytest.mark.parametrize("world,filtered,streamed", [(2, False, True), (3, False, True), (2, True, True), (3, True, True), (3, True, False)])
+def test_sharded_streamed_assignment_with_more_moving_than_fixed_points(tmp_path, oracle, world, filtered, streamed):
     """VERDICT r02 missing #4: config 4's code path (hypotheses streamed two at a time, rows sharded, nothing gathered) for N > M.
     The solver needs the short side as rows, so the ranks build the TRANSPOSED matrices (chi-square is symmetric bit for bit) on
     blocks of fixed rows.  Assignments must equal SciPy's on the oracle's N x M matrices, on every rank."""
     from scipy.optimize import linear_sum_assignment as scipy_lsa
     out = str(tmp_path / "m%d.npz")
-    mp.spawn(_more_moving_worker, args=(world, _free_port(), out, filtered), nprocs=world, join=True)
+    mp.spawn(_more_moving_worker, args=(world, _free_port(), out, filtered, streamed), nprocs=world, join=True)
     res = [np.load(out % r) for r in range(world)]
     for r in res[1:]:
         for k in ("A_sc", "A_icp", "inl", "rows", "cols"):
             assert np.array_equal(r[k], res[0][k]), k
-    if filtered:         # the filter route with the FIXED rows sharded (roles swapped), one pairing's block at a time
+    if filtered:         # the filter route with the FIXED rows sharded (roles swapped): one pairing's block at a time, or — resident —
+        # all four pairings with their roots' solvers side by side on three ranks (lsap_sharded.solve_pairs_sharded_filtered)
         assert all("(filter" in str(x) for x in res[0]["routes"]), res[0]["routes"]
+        assert ("side by side" in str(res[0]["mode"])) == (not streamed), res[0]["mode"]
     else:
         assert all("transposed" in str(x) for x in res[0]["routes"])
     d = load_golden("synth96x128")
