@@ -320,12 +320,15 @@ def _settle(M, sol, info, out, slot):
     return True
 
 
-def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=None, accept_near_ties=False):
+def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=None, accept_near_ties=False, settle_near_ties=True):
     """One hypothesis and (optionally) its twin, rows sharded: the root solves the first on its sparse core and certifies the
     result on both matrices; a twin that does not accept its sibling's duals is solved on its own core.  -> (col4row of the
     hypothesis or None, col4row of the twin or None) on EVERY rank; None = not certified (the caller takes another route
     for that matrix).  N <= M required.  accept_near_ties: an assignment certified optimal but not proven unique
-    (lsap.certify: info["optimal"]) is returned instead of None; info["near_tie"] lists which (0 = hypothesis, 1 = twin)."""
+    (lsap.certify: info["optimal"]) is returned instead of None; info["near_tie"] lists which (0 = hypothesis, 1 = twin).
+    settle_near_ties: a certified optimum with alternatives inside the margin is settled on the blocks its near-tight entries connect
+    (lsap.resolve_near_ties).  Callers that CAN hand the whole matrix to SciPy's algorithm instead (it fits the dense solver) pass
+    False and take that route — for exact ties SciPy's pick on a block need not be its pick on the whole matrix."""
     wire = _Wire(bounds, n_cols, group, root)
     locals_ = [local_h] + ([local_twin] if local_twin is not None else [])
     out = [None, None, None]                              # col4row, twin's col4row, error message
@@ -338,7 +341,7 @@ def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=No
             certified = sol is not None and lsap.certify(M, *sol, info=info)
             if certified:
                 out[0] = sol[2]
-            elif sol is not None and info.get("optimal") and _settle(M, sol, info, out, 0):
+            elif settle_near_ties and sol is not None and info.get("optimal") and _settle(M, sol, info, out, 0):
                 pass                                      # near-ties settled on their blocks (lsap.resolve_near_ties: a few entries travel)
             elif accept_near_ties and sol is not None and info.get("optimal"):
                 out[0] = sol[2]
@@ -354,7 +357,7 @@ def solve_pair_sharded(local_h, local_twin, bounds, n_cols, group, root, info=No
                     sol_t = lsap.solve_core(Mt, tinfo)
                     if sol_t is not None and lsap.certify(Mt, *sol_t, info=tinfo):
                         out[1] = sol_t[2]
-                    elif sol_t is not None and tinfo.get("optimal") and _settle(Mt, sol_t, tinfo, out, 1):
+                    elif settle_near_ties and sol_t is not None and tinfo.get("optimal") and _settle(Mt, sol_t, tinfo, out, 1):
                         pass
                     elif accept_near_ties and sol_t is not None and tinfo.get("optimal"):
                         out[1] = sol_t[2]

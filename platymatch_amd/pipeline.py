@@ -542,7 +542,8 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
             UT_h = be.chi2_cost_single(f_loc[bh], sc_m_full[ah])                      # [M_g, N] = U_h[:, block]^T
             UT_t = be.chi2_cost_single(f_loc[bt], sc_m_full[at])
             ih = {}
-            c_h, c_t = solve_pair_sharded(lm(UT_h), lm(UT_t), bm, n, group, h % world, ih, accept_near_ties=accept_near_ties)
+            c_h, c_t = solve_pair_sharded(lm(UT_h), lm(UT_t), bm, n, group, h % world, ih, accept_near_ties=accept_near_ties,
+                                          settle_near_ties=n * m > lsap.DENSE_FALLBACK_MAX_ENTRIES)
             for idx, c4r, UT in ((h, c_h, UT_h), (twin, c_t, UT_t)):
                 if c4r is None and n * m <= lsap.DENSE_FALLBACK_MAX_ENTRIES and getattr(UT, "is_cuda", False):
                     # ties / near-ties the sharded scheme cannot settle, and a matrix the dense solver can take: the blocks of
@@ -572,7 +573,8 @@ def assign_streamed(be, sc_m, sc_f, bounds, group=None, info=None, local_matrix=
         else:
             from .lsap_sharded import solve_pair_sharded
             lm = local_matrix or lsap.DeviceMatrix
-            c_h, c_t = solve_pair_sharded(lm(U2[0]), lm(U2[1]), bounds, m, group, h % world, ih, accept_near_ties=accept_near_ties)
+            c_h, c_t = solve_pair_sharded(lm(U2[0]), lm(U2[1]), bounds, m, group, h % world, ih, accept_near_ties=accept_near_ties,
+                                          settle_near_ties=n * m > lsap.DENSE_FALLBACK_MAX_ENTRIES)
             rows = np.arange(n, dtype=np.int64)
             got = [None if c_h is None else (rows, np.asarray(c_h, dtype=np.int64)),
                    None if c_t is None else (rows, np.asarray(c_t, dtype=np.int64))]
@@ -698,12 +700,13 @@ def assign(U_loc, bounds, group=None, info=None, local_matrix=None, accept_near_
     if local_matrix is None and U_loc.is_cuda:
         from .lsap import DeviceMatrix as local_matrix
     if local_matrix is not None and n <= U_loc.shape[2] and n >= SHARDED_ASSIGN_MIN_ROWS:
-        from .lsap import TWINS
+        from .lsap import TWINS, DENSE_FALLBACK_MAX_ENTRIES as DENSE_FALLBACK_MAX
         from .lsap_sharded import solve_pair_sharded
         routes = {}
         for twin, h in sorted(TWINS.items(), key=lambda kv: kv[1]):
             pinfo = {} if info is not None else None
-            c_h, c_t = solve_pair_sharded(local_matrix(U_loc[h]), local_matrix(U_loc[twin]), bounds, U_loc.shape[2], group, h % world, pinfo)
+            c_h, c_t = solve_pair_sharded(local_matrix(U_loc[h]), local_matrix(U_loc[twin]), bounds, U_loc.shape[2], group, h % world, pinfo,
+                                          settle_near_ties=n * U_loc.shape[2] > DENSE_FALLBACK_MAX)     # (else: gathered below, SciPy's algorithm)
             rows = np.arange(n, dtype=np.int64)
             if c_h is not None:
                 done[h] = (rows, np.asarray(c_h, dtype=np.int64))
