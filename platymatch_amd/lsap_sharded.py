@@ -21,7 +21,10 @@ A rank whose share raises still takes part in every collective of the query (zer
 on all ranks afterwards.  Workers loop in `serve` until the root sends the stop header.  With the "nccl" backend (RCCL) the
 buffers live on the GPU and a rank's candidates go from the kernel's output straight into the gather (DeviceMatrix.row_select_t);
 with "gloo" they are host tensors.  Rows must be the short side (N <= M): with N > M the solver works on the transpose, whose
-rows are this layout's columns."""
+rows are this layout's columns.
+Round 5: the same protocol serves the DEFAULT cost mode's float32 filter blocks (solve_pair_sharded_filtered: a FilteredMatrix on
+the root, exact entries evaluated there), and several pairings at once with their roots' host solvers side by side
+(solve_pairs_sharded_filtered: one all-reduce of pending headers per round, then the queries in pairing order)."""
 import numpy as np
 
 from . import lsap
