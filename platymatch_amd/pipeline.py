@@ -28,111 +28,9 @@ from .lsap import linear_sum_assignment, solve_many
 from ._pairings import HYPOTHESES, PAIRINGS  # noqa: E402
 _RNG_LOCK = threading.RLock()
 
-# The eight cost matrices of a large registration (160 GB at 50 000 x 50 000) are kept by THIS module between calls, one buffer
-# per (device, stream), instead of being handed back to torch's caching allocator: a freed block of that size is the only one
-# large enough for any later request of more than a megabyte that finds no exact fit, gets split for it, and — with a live
-# piece inside — can neither serve the next registration nor be returned to the driver (round 3: the fifth 50 000-point
-# registration of a process ran out of memory with 149 GB "reserved but unallocated").  Buffers below COST_CACHE_MIN_BYTES
-# (and every registration of a batch) go through the allocator as before.  release_cost_buffers() gives the memory back.
-COST_CACHE_MIN_BYTES = 8 << 30
-_COST_CACHE = {}
-_COST_LOCK = threading.Lock()
-
-
-def _cost_key(device):
-    import torch
-    return (device.index, torch.cuda.current_stream(device).cuda_stream)
-
-
-class _CostLease:
-    """A registration's hold on the kept cost buffer of its (device, stream): release() — always from a finally — makes the
-    buffer available to the next registration.  A buffer is handed to ONE registration at a time: two host threads registering
-    on the same stream (e.g. both on the default stream) must not write their matrices into the same storage while the other's
-    assignment passes still read it."""
-
-    def __init__(self, key, view):
-        self.key, self.view = key, view
-
-    def release(self):
-        with _COST_LOCK:
-            e = _COST_CACHE.get(self.key)
-            if e is not None and e["lease"] is self:
-                e["lease"] = None
-        self.view = None
-
-
-def cost_buffer(device, shape):
-    """Lease a float64 [shape] view of this (device, stream)'s kept buffer, grown if it is too small (the old one is released
-    first).  -> _CostLease, or None when another registration holds the buffer: the caller then takes a fresh allocation."""
-    import torch
-    need = int(np.prod(shape))
-    key = _cost_key(device)
-    with _COST_LOCK:
-        e = _COST_CACHE.get(key)
-        if e is not None and e["lease"] is not None:
-            return None
-        if e is None or e["t"].numel() < need:
-            _COST_CACHE.pop(key, None)
-            e = None                                       # (released before the larger one is asked for)
-            e = {"t": torch.empty(need, dtype=torch.float64, device=device), "lease": None}
-            _COST_CACHE[key] = e
-        lease = _CostLease(key, e["t"][:need].view(*shape))
-        e["lease"] = lease
-    return lease
-
-
-def kept_cost_bytes(device):
-    """Bytes of this (device, stream)'s kept buffer that a new registration can have (0 while another one holds it)."""
-    with _COST_LOCK:
-        e = _COST_CACHE.get(_cost_key(device))
-        return 0 if (e is None or e["lease"] is not None) else e["t"].numel() * 8
-
-
-def release_cost_buffers():
-    """Hand every kept cost buffer that no registration holds back to torch's allocator (and, with torch.cuda.empty_cache(), to
-    the driver); a buffer in use goes when its registration releases it... the next call of this function."""
-    with _COST_LOCK:
-        for key in [k for k, e in _COST_CACHE.items() if e["lease"] is None]:
-            del _COST_CACHE[key]
-
-
-class _EarlyLease:
-    """The kept cost buffer asked for on a helper thread AT THE START of a registration: a fresh process pays
-    ~22 ms per GB for the buffer's first allocation (0.9 s for the default mode's 40 GB at 50 000 nuclei, 3.5 s for the exact
-    mode's 160 GB), and until the cost kernel needs it the host is busy with other first-call costs — self-check, code-object
-    loads, statistics, descriptors.  result() -> the lease, or None (another registration holds the buffer / allocation failed:
-    the caller goes the ordinary way).  A buffer that already exists is leased on the spot, without a thread."""
-
-    def __init__(self, device, nbytes):
-        import torch
-        self.lease, self.thread, self.nbytes = None, None, int(nbytes)
-        stream = torch.cuda.current_stream(device)
-        elems = (int(nbytes) + 7) // 8
-        if kept_cost_bytes(device) >= 8 * elems:
-            self.lease = cost_buffer(device, (elems,))
-            return
-
-        def work():
-            try:
-                with torch.cuda.device(device), torch.cuda.stream(stream):      # (the buffer is kept per (device, stream))
-                    self.lease = cost_buffer(device, (elems,))
-            except Exception:       # noqa: BLE001 — out of memory here is not an error: the caller decides again with what is free
-                self.lease = None
-
-        self.thread = threading.Thread(target=work, name="pm-cost-buffer")
-        self.thread.start()
-
-    def result(self):
-        if self.thread is not None:
-            self.thread.join()
-            self.thread = None
-        return self.lease
-
-    def cancel(self):
-        lease = self.result()
-        if lease is not None:
-            lease.release()
-        self.lease = None
+# (the kept cost buffers and their leases: cost_buffers.py)
+COST_CACHE_MIN_BYTES = 8 << 30     # cost buffers of at least this size are kept per (device, stream) between registrations (cost_buffers.py)
+from .cost_buffers import _CostLease, _EarlyLease, cost_buffer, kept_cost_bytes, release_cost_buffers  # noqa: E402,F401
 
 
 def kept_bytes_wanted(mode, n, m):
@@ -160,166 +58,12 @@ def reserve(n, m=None, cost_mode='auto', device=None):
     return kept_cost_bytes(dev)
 
 
-RELAXED_VARIANT = 2            # pm_chi2_cost8_relaxed: 0 all computed, 1 94 x 94 term table, 2 64 x 64 table at three waves per SIMD (fastest at 50k)
-
-
 class EdgeGuardWarning(UserWarning):
     """estimate_transform met neighbours that sit on a bin boundary of the shape context within the reference's own rounding
     noise: the integer histograms are then not defined by the reference's source alone."""
 
 
-class GpuBackend:
-    """The product's only compute backend: the HIP kernels behind libplatymatch_hip.so."""
-
-    device_sampler = True      # do_ransac can draw its index sets on the device (unseeded runs)
-
-    def __init__(self, dev=None):
-        from . import _kernels
-        self.K = _kernels
-        self.device = nat.device(dev)
-
-    def cloud(self, x):
-        t = nat.to_dev(x, dev=self.device)
-        if t.dim() != 2 or t.shape[0] not in (3, 4):
-            raise ValueError("clouds must be 3 x N (or 4 x N)")
-        return t[:3, :].contiguous()
-
-    def axis(self, xyz, view=None):
-        """First PCA axis of the cloud as the reference gets it from sklearn (shape_context.py:162-165): sklearn's own NumPy calls on
-        the host (shape_context.pca_axis_host: the reference's bits), on `view` — the N x 3 array the reference would pass, made
-        from the caller's own array (shape_context.pca_view) — or, without one, on a host copy of the device cloud."""
-        from .estimate_transform.shape_context import pca_axis_host
-        if view is None:
-            view = xyz.cpu().numpy().transpose()
-        torch = nat.torch_mod()
-        host = torch.from_numpy(np.ascontiguousarray(pca_axis_host(view), dtype=np.float64).reshape(3)).pin_memory()
-        return host.to(xyz.device, non_blocking=True)     # queued behind this stream's launches: a pageable copy would make the host wait for them
-
-    def stats(self, xyz, view=None):
-        if view is None:
-            view = xyz.cpu().numpy().transpose()      # read back BEFORE this call's launches are queued in front of the copy
-        c, md = self.K.centroid(xyz), self.K.mean_distance(xyz)
-        return c, md, self.axis(xyz, view)            # the host's ~0.3 ms of NumPy run while the device sums the pair distances
-
-    def mean_distance_partials(self, xyz, row_offset, row_stride):
-        return self.K.mean_distance_partials(xyz, row_offset, row_stride)
-
-    def mean_distance_finish(self, partials, n):
-        return self.K.mean_distance_finish(partials, n)
-
-    def centroid_and_axis(self, xyz, view=None):
-        if view is None:
-            view = xyz.cpu().numpy().transpose()
-        return self.K.centroid(xyz), self.axis(xyz, view)
-
-    def shape_context(self, xyz, c, md, x0, nf, row0, nrows, guards=None):
-        r = self.K.shape_context(xyz, c, x0, md, nf, row0=row0, nrows=nrows)
-        if guards is not None:
-            guards.append(r["guard"])         # int32 GPU [2]: neighbours too close to a ring radius / sector edge (edge guard)
-        return r["hist"]
-
-    def symmetry_flag(self, sc_m, sc_f):
-        return self.K.chi2_symmetry_flag(sc_m, sc_f)
-
-    def chi2_cost8(self, sc_m, sc_f, out=None):
-        if sc_f.shape[0] == 1:            # frame 1 only: gather_fixed_descriptors verified the permutation relation
-            return self.K.chi2_cost8_frame1(sc_m[0], sc_f[0], out=out)
-        return self.K.chi2_cost8(sc_m, sc_f, out=out)
-
-    def chi2_cost8_relaxed(self, sc_m, sc_f, out=None):
-        """The eight matrices in relaxed float64 arithmetic (K.chi2_cost8_relaxed) -> (U, delta).  Only where the frame-permutation
-        relation holds: the caller has checked it (chi2_symmetric / the sharded gather's verdict)."""
-        return self.K.chi2_cost8_relaxed(sc_m[0], sc_f[0], out=out, variant=RELAXED_VARIANT), self.K.chi2_relaxed_delta()
-
-    def chi2_cost_pair_into(self, sc_m1, sc_f1, pairing, out8):
-        """One pairing's two EXACT matrices written over their slots of an eight-matrix buffer (the relaxed route's rebuild)."""
-        return self.K.chi2_cost_pair_into(sc_m1, sc_f1, pairing, out8)
-
-    def chi2_cost_pair(self, sc_m, sc_f, pairing, out=None):
-        """The two matrices of one pairing (hypothesis + twin) only -> [2, rows, M]; symmetric iff sc_f holds frame 1 only or
-        the permutation relation checks out (symmetric_hint caches the check of the whole-cloud call)."""
-        sym = sc_f.shape[0] == 1 or self.K.chi2_symmetric(sc_m, sc_f)
-        return self.K.chi2_cost_pair(sc_m, sc_f, pairing, sym, out=out)
-
-    def chi2_symmetric(self, sc_m, sc_f):
-        """Do frames 2..4 permute frame 1's phi sectors bit for bit on these rows (the premise of the half-cost, relaxed and filter
-        builds)?  One pass over the descriptors."""
-        return sc_f.shape[0] == 1 or self.K.chi2_symmetric(sc_m, sc_f)
-
-    def chi2_filter4(self, a1, b1, out=None, dtype=None):
-        """The four pairings' FILTER matrices [4, rows of a1, rows of b1] (packed float32 arithmetic; within chi2_filter_delta() of
-        the exact costs) — a1's rows may be a rank's block."""
-        return self.K.chi2_filter4(a1, b1, out=out, dtype=dtype)
-
-    def chi2_filter_pair(self, a1, b1, pairing, out=None, dtype=None):
-        return self.K.chi2_filter_pair(a1, b1, pairing, out=out, dtype=dtype)
-
-    def chi2_filter_delta(self):
-        return self.K.chi2_filter_delta()
-
-    def chi2_entries(self, sc_m1, sc_f1, pairing, rows, cols, trusted=False):
-        """Listed entries of pairing t's two EXACT matrices (hypothesis, twin) -> two float64 GPU tensors."""
-        return self.K.chi2_entries(sc_m1, sc_f1, pairing, rows, cols, trusted=trusted)
-
-    def chi2_cost_single(self, scA, scB):
-        """One matrix chi2(scA[i], scB[j]) for any two descriptor sets [*, 360] (pm_chi2_cost)."""
-        return self.K.chi2_cost(scA.contiguous(), scB.contiguous())
-
-    def free_bytes(self):
-        """Device memory a new allocation can draw on: what the driver reports free plus what torch's caching allocator holds
-        without using (the eight matrices of a previous registration sit there: counting them as taken would send the next
-        registration of the same size into the streamed mode)."""
-        import torch
-        cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
-        return torch.cuda.mem_get_info(self.device)[0] + max(int(cached), 0) + kept_cost_bytes(self.device)   # (+ this stream's kept buffer: it IS the room)
-
-    def row_argmin(self, U):
-        return self.K.row_argmin(U)
-
-    def draw_samples(self, n, min_samples, trials, rng=None):
-        from .estimate_transform.shape_context import draw_ransac_samples
-        return draw_ransac_samples(n, min_samples, trials, rng=rng)
-
-    def do_ransac(self, mov, fix, rows, cols, trials, error, transform, min_samples, samples=None, device_seed=None, run=0, defer=None,
-                  prelaunched=None):
-        from .estimate_transform.shape_context import do_ransac
-        return do_ransac(mov, fix, min_samples=min_samples, trials=trials, error=error, transform=transform,
-                         rows=rows, cols=cols, samples=samples, device_seed=device_seed, run=run, defer=defer, prelaunched=prelaunched)
-
-    def ransac_prelaunch(self, mov, fix, rows, cols, trials, error, min_samples, device_seed, run):
-        from .estimate_transform.shape_context import ransac_prelaunch
-        return ransac_prelaunch(mov, fix, rows, cols, min_samples, trials, error, device_seed, run)
-
-    def refit_winner(self, deferred):
-        """The chosen hypothesis's RANSAC model by the reference's own host expression (shape_context.refit_affine_winner)."""
-        from .estimate_transform.shape_context import refit_affine_winner
-        return refit_affine_winner(deferred)
-
-    def fit(self, kp_m, kp_f, transform):
-        from .estimate_transform.find_transform import get_affine_transform, get_similar_transform
-        fn = get_affine_transform if transform == 'Affine' else get_similar_transform
-        return nat.to_dev(fn(kp_m, kp_f), dev=self.device)
-
-    def apply_affine(self, A, xyz):
-        return self.K.apply_affine(A.reshape(16).contiguous(), xyz)
-
-    def icp(self, mov, fix, iters, transform, log, one_launch=None):
-        from .estimate_transform.perform_icp import perform_icp
-        return perform_icp(mov, fix, iters, transform, log=log, one_launch=one_launch)
-
-    def icp_grid(self, fix):
-        """Bin the fixed cloud once per ICP run; the run owns the grid and hands it to icp_nn (no hidden backend state:
-        a backend may be shared between threads and the allocator reuses addresses)."""
-        return self.K.icp_grid(fix)
-
-    def icp_nn(self, mov, fix, grid=None):
-        return self.K.icp_nn(mov, fix, want_dist=False, grid=grid)[0]
-
-    def icp_accumulate(self, mov, fix, nn, origin, out=None):
-        return self.K.icp_accumulate(mov, fix, nn, origin, out=out, nn_trusted=True)     # nn is icp_nn's own output
-
-    def icp_update(self, sums, origin, mov, fix, nn, A_icp, parts_out=None, status=None):
-        return self.K.icp_update(sums, origin, mov, fix, nn, A_icp, parts_out=parts_out, nn_trusted=True, status=status)
+from .backend import GpuBackend, RELAXED_VARIANT  # noqa: E402,F401
 
 
 def cost_bytes(rows, n, m, world=1):
@@ -1432,166 +1176,5 @@ def estimate_transform(moving, fixed, *, transform='Affine', mode='unsupervised'
     return A_sc.cpu().numpy(), (A_icp.cpu().numpy() if nat.is_torch(A_icp) else np.asarray(A_icp)), inliers
 
 
-def batch_costs(sizes):
-    """Relative cost of a registration of N x M nuclei, for sharing a batch out: the eight N x M cost matrices grow
-    with N*M, the eight Hungarian solves (the dominant host step) roughly with N*M*sqrt(min(N, M)) (measured at 2k-20k,
-    profiles/r02_batch64.json)."""
-    return [float(n) * float(m) * float(min(n, m)) ** 0.5 for n, m in sizes]
-
-
-def batch_assignment(sizes, world):
-    """Pairs -> ranks, largest first onto the least loaded rank (LPT): a pure function of the sizes, so every rank
-    computes the same table without talking.  -> list of rank indices, one per pair."""
-    cost = batch_costs(sizes)
-    load = [0.0] * world
-    owner = [0] * len(cost)
-    for k in sorted(range(len(cost)), key=lambda k: (-cost[k], k)):
-        g = min(range(world), key=lambda g: (load[g], g))
-        owner[k] = g
-        load[g] += cost[k]
-    return owner
-
-
-def _pair_size(pair):
-    return tuple(int(x.shape[1]) for x in pair[:2])
-
-
-def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
-    """This process's share of a batch: pairs ks on `workers` host threads, one HIP stream each."""
-    import torch
-    from concurrent.futures import ThreadPoolExecutor
-    kwargs = dict(kwargs)
-    given = kwargs.pop("options", None)
-    opts = dataclasses.replace(Options.of(given), private_rng=True)
-    stated = set(given) if isinstance(given, dict) else {f.name for f in dataclasses.fields(Options) if getattr(opts, f.name) != f.default}
-    be = opts.backend
-    on_gpu = be is None or getattr(be, "device", None) is None or torch.device(be.device).type == "cuda"
-    if on_gpu:
-        dev = nat.device(None if be is None else be.device)
-        nat.load()
-
-    # HBM gate: the eight cost matrices of a pair (64 N M bytes, plus descriptors) live on the device while it is being
-    # assigned; workers wait until the pairs in flight leave room for theirs (a pair larger than the whole budget runs alone)
-    gate = threading.Condition()
-    in_flight = [0.0]
-    budget = 0.0
-    if on_gpu:
-        free_b = torch.cuda.mem_get_info(dev)[0] + max(int(torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)), 0)
-        budget = 0.8 * free_b                # (what torch's allocator holds unused is there to be drawn on, as in GpuBackend.free_bytes)
-
-    def need(k):
-        n, m = _pair_size(pairs[k])
-        return cost_bytes(n, n, m) + 2880.0 * (2 * n + 4 * m) * 2
-
-    slots = threading.local()
-    next_slot = [0]
-
-    def worker_slot():
-        if not hasattr(slots, "id"):
-            with gate:
-                slots.id = next_slot[0]
-                next_slot[0] += 1
-        return slots.id
-
-    def one(k):
-        det = {"timing": True} if timings is not None else ({} if reports is not None else None)
-        if not on_gpu:                       # a caller-supplied host backend (tests): no stream to set
-            out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], details=det, options=opts, **kwargs)
-        else:
-            want = min(need(k), budget)
-            with gate:
-                while in_flight[0] + want > budget and in_flight[0] > 0:
-                    gate.wait()
-                in_flight[0] += want
-            try:
-                from . import lsap
-                lsap.set_pin_base(None if (workers > 1 and len(ks) > 1) else 0)     # several registrations side by side: placement left to the scheduler (measured)
-                stream = nat.side_stream(dev, ("batch worker", worker_slot()))   # persistent per worker thread
-                with torch.cuda.device(dev), torch.cuda.stream(stream):
-                    out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], details=det, options=opts, **kwargs)
-                    stream.synchronize()
-            finally:
-                with gate:
-                    in_flight[0] -= want
-                    gate.notify_all()
-        if timings is not None:
-            timings[k] = det["timing"]
-        if reports is not None:
-            reports[k] = {"routes": det.get("assignment", {}).get("routes"), "mode": det.get("assignment", {}).get("mode"),
-                          "cost_modes": [d.get("cost_mode") for d in det.get("assignment", {}).get("details", [])]}
-        return out
-
-    if on_gpu and workers > 1 and len(ks) > 1 and "icp_one_launch" not in stated:
-        opts = dataclasses.replace(opts, icp_one_launch=False)       # several streams in flight: no persistent grid (perform_icp.ONE_LAUNCH)
-    if on_gpu and workers > 1 and len(ks) > 1 and "keep_cost_buffer" not in stated:
-        opts = dataclasses.replace(opts, keep_cost_buffer=False)     # (a buffer kept per worker stream would pin memory the HBM gate counts as free)
-    # largest first: the long Hungarian solves start early and the short pairs fill the gaps at the end
-    cost = batch_costs([_pair_size(pairs[k]) for k in ks])
-    order = [ks[i] for i in sorted(range(len(ks)), key=lambda i: (-cost[i], ks[i]))]
-    if workers <= 1 or len(order) <= 1:
-        return {k: one(k) for k in order}
-    with ThreadPoolExecutor(max_workers=min(workers, len(order))) as ex:
-        return dict(zip(order, ex.map(one, order)))
-
-
-def estimate_transform_batch(pairs, workers=8, seeds=None, group=None, timings=None, reports=None, **kwargs):
-    """Several independent registrations (BASELINE config 5: "replicas only" — pairs never exchange data).
-
-    One GPU (group=None): each worker thread drives its pairs on its own HIP stream — a PERSISTENT one (nat.side_stream:
-    torch's allocator caches per stream; with a fresh stream per pair every cost buffer was a new hipMalloc, ~13 s of a 15 s
-    batch) —, so the GPU stages of different pairs overlap and the host stages (assignment cores, RANSAC draws: GIL-free)
-    run concurrently.  workers: 8 measured best on the 16 cores a one-GPU box grants (64 pairs of 2k-20k nuclei: 5 workers
-    10.0 s, 8 5.8-6.9 s, 10 5.7-5.9 s, 12 6.6 s); the HBM gate below bounds what is in flight.
-    Several GPUs (group = a torch.distributed group, one process per GPU): every rank holds the whole list; pairs are
-    dealt to ranks largest first (batch_assignment, no communication), each rank registers its share as above, and ONE
-    all-reduce of 40 doubles per pair (A_sc, A_icp, inlier counts; every entry is non-zero on its owner only, so the sum is
-    exact) hands every result to every rank.  A failure on any rank is raised on all of them.
-
-    Seeded pairs draw their RANSAC index sets from a private RandomState(seed) (the sets np.random.seed(seed) would
-    give); unseeded pairs draw from NumPy's global generator one after the other.
-    pairs: iterable of (moving, fixed); seeds: optional per-pair RANSAC seeds; timings: optional dict, filled with
-    {pair index: wall-clock split of its stages} for the pairs this process registered (adds stream synchronisations);
-    reports: optional dict, filled with {pair index: {"routes": how each of its eight assignments was obtained, "cost_modes": with
-    cost_mode='relaxed', whether each was certified on the relaxed build or after an exact rebuild}}.
-    -> list of (A_sc, A_icp, inliers) in input order, each identical to a stand-alone estimate_transform call."""
-    import torch
-    pairs = list(pairs)
-    seeds = list(seeds) if seeds is not None else [None] * len(pairs)
-    if len(seeds) != len(pairs):
-        raise ValueError("one seed per pair")
-    if "details" in kwargs:
-        raise ValueError("details is per registration: call estimate_transform for the pair of interest")
-    rank, world = _world(group)
-    if world == 1:
-        res = _run_local(pairs, list(range(len(pairs))), workers, seeds, kwargs, timings, reports)
-        return [res[k] for k in range(len(pairs))]
-    dist = _dist()
-    owner = batch_assignment([_pair_size(p) for p in pairs], world)
-    mine = [k for k in range(len(pairs)) if owner[k] == rank]
-    failure = None
-    try:
-        res = _run_local(pairs, mine, workers, seeds, kwargs, timings, reports)
-    except Exception as e:                     # keep the collective below matched on every rank, then raise everywhere
-        failure, res = e, {}
-    be = Options.of(kwargs.get("options")).backend
-    on_host = dist.get_backend(group) == "gloo"
-    dev = torch.device("cpu") if on_host else (nat.device(None if be is None else be.device))
-    table = torch.zeros((len(pairs) + 1, 40), dtype=torch.float64, device=dev)
-    table[len(pairs), 0] = 0.0 if failure is None else 1.0
-    for k, (A_sc, A_icp, inl) in res.items():
-        table[k, :16] = torch.as_tensor(np.asarray(A_sc.cpu() if nat.is_torch(A_sc) else A_sc, dtype=np.float64).reshape(16))
-        table[k, 16:32] = torch.as_tensor(np.asarray(A_icp.cpu() if nat.is_torch(A_icp) else A_icp, dtype=np.float64).reshape(16))
-        table[k, 32:] = torch.as_tensor(np.asarray(inl, dtype=np.float64))
-    dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
-    if failure is not None:
-        raise failure
-    if float(table[len(pairs), 0]) != 0.0:
-        raise RuntimeError("estimate_transform_batch: a registration failed on another rank")
-    out = []
-    host = table.cpu().numpy()
-    for k, p in enumerate(pairs):
-        A_sc, A_icp, inl = host[k, :16].reshape(4, 4).copy(), host[k, 16:32].reshape(4, 4).copy(), host[k, 32:].astype(np.int64)
-        if nat.is_torch(p[0]):
-            A_sc, A_icp = torch.as_tensor(A_sc, device=p[0].device), torch.as_tensor(A_icp, device=p[0].device)
-        out.append((A_sc, A_icp, inl))
-    return out
+# (several independent registrations: batch.py — imported at the end of this module, it needs estimate_transform)
+from .batch import batch_assignment, batch_costs, estimate_transform_batch, _run_local  # noqa: E402,F401
