@@ -209,14 +209,23 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
     __shared__ __attribute__((aligned(16))) double B_s[CH_TJ][CH_BPITCH];
     __shared__ __attribute__((aligned(16))) double tab[TL > 0 ? TL * TL : 1];
 
+    unsigned int bid = blockIdx.x;
+    const unsigned int full = nblocks / 8u * 8u;
+    if (bid < full) bid = (bid % 8u) * (full / 8u) + bid / 8u;
+    int ti, tj;
+    tile_of(bid, nTi, nblocks, ti, tj);
+    const int i0 = ti * SY_TI, j0 = tj * CH_TJ;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
     constexpr int NH = (TSEL < 0) ? 8 : 2;
     constexpr int NACC = RELAX ? NH / 2 : NH;      // relaxed: one sum per pairing (the twins coincide)
+    double acc[SY_RI][NACC];
+#pragma unroll
+    for (int r = 0; r < SY_RI; ++r)
+#pragma unroll
+        for (int h = 0; h < NACC; ++h) acc[r][h] = 0.0;
 
-    // The term table depends on the two clouds' totals only: a workgroup fills it ONCE and keeps it for every tile it works on
-    // (round 5: the table kernels are launched with as many workgroups as the device holds at a time, each striding over the
-    // tiles — filled per tile, its 8 836 entries with two IEEE divisions each were 6.5 % of the launch's instructions).
     unsigned int tabmask = 0;             // shells served from the table (uniform)
     if constexpr (TL > 0) {
         if (meta->bad == 0) {
@@ -235,20 +244,6 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
             __syncthreads();
         }
     }
-
-    const unsigned int full = nblocks / 8u * 8u;
-    for (unsigned int tile = blockIdx.x; tile < nblocks; tile += gridDim.x) {      // (one tile per workgroup unless the launch is persistent)
-    unsigned int bid = tile;
-    if (bid < full) bid = (bid % 8u) * (full / 8u) + bid / 8u;
-    int ti, tj;
-    tile_of(bid, nTi, nblocks, ti, tj);
-    const int i0 = ti * SY_TI, j0 = tj * CH_TJ;
-
-    double acc[SY_RI][NACC];
-#pragma unroll
-    for (int r = 0; r < SY_RI; ++r)
-#pragma unroll
-        for (int h = 0; h < NACC; ++h) acc[r][h] = 0.0;
 
     // counts of the next tabled shell, fetched one tabled shell ahead (an L2 round trip is about as long as a tabled shell):
     // the lane's twelve fixed counts (3 dwords) and, per row of the wave, the twelve moving counts (3 dwords, wave-uniform)
@@ -474,7 +469,6 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
             }
         }
     }
-    }       // tiles of this workgroup
 }
 
 // sum over a descriptor row's 360 bins, bin order (relaxed cost build: 0.5 (sum a + sum b) - 2 sum ab/(a+b))
@@ -645,18 +639,6 @@ extern "C" int pm_chi2_symmetry_check(const double *sc_m1, const double *sc_m2, 
 }
 
 namespace pm {
-// workgroups of `kernel` (CH_THREADS threads, static LDS only) the current device holds at a time: CUs x the occupancy the
-// runtime reports; 0 if it cannot be told (the caller then launches one workgroup per tile).  A device constant, asked per launch.
-static unsigned int resident_workgroups(const void *kernel) {
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, CH_THREADS, 0) != hipSuccess || cus <= 0 || per_cu <= 0) {
-        (void)hipGetLastError();
-        return 0;
-    }
-    return (unsigned int)cus * (unsigned int)per_cu;
-}
-
 template <int RI, int MINW, int TSEL = -1, int TL = 0, bool RELAX = false>
 int chi2_sym_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, double *out, size_t ld, size_t mstride, hipStream_t s,
                     const unsigned char *cntA = nullptr, const unsigned char *cntB = nullptr, const SymMeta *meta = nullptr,
@@ -666,15 +648,8 @@ int chi2_sym_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, do
     if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
     if (TL > 0 && (!cntA || !cntB || !meta)) return PM_ERR_INVALID_ARG;
     if (RELAX && (!sumA || !sumB)) return PM_ERR_INVALID_ARG;
-    unsigned int grid = (unsigned int)nblocks;
-    if (TL > 0) {
-        // persistent launch: as many workgroups as the device holds at a time (a multiple of 8, so that tile t of workgroup w keeps
-        // w's XCD: tile_of's grouping), each striding over the tiles with its table in LDS
-        const unsigned int resident = resident_workgroups((const void *)chi2_sym_kernel<RI, MINW, TSEL, TL, RELAX>);
-        if (resident >= 8 && resident < grid) grid = resident / 8u * 8u;
-    }
-    chi2_sym_kernel<RI, MINW, TSEL, TL, RELAX><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, mstride, (int)nTi,
-                                                                          (unsigned int)nblocks, cntA, cntB, meta, sumA, sumB);
+    chi2_sym_kernel<RI, MINW, TSEL, TL, RELAX><<<(unsigned int)nblocks, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, mstride, (int)nTi,
+                                                                                           (unsigned int)nblocks, cntA, cntB, meta, sumA, sumB);
     return launch_status();
 }
 
