@@ -169,7 +169,6 @@ int chi2_launch(const Chi2Args<NFA, NFB> &args, int nA, int nB, double *out, siz
 // (the outer ones of a large cloud) are computed.
 constexpr int CH_NSHELL = CH_STAGES;
 constexpr int CH_TL = 94;              // 94 x 94 doubles + the staging tiles = 79 392 B: two workgroups per CU (160 KiB), as the registers allow
-constexpr size_t SYM_QUOT_OFFSET = 512;      // workspace: SymMeta, then at this offset the quotient vectors count / total (see sym_prepare)
 struct SymMeta {
     unsigned long long minbits[2];     // smallest positive descriptor value of each cloud (bit pattern; +inf if none)
     double tot[2];                     // its reciprocal rounded to an integer: the candidate total
@@ -235,11 +234,10 @@ __global__ __launch_bounds__(CH_THREADS, MINW) void chi2_sym_kernel(const double
         }
         tabmask = __builtin_amdgcn_readfirstlane(tabmask);
         if (tabmask) {
-            // a = count / total, from the launch's quotient vectors (sym_prepare: the same IEEE division, once per launch)
-            const double *qa = reinterpret_cast<const double *>(reinterpret_cast<const char *>(meta) + SYM_QUOT_OFFSET), *qb = qa + 256;
+            const double totA = meta->tot[0], totB = meta->tot[1];
             for (int e = tid; e < TL * TL; e += CH_THREADS) {
                 const int ca = e / TL, cb = e - ca * TL;
-                const double a = qa[ca], b = cb ? qb[cb] : CH_TINY;
+                const double a = (double)ca / totA, b = cb ? (double)cb / totB : CH_TINY;
                 const double df = a - b;
                 tab[e] = RELAX ? (a * b) * relaxed_recip(a + b) : div_pos(df * df, a + b);
             }
@@ -732,18 +730,8 @@ __global__ __launch_bounds__(256) void counts_extract_kernel(const double *__res
     if (threadIdx.x < CH_NSHELL && smax[threadIdx.x] > 0) atomicMax(&m->maxc[which][threadIdx.x], smax[threadIdx.x]);
 }
 
-// workspace header: SymMeta (<= 512 bytes), then the quotients count / total of both clouds for counts 0..255 — what the kernel's
-// per-tile table fill starts from (round 5: two IEEE divisions per table entry and tile were 6.5 % of the launch's instructions;
-// the same quotients, computed once per launch by the same division)
-constexpr size_t SYM_META_BYTES = SYM_QUOT_OFFSET + 2 * 256 * sizeof(double);
-static_assert(sizeof(SymMeta) <= SYM_QUOT_OFFSET, "workspace header");
-
-__global__ void counts_quotients_kernel(SymMeta *m) {
-    double *q = reinterpret_cast<double *>(reinterpret_cast<char *>(m) + SYM_QUOT_OFFSET);
-    const int c = threadIdx.x;                       // 256 threads: one count each, both clouds
-    q[c] = (double)c / m->tot[0];
-    q[256 + c] = (double)c / m->tot[1];
-}
+constexpr size_t SYM_META_BYTES = 512;
+static_assert(sizeof(SymMeta) <= SYM_META_BYTES, "workspace header");
 
 struct SymWs {
     SymMeta *meta;
@@ -761,7 +749,6 @@ int sym_prepare(const double *sc_m1, int nM, const double *sc_f1, int nF, void *
     counts_min_kernel<<<(unsigned int)min((eA + 255) / 256, (size_t)4096), 256, 0, s>>>(sc_m1, eA, w.meta, 0);
     counts_min_kernel<<<(unsigned int)min((eB + 255) / 256, (size_t)4096), 256, 0, s>>>(sc_f1, eB, w.meta, 1);
     counts_total_kernel<<<1, 64, 0, s>>>(w.meta);
-    counts_quotients_kernel<<<1, 256, 0, s>>>(w.meta);
     const size_t gA = eA / CH_K, gB = eB / CH_K;              // (row, shell) groups: 360 = 30 x 12
     counts_extract_kernel<<<(unsigned int)((gA + 255) / 256), 256, 0, s>>>(sc_m1, gA, w.cntA, w.meta, 0);
     counts_extract_kernel<<<(unsigned int)((gB + 255) / 256), 256, 0, s>>>(sc_f1, gB, w.cntB, w.meta, 1);
