@@ -521,12 +521,11 @@ __global__ __launch_bounds__(256) void entries_sym_kernel(const double *__restri
 // U~ = 0.5 (sum a + sum b) - 2 sum_k a_k b_k / (a_k + b_k) with the terms in float32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 on two
 // bins at a time, v_rcp_f32 per bin: 5.5 issue slots per term against the exact build's ~18), every shell computed, a shell's two
 // float32 chains added into a float64 sum per (row, pairing).  NOT the reference's values: every entry is within PM_CHI2_FILTER_DELTA of
-// the exact cost — per term 10 x 2^-24 relative (a, b rounded to float32: 2 each; a + b, a b: 1 each; the shared reciprocal of a pair of
-// bins, 1/x = y rcp(x y): product 1, v_rcp_f32 2, multiply 1), i.e. <= 3.0e-7 on the sum (<= 0.5); the six fused adds and the final add
-// of a shell's chains 7 x 2^-24 of that shell's sum, <= 2.1e-7 over all shells; doubled by the factor 2: < 1.03e-6; stored as float32
-// (pm_chi2_filter4_f32) another 2^-24 of an entry <= 1 and an empty bin's 1e-18 stand-in: PM_CHI2_FILTER_DELTA (1.3e-6) covers all of it.  It serves as a FILTER only (lsap.FilteredMatrix): it says which entries can matter, their exact
+// the exact cost — per term 8 x 2^-24 relative (a, b rounded to float32: 2 each; a + b, a b: 1 each; v_rcp_f32: 2), i.e. <= 2.4e-7 on
+// the sum (<= 0.5); the six fused adds and the final add of a shell's chains 7 x 2^-24 of that shell's sum, <= 2.1e-7 over all shells;
+// doubled by the factor 2: < 1e-6; stored as float32 (pm_chi2_filter4_f32) another 2^-24 of an entry <= 1: PM_CHI2_FILTER_DELTA covers both.  It serves as a FILTER only (lsap.FilteredMatrix): it says which entries can matter, their exact
 // costs come from entries_sym_kernel.  out4 + t * mstride = the matrix of pairing t (both U11/U22-type twins: one matrix).
-#define PM_CHI2_FILTER_DELTA 1.3e-6
+#define PM_CHI2_FILTER_DELTA 1.1e-6
 typedef float pm_f2 __attribute__((ext_vector_type(2)));
 
 template <int TSEL, typename OUT>      // -1: the four pairings -> out + t * mstride; t: pairing t alone -> out.  OUT: float64 or float32 storage
@@ -560,7 +559,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__
         for (int e = tid; e < CH_TJ * CH_K; e += CH_THREADS) {
             const int j = e / CH_K, k = e - j * CH_K;
             const float v = (float)scB[(size_t)min(j0 + j, nB - 1) * PM_NBINS + g * CH_K + k];
-            B_s[j][k] = (v == 0.f) ? 1e-18f : v;       // (an empty fixed bin: its terms are a x 1e-18 / (a + 1e-18) <= 1e-18, nothing beside the bound)
+            B_s[j][k] = (v == 0.f) ? 1e-30f : v;
         }
         __syncthreads();
         pm_f2 b[6], br[6];                            // the lane's twelve fixed bins as pairs, and the same pairs swapped
@@ -586,11 +585,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void filter4_kernel(const double *__
                     const int t = TSEL < 0 ? tt : TSEL;
                     const pm_f2 sm = a[k] + q[t];
                     const pm_f2 pr = a[k] * q[t];
-                    // ONE reciprocal for the pair of bins: 1/x = y rcp(x y), 1/y = x rcp(x y).  v_rcp_f32 runs at a quarter of the
-                    // packed rate and was ~95 % of a stage's issue time (192 of them per stage); a multiply and a packed multiply
-                    // replace every second one.  x, y >= 1e-18 (the stand-in for an empty fixed bin) and <= 2: x y stays normal.
-                    const float rp = __builtin_amdgcn_rcpf(sm.x * sm.y);
-                    const pm_f2 rc = (pm_f2){sm.y, sm.x} * (pm_f2){rp, rp};
+                    const pm_f2 rc = (pm_f2){__builtin_amdgcn_rcpf(sm.x), __builtin_amdgcn_rcpf(sm.y)};
                     s4[tt] = __builtin_elementwise_fma(pr, rc, s4[tt]);
                 }
             }
