@@ -114,3 +114,19 @@ def test_bench_step_on_two_ranks_sharing_the_gpu():
     a = d["assignment_extra"]
     assert a["error"] is None and a["route"].startswith("sharded filter") and a["seconds"] > 0 and all(a["perfect_matchings"])
     assert all("(filter" in str(x) for x in a["routes"]), a["routes"]
+
+
+def test_bench_line_survives_a_sharded_extra_that_does_not_return():
+    """The sharded assignment extra runs under a watchdog (bench.py): with the limit set to nothing it "hangs" by definition — rank 0
+    must still print its one JSON line (the extra reported as timed out, no CPU baseline touching the device afterwards) and every
+    rank must leave with exit code 0 without the closing barrier."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--points", "6000",
+                        "--icp-iters", "3"], env=_env(PM_BENCH_ONE_DEVICE="1", PM_BENCH_BACKEND="gloo", PM_BENCH_EXTRA_TIMEOUT_S="0.001"),
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-2500:])
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["value"] > 0 and d["n_gpus"] == 2
+    assert "timed out" in d["assignment_extra"]["error"] and d["assignment_extra"]["seconds"] is None
+    assert "skipped" in d["cpu_baseline"]
