@@ -306,14 +306,25 @@ class FilteredMatrix:
     def entries(self, rows, cols):
         return self._exact(rows, cols)
 
-    def _row_select_t(self, v, k):
-        """row_select with selection, exact evaluation and re-sorting on the device: one read-back."""
+    def _row_select_t(self, v, k, with_diagonal=False):
+        """row_select with selection, exact evaluation and re-sorting on the device: one read-back.  with_diagonal: the exact
+        entries (i, i) ride along in the same evaluation launch and come back as a fourth value (solve_core's safety edges: one
+        round trip less per hypothesis — with four pairings sharing the GPU a tiny launch of its own waited 1-34 ms in the queue)."""
         torch = nat.torch_mod()
         cols, _, flag = self.A.row_select_t(v, k)
         valid = cols >= 0
         rows = torch.arange(cols.shape[0], dtype=torch.int32, device=cols.device)[:, None].expand_as(cols)
-        exact = self.exact_entries_t(rows[valid].contiguous(), cols[valid].contiguous())[0]
+        r_list, c_list = rows[valid].contiguous(), cols[valid].contiguous()
+        n_diag = 0
+        if with_diagonal:
+            n_diag = min(self.shape)
+            d = torch.arange(n_diag, dtype=torch.int32, device=cols.device)
+            r_list, c_list = torch.cat([r_list, d]), torch.cat([c_list, d])
+        exact = self.exact_entries_t(r_list, c_list)[0]
         self.exact_evaluated += int(exact.numel())
+        diag = None
+        if with_diagonal:
+            diag, exact = exact[exact.numel() - n_diag:], exact[:exact.numel() - n_diag]
         costs = torch.full(cols.shape, float("inf"), dtype=torch.float64, device=cols.device)
         costs[valid] = exact
         red = costs
@@ -324,7 +335,15 @@ class FilteredMatrix:
         cols_s, costs_s = torch.gather(cols, 1, order), torch.gather(costs, 1, order)
         bad = torch.stack([flag.reshape(-1)[0].to(torch.int32), (~torch.isfinite(exact)).any().to(torch.int32)])
         cols_h, costs_h, bad_h = cols_s.cpu().numpy(), costs_s.cpu().numpy(), bad.cpu().numpy()
+        if with_diagonal:
+            return cols_h, costs_h, int(bad_h.max()), diag.cpu().numpy()
         return cols_h, costs_h, int(bad_h.max())
+
+    def row_select_with_diagonal(self, v, k):
+        """row_select(v, k) + diagonal(min(shape)) in one evaluation launch where the device path exists, else None."""
+        if self.exact_entries_t is not None and hasattr(self.A, "row_select_t"):
+            return self._row_select_t(v, k, with_diagonal=True)
+        return None
 
     def row_select(self, v, k):
         if self.exact_entries_t is not None and hasattr(self.A, "row_select_t"):
@@ -847,10 +866,17 @@ def solve_core(M, info=None):
     if ROW_REDUCTION_ROUNDS > 0 and hasattr(M, "bid"):
         # warm start: a dozen bidding rounds on the dense rows match most rows and leave prices close to the optimum's
         u_rr, v0, c4r_rr = _row_reduction(M, v0, ROW_REDUCTION_ROUNDS)
-    cols, costs, bad = M.row_select(v0, k)
+    both = M.row_select_with_diagonal(v0, k) if hasattr(M, "row_select_with_diagonal") else None
+    if both is not None:
+        cols, costs, bad, safety = both
+        safety = safety[:nr]
+    else:
+        cols, costs, bad = M.row_select(v0, k)
+        safety = None
     if bad:
         return None
-    safety = M.diagonal(nr)                              # row i -> column i: the core always holds a perfect matching
+    if safety is None:
+        safety = M.diagonal(nr)                          # row i -> column i: the core always holds a perfect matching
     scale = max(float(np.abs(costs[cols >= 0]).max()), float(np.abs(safety).max()), float(np.abs(v0).max()), 1e-300)
     delta = REL_DELTA * scale
     kp = min(PRICE_EDGES_PER_ROW, 256)
