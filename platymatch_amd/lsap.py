@@ -1099,6 +1099,9 @@ PIPELINED_PRIORITY = -1
 # shortest paths, the same four side by side 0.39-0.60 s each — threads started from one parent land on one CCD and share its L3.
 # pin_solver_thread(slot) gives each of the four its own L3 domain (same NUMA node as the caller where possible).
 PIN_SOLVER_THREADS = os.environ.get("PM_LSAP_PIN", "1") != "0"
+# (A softer form — every fourth domain of the caller's NUMA node per thread, so that the scheduler could still dodge a busy core — was
+# measured equal: nine warm 50k registrations each, median 865 ms pinned to one domain, 861 ms to a class of two, 897 ms unpinned
+# with a tail up to 1 291 ms; profiles/r05_pin_ab.txt.  The simpler form stays.)
 _L3_DOMAINS = None
 
 
