@@ -137,9 +137,22 @@ def pmc_traffic(kernel_substring, n):
         return None, None
     if int(d.get("n", -1)) != int(n):
         return None, None
+    # the counters describe the kernel sources they were collected on: a source edited since makes them stale
+    import hashlib
+    stale = []
+    for fname, sha in (d.get("kernel_source_sha16") or {}).items():
+        try:
+            with open(os.path.join(ROOT, "platymatch_amd", "csrc", fname), "rb") as fh:
+                if hashlib.sha256(fh.read()).hexdigest()[:16] != sha:
+                    stale.append(fname)
+        except OSError:
+            stale.append(fname)
     for name, rec in d.get("kernels", {}).items():
         if kernel_substring in name:
-            return float(rec["traffic_gb"]), "profiles/pmc_traffic.json (round %s: %s)" % (d.get("round"), ", ".join(d.get("source", [])))
+            src = "profiles/pmc_traffic.json (round %s: %s)" % (d.get("round"), ", ".join(d.get("source", [])))
+            if stale:
+                src += "; STALE: %s changed since these passes were collected" % ", ".join(stale)
+            return float(rec["traffic_gb"]), src
     return None, None
 
 

@@ -30,7 +30,12 @@ def per_kernel(path, counter):
 def main():
     fetch_csv, write_csv, n, tag = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     fetch, write = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    import hashlib
+    csrc = os.path.join(ROOT, "platymatch_amd", "csrc")
+    shas = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16] for f in ("pm_chi2.hip", "pm_shape_context.hip")}
     out = {"n": n, "round": tag, "source": [os.path.relpath(fetch_csv, ROOT), os.path.relpath(write_csv, ROOT)],
+           # the kernel sources these counters were collected on: bench.py flags the figures as stale when a source has changed since
+           "kernel_source_sha16": shas,
            "unit": "GB per launch (FETCH_SIZE KiB x 2 for gfx950 + WRITE_SIZE KiB)", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f_kib, launches = fetch.get(k, (0.0, 0))
