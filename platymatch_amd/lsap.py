@@ -280,10 +280,12 @@ class FilteredMatrix:
 
     LIST_CAPACITY_PER_COLUMN = 64
 
-    def __init__(self, approx, exact_entries, cost_delta, exact_entries_t=None):
-        """exact_entries_t (optional, with a DeviceMatrix as `approx`): the same question asked and answered with GPU tensors
-        (rows, cols int32 [t] -> tuple of float64 [t]); the per-row lists of threshold_select are then assembled on the device."""
+    def __init__(self, approx, exact_entries, cost_delta, exact_entries_t=None, entries_device=None):
+        """exact_entries_t (optional): the same question asked and answered with GPU tensors (rows, cols int32 [t] -> tuple of
+        float64 [t]); selections and the per-row lists of threshold_select are then finished on the device — the selector's own
+        (a DeviceMatrix as `approx`) or, for a selector that answers on the host (ShardedMatrix), entries_device."""
         self.A = approx
+        self.entries_device = entries_device
         self.shape = tuple(approx.shape)
         self.exact_entries = exact_entries
         self.exact_entries_t = exact_entries_t
@@ -311,7 +313,14 @@ class FilteredMatrix:
         entries (i, i) ride along in the same evaluation launch and come back as a fourth value (solve_core's safety edges: one
         round trip less per hypothesis — with four pairings sharing the GPU a tiny launch of its own waited 1-34 ms in the queue)."""
         torch = nat.torch_mod()
-        cols, _, flag = self.A.row_select_t(v, k)
+        if hasattr(self.A, "row_select_t"):
+            cols, _, flag = self.A.row_select_t(v, k)
+        else:
+            # a selector that answers on the host (lsap_sharded.ShardedMatrix: the ranks' candidate lists, gathered): the lists go up
+            # to the device the exact entries are evaluated on (entries_device) and are finished there like a local selection's
+            cols_h0, _, bad0 = self.A.row_select(v, k)
+            cols = torch.as_tensor(np.ascontiguousarray(cols_h0, dtype=np.int32), device=self.entries_device)
+            flag = torch.tensor([int(bad0)], dtype=torch.int32, device=self.entries_device)
         valid = cols >= 0
         rows = torch.arange(cols.shape[0], dtype=torch.int32, device=cols.device)[:, None].expand_as(cols)
         r_list, c_list = rows[valid].contiguous(), cols[valid].contiguous()
@@ -339,14 +348,19 @@ class FilteredMatrix:
             return cols_h, costs_h, int(bad_h.max()), diag.cpu().numpy()
         return cols_h, costs_h, int(bad_h.max())
 
+    def _device_finish(self):
+        """Can selections be finished on a device?  Yes with a tensor-valued entry function and either a selector that leaves its
+        lists on that device (DeviceMatrix) or a stated entries_device for a host-side selector (the sharded route's root)."""
+        return self.exact_entries_t is not None and (hasattr(self.A, "row_select_t") or self.entries_device is not None)
+
     def row_select_with_diagonal(self, v, k):
         """row_select(v, k) + diagonal(min(shape)) in one evaluation launch where the device path exists, else None."""
-        if self.exact_entries_t is not None and hasattr(self.A, "row_select_t"):
+        if self._device_finish():
             return self._row_select_t(v, k, with_diagonal=True)
         return None
 
     def row_select(self, v, k):
-        if self.exact_entries_t is not None and hasattr(self.A, "row_select_t"):
+        if self._device_finish():
             return self._row_select_t(v, k)
         cols, costs, bad = self.A.row_select(v, k)
         if bad:
@@ -384,10 +398,17 @@ class FilteredMatrix:
         torch = nat.torch_mod()
         nr, nc = self.shape
         tau = self._tau(u, v)
-        viol, _, tight, red, _ = self.A.certificate_t(u, v, col4row, float("inf"), tau, self.LIST_CAPACITY_PER_COLUMN * nc)
-        if tight is None or viol:
-            return None
-        self._listed = (np.array(u, copy=True), np.array(v, copy=True), np.array(col4row, copy=True), tau, tight.cpu().numpy(), red.cpu().numpy())
+        if hasattr(self.A, "certificate_t"):
+            viol, _, tight, red, _ = self.A.certificate_t(u, v, col4row, float("inf"), tau, self.LIST_CAPACITY_PER_COLUMN * nc)
+            if tight is None or viol:
+                return None
+            tight_h, red_h = tight.cpu().numpy(), red.cpu().numpy()
+        else:                                    # a host-side selector: its list goes up to the entries' device
+            viol, _, tight_h, red_h, _ = self.A.certificate(u, v, col4row, float("inf"), tau, self.LIST_CAPACITY_PER_COLUMN * nc)
+            if tight_h is None or viol:
+                return None
+            tight = torch.as_tensor(np.ascontiguousarray(tight_h, dtype=np.int32), device=self.entries_device)
+        self._listed = (np.array(u, copy=True), np.array(v, copy=True), np.array(col4row, copy=True), tau, tight_h, red_h)
         if tight.shape[0] == 0:
             return np.full((nr, 1), -1, dtype=np.int32), np.full((nr, 1), np.inf)
         r = tight[:, 0].long()
@@ -407,7 +428,7 @@ class FilteredMatrix:
     def threshold_select(self, u, v, col4row):
         """-> (cols [nr, kmax] int32, -1 padded; exact costs [nr, kmax], inf padded) of every non-matched entry whose EXACT reduced
         cost can be below REL_EPS_COLLECT x scale, or None if the list overflowed."""
-        if self.exact_entries_t is not None and hasattr(self.A, "certificate_t"):
+        if self.exact_entries_t is not None and (hasattr(self.A, "certificate_t") or self.entries_device is not None):
             return self._threshold_select_t(u, v, col4row)
         nr = self.shape[0]
         tau = self._tau(u, v)

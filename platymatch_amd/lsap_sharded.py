@@ -398,7 +398,8 @@ def _share_result(wire, out, root):
     return (got[0].copy() if has_h else None), (got[1].copy() if has_t else None)
 
 
-def solve_pair_sharded_filtered(local_filter, exact_entries, cost_delta, bounds, n_cols, group, root, info=None):
+def solve_pair_sharded_filtered(local_filter, exact_entries, cost_delta, bounds, n_cols, group, root, info=None, exact_entries_t=None,
+                                entries_device=None):
     """One pairing (hypothesis + twin) from ROW BLOCKS OF ITS FILTER MATRIX (pipeline.assign_sharded_filtered): local_filter is this
     rank's block of an approximate matrix within cost_delta of both exact matrices (lsap.DeviceMatrix over the float32 block; the CPU
     tests pass a NumPy double).  The root runs lsap.solve_core on a lsap.FilteredMatrix whose selector is the ShardedMatrix over
@@ -413,7 +414,8 @@ def solve_pair_sharded_filtered(local_filter, exact_entries, cost_delta, bounds,
         try:
             info = {} if info is None else info
             tinfo = info["twin"] = {}
-            M = lsap.FilteredMatrix(ShardedMatrix(locals_, 0, wire), exact_entries, cost_delta)
+            M = lsap.FilteredMatrix(ShardedMatrix(locals_, 0, wire), exact_entries, cost_delta, exact_entries_t=exact_entries_t,
+                                    entries_device=entries_device)
             sol = lsap.solve_core(M, info)
             if sol is not None:
                 ok = lsap.certify_listed(M, *sol, exact_entries=exact_entries, cost_delta=cost_delta, infos=[info, tinfo])
@@ -490,7 +492,8 @@ def solve_pairs_sharded_filtered(jobs, group, cost_delta, poll_s=1e-4):
     """Several pairings from row blocks of their filter matrices, the roots' host solvers running concurrently.
     jobs: list of dicts {local: this rank's block of the pairing's filter matrix, exact_entries: (rows, cols) -> (exact hypothesis
     values, exact twin values) — called on the pairing's root only —, bounds, n_cols, root, info (dict or None), device / stream
-    (optional: the GPU and stream the root's exact evaluations belong to — a new thread would start on device 0's default stream)}.
+    (optional: the GPU and stream the root's exact evaluations belong to — a new thread would start on device 0's default stream),
+    exact_entries_t (optional: the same with GPU tensors in and out; the root then finishes its selections on `device`)}.
     -> list of (col4row, col4row) | (None, None) per job, on every rank (as solve_pair_sharded_filtered)."""
     import threading
     import time
@@ -517,7 +520,8 @@ def solve_pairs_sharded_filtered(jobs, group, cost_delta, poll_s=1e-4):
         try:
             info = job["info"] if job.get("info") is not None else {}
             tinfo = info["twin"] = {}
-            M = lsap.FilteredMatrix(MultiplexedMatrix([job["local"]], 0, wires[k], ch), job["exact_entries"], cost_delta)
+            M = lsap.FilteredMatrix(MultiplexedMatrix([job["local"]], 0, wires[k], ch), job["exact_entries"], cost_delta,
+                                    exact_entries_t=job.get("exact_entries_t"), entries_device=job.get("device"))
             sol = lsap.solve_core(M, info)
             if sol is not None:
                 ok = lsap.certify_listed(M, *sol, exact_entries=job["exact_entries"], cost_delta=cost_delta, infos=[info, tinfo])

@@ -878,15 +878,25 @@ def assign_sharded_filtered(be, sc_m, sc_f, bounds, group, streamed=False, info=
             return tuple(np.asarray(x.cpu().numpy() if nat.is_torch(x) else x, dtype=np.float64) for x in be.chi2_entries(sc_m1_full, sc_f1, t, r, c))
         return fetch
 
+    on_gpu = bool(getattr(sc_f1, "is_cuda", False))
+
+    def fetcher_t(t):                       # the same with GPU tensors (index lists from the library's own kernels / the ranks' answers)
+        if not on_gpu:
+            return None
+
+        def fetch_t(rows, cols):
+            r, c = (rows, cols) if n <= m else (cols, rows)
+            return be.chi2_entries(sc_m1_full, sc_f1, t, r, c, trusted=True)
+        return fetch_t
+
     together = None
     pinfos = [dict() for _ in range(4)]
     if F4 is not None and SHARDED_PAIRINGS_CONCURRENT:
         # all four pairings at once: the roots' host solvers run concurrently (pairing t on rank t mod G, a thread each), one serving
         # loop per rank answers their queries in turn (lsap_sharded.solve_pairs_sharded_filtered)
         from .lsap_sharded import solve_pairs_sharded_filtered
-        on_gpu = bool(getattr(sc_f1, "is_cuda", False))
         import torch
-        jobs = [dict(local=lm(F4[t]), exact_entries=fetcher(t), bounds=rb, n_cols=max(n, m), root=t % world, info=pinfos[t],
+        jobs = [dict(local=lm(F4[t]), exact_entries=fetcher(t), exact_entries_t=fetcher_t(t), bounds=rb, n_cols=max(n, m), root=t % world, info=pinfos[t],
                      device=sc_f1.device if on_gpu else None, stream=torch.cuda.current_stream(sc_f1.device) if on_gpu else None)
                 for t in range(4)]
         together = solve_pairs_sharded_filtered(jobs, group, delta)
@@ -899,7 +909,8 @@ def assign_sharded_filtered(be, sc_m, sc_f, bounds, group, streamed=False, info=
                 Ft = F4[t]
             else:
                 Ft = buf = be.chi2_filter_pair(a_loc, b_all, t, out=buf, dtype=_filter_dtype())
-            c_h, c_t = solve_pair_sharded_filtered(lm(Ft), fetcher(t), delta, rb, max(n, m), group, t % world, pinfo)
+            c_h, c_t = solve_pair_sharded_filtered(lm(Ft), fetcher(t), delta, rb, max(n, m), group, t % world, pinfo,
+                                                   exact_entries_t=fetcher_t(t), entries_device=sc_f1.device if on_gpu else None)
         if c_h is None or c_t is None:
             fallback.append(t)
             continue
