@@ -19,6 +19,8 @@
 //   free), A rows are wave-uniform broadcasts.
 //   The block id is remapped so that each XCD walks a contiguous run of tiles, ordered in groups of 8
 //   column tiles (tile_of): concurrent workgroups of an XCD share a few A and B tiles in its L2.
+#include <algorithm>
+#include <cstdlib>
 #include "pm_common.h"
 
 namespace pm {
@@ -45,6 +47,22 @@ __device__ __forceinline__ void tile_of(unsigned int lid, int nTi, unsigned int 
     ti = (int)(rem / gcols);
     tj = (int)(g * CH_GJ + rem % gcols);
 }
+
+// A HIP launch holds fewer than 2^32 work-items per grid dimension (gridDim.x * blockDim.x); beyond that this runtime neither
+// refuses the launch nor runs all of it — 140 000 x 140 000 nuclei are 19.1 M tiles of 16 x 64 = 4.9e9 threads, and the filter
+// matrix came back mostly unwritten (round 5: every row "violated" in every pricing round, tools/solve_trace.py).  The tile
+// launchers therefore cut the tile rows into BANDS of at most CH_MAX_BLOCKS tiles, one launch per band on offset pointers.
+// (PM_CHI2_MAX_BLOCKS in the environment lowers the cap: the tests force many bands on a small problem with it.)
+constexpr long CH_MAX_BLOCKS = 0xffffffffL / CH_THREADS;
+inline long max_blocks() {
+    const char *e = getenv("PM_CHI2_MAX_BLOCKS");          // (read per launch: a test switches it within one process)
+    const long v = e ? atol(e) : 0;
+    return (v > 0 && v < CH_MAX_BLOCKS) ? v : CH_MAX_BLOCKS;
+}
+inline long band_tile_rows(long nTj) {
+    const long cap = max_blocks();
+    return nTj > cap ? 0 : cap / nTj;
+}      // 0: one tile row alone is too wide
 
 template <int NFA, int NFB>
 struct Chi2Args {
@@ -137,9 +155,16 @@ __global__ __launch_bounds__(CH_THREADS) void chi2_kernel(Chi2Args<NFA, NFB> arg
 template <int NFA, int NFB>
 int chi2_launch(const Chi2Args<NFA, NFB> &args, int nA, int nB, double *out, size_t ld, size_t mstride, hipStream_t s) {
     const long nTi = ((long)nA + CH_TI - 1) / CH_TI, nTj = ((long)nB + CH_TJ - 1) / CH_TJ;
-    const long nblocks = nTi * nTj;
-    if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
-    chi2_kernel<NFA, NFB><<<(unsigned int)nblocks, CH_THREADS, 0, s>>>(args, nA, nB, out, ld, mstride, (int)nTi, (unsigned int)nblocks);
+    const long band = band_tile_rows(nTj);
+    if (band == 0) return PM_ERR_INVALID_ARG;
+    for (long t0 = 0; t0 < nTi; t0 += band) {
+        const long tiles = std::min(band, nTi - t0), r0 = t0 * CH_TI;
+        const int rows = (int)std::min((long)nA - r0, tiles * CH_TI);
+        Chi2Args<NFA, NFB> part = args;
+        for (int f = 0; f < NFA; ++f) part.a[f] = args.a[f] + (size_t)r0 * PM_NBINS;
+        const unsigned int nblocks = (unsigned int)(tiles * nTj);
+        chi2_kernel<NFA, NFB><<<nblocks, CH_THREADS, 0, s>>>(part, rows, nB, out + (size_t)r0 * ld, ld, mstride, (int)tiles, nblocks);
+    }
     return launch_status();
 }
 
@@ -644,12 +669,18 @@ int chi2_sym_launch(const double *sc_m1, int nM, const double *sc_f1, int nF, do
                     const unsigned char *cntA = nullptr, const unsigned char *cntB = nullptr, const SymMeta *meta = nullptr,
                     const double *sumA = nullptr, const double *sumB = nullptr) {
     const long nTi = ((long)nM + 4 * RI - 1) / (4 * RI), nTj = ((long)nF + CH_TJ - 1) / CH_TJ;
-    const long nblocks = nTi * nTj;
-    if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
+    const long band = band_tile_rows(nTj);
+    if (band == 0) return PM_ERR_INVALID_ARG;
     if (TL > 0 && (!cntA || !cntB || !meta)) return PM_ERR_INVALID_ARG;
     if (RELAX && (!sumA || !sumB)) return PM_ERR_INVALID_ARG;
-    chi2_sym_kernel<RI, MINW, TSEL, TL, RELAX><<<(unsigned int)nblocks, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, mstride, (int)nTi,
-                                                                                           (unsigned int)nblocks, cntA, cntB, meta, sumA, sumB);
+    for (long t0 = 0; t0 < nTi; t0 += band) {              // (one band up to ~130 000 x 130 000; see CH_MAX_BLOCKS)
+        const long tiles = std::min(band, nTi - t0), r0 = t0 * 4 * RI;
+        const int rows = (int)std::min((long)nM - r0, tiles * 4 * RI);
+        const unsigned int nblocks = (unsigned int)(tiles * nTj);
+        chi2_sym_kernel<RI, MINW, TSEL, TL, RELAX><<<nblocks, CH_THREADS, 0, s>>>(
+            sc_m1 + (size_t)r0 * PM_NBINS, rows, sc_f1, nF, out + (size_t)r0 * ld, ld, mstride, (int)tiles, nblocks,
+            cntA ? cntA + (size_t)r0 * PM_NBINS : nullptr, cntB, meta, sumA ? sumA + r0 : nullptr, sumB);
+    }
     return launch_status();
 }
 
@@ -853,16 +884,21 @@ static int filter_launch(const double *sc_m1, int nM, const double *sc_f1, int n
     relaxed_rowsum_kernel<<<(nM + 255) / 256, 256, 0, s>>>(sc_m1, nM, sumA);
     relaxed_rowsum_kernel<<<(nF + 255) / 256, 256, 0, s>>>(sc_f1, nF, sumB);
     const long nTi = ((long)nM + 15) / 16, nTj = ((long)nF + CH_TJ - 1) / CH_TJ;
-    const long nblocks = nTi * nTj;
-    if (nblocks > 0x7fffffffL) return PM_ERR_INVALID_ARG;
-    const unsigned int grid = (unsigned int)nblocks;
-    switch (pairing) {
-        case -1: filter4_kernel<-1, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, matrix_stride, (int)nTi, grid, sumA, sumB); break;
-        case 0: filter4_kernel<0, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
-        case 1: filter4_kernel<1, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
-        case 2: filter4_kernel<2, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
-        case 3: filter4_kernel<3, OUT><<<grid, CH_THREADS, 0, s>>>(sc_m1, nM, sc_f1, nF, out, ld, 0, (int)nTi, grid, sumA, sumB); break;
-        default: return PM_ERR_INVALID_ARG;
+    const long band = band_tile_rows(nTj);
+    if (band == 0 || pairing < -1 || pairing > 3) return PM_ERR_INVALID_ARG;
+    for (long t0 = 0; t0 < nTi; t0 += band) {              // (one band up to ~130 000 x 130 000; see CH_MAX_BLOCKS)
+        const long tiles = std::min(band, nTi - t0), r0 = t0 * 16;
+        const int rows = (int)std::min((long)nM - r0, tiles * 16);
+        const unsigned int grid = (unsigned int)(tiles * nTj);
+        const double *a = sc_m1 + (size_t)r0 * PM_NBINS, *sa = sumA + r0;
+        OUT *o = out + (size_t)r0 * ld;
+        switch (pairing) {
+            case -1: filter4_kernel<-1, OUT><<<grid, CH_THREADS, 0, s>>>(a, rows, sc_f1, nF, o, ld, matrix_stride, (int)tiles, grid, sa, sumB); break;
+            case 0: filter4_kernel<0, OUT><<<grid, CH_THREADS, 0, s>>>(a, rows, sc_f1, nF, o, ld, 0, (int)tiles, grid, sa, sumB); break;
+            case 1: filter4_kernel<1, OUT><<<grid, CH_THREADS, 0, s>>>(a, rows, sc_f1, nF, o, ld, 0, (int)tiles, grid, sa, sumB); break;
+            case 2: filter4_kernel<2, OUT><<<grid, CH_THREADS, 0, s>>>(a, rows, sc_f1, nF, o, ld, 0, (int)tiles, grid, sa, sumB); break;
+            default: filter4_kernel<3, OUT><<<grid, CH_THREADS, 0, s>>>(a, rows, sc_f1, nF, o, ld, 0, (int)tiles, grid, sa, sumB); break;
+        }
     }
     return launch_status();
 }

@@ -189,7 +189,7 @@ int pm_row_argmin(const double *U, int n_mat, int rows, int cols, size_t ld, siz
     if (n_mat > 1 && matrix_stride < (size_t)(rows - 1) * ld + (size_t)cols) return PM_ERR_INVALID_ARG;
     const long long total = (long long)n_mat * rows;
     const long long blocks = (total + 3) / 4;
-    if (blocks > 0x7fffffffLL) return PM_ERR_INVALID_ARG;
+    if (blocks > 0xffffffffLL / 256) return PM_ERR_INVALID_ARG;      // (a launch holds fewer than 2^32 work-items)
     pm::row_argmin_kernel<<<(unsigned int)blocks, 256, 0, (hipStream_t)stream>>>(U, total, rows, cols, ld, matrix_stride, idx, val);
     return pm::launch_status();
 }
@@ -211,7 +211,7 @@ int pm_label_moments(const int32_t *labels, int nz, int ny, int nx, int n_labels
     if (hipMemsetAsync(sums3, 0, sizeof(unsigned long long) * 3 * (size_t)n_labels, s) != hipSuccess) return pm::launch_status();
     const long long chunks = (nx + pm::LM_RUN - 1) / pm::LM_RUN;
     const long long blocks = ((chunks + pm::LM_TX - 1) / pm::LM_TX) * ((ny + pm::LM_TY - 1) / pm::LM_TY) * ((nz + pm::LM_TZ - 1) / pm::LM_TZ);
-    if (blocks > 0x7fffffffLL) return PM_ERR_INVALID_ARG;
+    if (blocks > 0xffffffffLL / 256) return PM_ERR_INVALID_ARG;      // (a launch holds fewer than 2^32 work-items)
     pm::label_moments_kernel<<<(unsigned int)blocks, 256, 0, s>>>(labels, nz, ny, nx, n_labels, counts, sums3, (int *)counts);
     return pm::launch_status();
 }

@@ -323,3 +323,42 @@ def test_filter_mode_leases_what_it_writes_and_stays_resident_where_only_that_fi
     assert "streamed" in str(ds["assignment"].get("mode", "")), ds["assignment"].get("mode")
     assert np.array_equal(a[2], c[2]) and np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
     g.P.release_cost_buffers()
+
+
+def test_banded_tile_launches_write_the_single_launch_matrices(g, monkeypatch):
+    """A launch holds fewer than 2^32 work-items: from ~130 000 x 130 000 nuclei the tile launchers (16 x 64 entries per workgroup
+    of 256) cut the tile rows into bands, one launch per band on offset pointers (csrc/pm_chi2.hip: band_tile_rows; found at
+    140 000 nuclei, where one launch left most of the filter matrix unwritten).  PM_CHI2_MAX_BLOCKS forces the banding at a size
+    the suite can afford — ragged last band, ragged last tile row — and every build must write the bits of its one-launch self:
+    the exact eight (table kernel and generic four-frame kernel), one exact pairing, the relaxed build, the filter in both
+    storage types, four pairings at once and one alone."""
+    n, m = 1111, 777                                    # 70 tile rows (the last one 7 rows) x 13 tile columns
+    mv, fx, _ = synth_pair(max(n, m), 5)
+    be = g.P.GpuBackend()
+    sc_m, sc_f, _ = g.P.build_descriptors(be, be.cloud(np.ascontiguousarray(mv[:, :n])), be.cloud(np.ascontiguousarray(fx[:, :m])))
+
+    def builds():
+        out = {"exact8": g.K.chi2_cost8(sc_m, sc_f), "general8": g.K.chi2_cost8(sc_m, sc_f, path="general"),
+               "computed8": g.K.chi2_cost8(sc_m, sc_f, path="symmetric-computed"),
+               "relaxed": g.K.chi2_cost8_relaxed(sc_m[0], sc_f[0]), "filter4": g.K.chi2_filter4(sc_m[0], sc_f[0]),
+               "filter4_f32": g.K.chi2_filter4(sc_m[0], sc_f[0], dtype=g.t.float32), "one": g.K.chi2_cost(sc_m[1], sc_f[2])}
+        for t in range(4):
+            out["pair%d" % t] = g.K.chi2_cost_pair(sc_m, sc_f, t, True)
+            out["filter_pair%d" % t] = g.K.chi2_filter_pair(sc_m[0], sc_f[0], t, dtype=g.t.float32)
+        g.t.cuda.synchronize()
+        return out
+
+    monkeypatch.delenv("PM_CHI2_MAX_BLOCKS", raising=False)
+    whole = builds()
+    for cap in (13, 13 * 9 + 5, 13 * 69):               # one tile row per band (70 launches); 9 per band, ragged; 69 + 1
+        monkeypatch.setenv("PM_CHI2_MAX_BLOCKS", str(cap))
+        banded = builds()
+        for k in whole:
+            a, b = whole[k], banded[k]
+            if isinstance(a, (tuple, list)):
+                assert all(g.t.equal(x, y) for x, y in zip(a, b)), (cap, k)
+            else:
+                assert g.t.equal(a, b), (cap, k)
+    monkeypatch.setenv("PM_CHI2_MAX_BLOCKS", "12")      # narrower than one tile row: refused, not truncated
+    with pytest.raises(Exception):
+        g.K.chi2_filter_pair(sc_m[0], sc_f[0], 0, dtype=g.t.float32)
