@@ -300,3 +300,37 @@ def test_repeated_large_registrations_keep_their_cost_buffer_and_do_not_run_out_
     P.release_cost_buffers()
     torch.cuda.empty_cache()
     assert P.kept_cost_bytes(dev) == 0
+
+
+def test_a_filter_matrix_beyond_one_launch_is_written_completely():
+    """140 000 x 140 000 nuclei = 19.1 M tiles of 16 x 64 entries = 4.9e9 work-items: more than one launch holds (< 2^32).  The
+    tile launchers cut the tile rows into bands (csrc/pm_chi2.hip: band_tile_rows; before, the runtime neither refused nor
+    completed that launch and registrations of this size never finished).  Every entry of the 78 GB float32 filter matrix must
+    be written, and complete rows around the band boundary (tile row 7 667 = row 122 672), the first and the last ones must lie
+    within the filter's bound of the exact entries (pm_chi2_entries_sym: the bits of shape_context.py:88-99)."""
+    import torch
+    from conftest import synth_pair
+    from platymatch_amd import _kernels as K, pipeline as P
+    n = 140_000
+    P.release_cost_buffers()
+    torch.cuda.empty_cache()
+    if torch.cuda.mem_get_info()[0] < 110e9:
+        pytest.skip("needs 110 GB of free HBM")
+    mv, fx, _ = synth_pair(n, 42)
+    be = P.GpuBackend()
+    sc_m, sc_f, _ = P.build_descriptors(be, be.cloud(mv), be.cloud(fx))
+    a, b = sc_m[0], sc_f[0]
+    F = torch.full((n, n), float("nan"), dtype=torch.float32, device=a.device)
+    K.chi2_filter_pair(a, b, 1, out=F)
+    for r0 in range(0, n, 10_000):                                   # (slabs: the comparison's temporary stays at 1.4 GB)
+        assert not bool(torch.isnan(F[r0:r0 + 10_000]).any()), "rows from %d hold unwritten entries" % r0
+    band_rows = (0xffffffff // 256) // ((n + 63) // 64) * 16
+    assert 0 < band_rows < n                                         # this size does need a second band
+    delta = K.chi2_filter_delta()
+    cols = torch.arange(n, dtype=torch.int32, device=a.device)
+    for row in (0, 15, 16, band_rows - 16, band_rows - 1, band_rows, band_rows + 17, n - 17, n - 1):
+        exact = K.chi2_entries(a, b, 1, torch.full((n,), row, dtype=torch.int32, device=a.device), cols, trusted=True)
+        for e in exact:                                              # natural-order and rolled-order twin
+            assert float((F[row].double() - e).abs().max()) <= delta, row
+    del F
+    torch.cuda.empty_cache()
