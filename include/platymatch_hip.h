@@ -41,6 +41,7 @@ extern "C" {
 #define PM_ERR_WORKSPACE (-2)     /* workspace missing or too small */
 #define PM_ERR_LAUNCH (-3)        /* HIP reported an error enqueuing work; see pm_last_hip_error() */
 #define PM_ERR_UNSUPPORTED (-4)   /* valid in the reference, not implemented on the device path */
+#define PM_ERR_NO_MEMORY (-5)     /* pm_device_alloc: the device has no block of that size left */
 
 #define PM_AFFINE 0  /* transform='Affine'  (find_transform.py:4-17)  */
 #define PM_SIMILAR 1 /* transform='Similar' (find_transform.py:21-99) — host-side only, see DESIGN.md */
@@ -48,6 +49,17 @@ extern "C" {
 int pm_version(void);
 const char *pm_error_string(int code);
 int pm_last_hip_error(void); /* hipError_t of the calling thread's most recent PM_ERR_LAUNCH */
+
+/* Device memory for the matrices of this path, straight from the driver (hipMalloc / hipFree on `device`; the calling thread's
+ * current device is left as it was).  The reference keeps its eight N x M matrices in NumPy arrays (_dock_widget.py:547-602:
+ * eight np.zeros((N, M))); here they are 64 N M bytes of HBM — 160 GB at 50 000 nuclei — and a general-purpose caching
+ * allocator that splits such a block for a small request can neither reuse nor return it afterwards.  The Python mirror
+ * (platymatch_amd/device_memory.py) takes every block of 4 GiB and more from these entries and keeps the idle ones itself, whole;
+ * a C caller needs them anyway: every other entry of this header takes device pointers.  pm_device_free waits for the device's
+ * outstanding work.  PM_ERR_NO_MEMORY: no block of that size left (nothing was allocated, *out = NULL). */
+int pm_device_alloc(int device, size_t bytes, void **out);
+int pm_device_free(int device, void *ptr);
+int pm_device_memory(int device, size_t *free_bytes, size_t *total_bytes);
 
 /* Measurement aid (bench.py; nothing of the path calls it): ONE wave that samples the shader clock while other work runs on the
  * device.  Every period_ticks ticks of the constant 100 MHz counter (s_memrealtime) it stores the pair (s_memtime, s_memrealtime)

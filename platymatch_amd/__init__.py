@@ -25,6 +25,13 @@ def reserve(n, m=None, cost_mode='auto', device=None):
     return run(n, m, cost_mode=cost_mode, device=device)
 
 
+def release_memory(device=None):
+    """Give the device memory this package holds without using back to the driver: the kept cost buffers no registration holds,
+    the idle matrix blocks (device_memory.py) and torch's idle cache.  The next large registration pays its allocation again."""
+    from .device_memory import release_everything_idle
+    release_everything_idle(device)
+
+
 def install_as_platymatch():
     """Register this package's modules under the reference's import paths
     (platymatch.estimate_transform.{shape_context,find_transform,apply_transform,perform_icp},

@@ -2,7 +2,7 @@
 
 Every function validates shapes, dtypes and index ranges on the host before a kernel is
 enqueued (a faulting kernel can take the whole node down), allocates outputs/workspace with
-torch, and launches on torch's current stream.  Clouds are float64 [3, N] contiguous.
+torch (whole matrices of 4 GiB and more: device_memory.big_empty), and launches on torch's current stream.  Clouds are float64 [3, N] contiguous.
 """
 import os
 
@@ -10,6 +10,7 @@ import numpy as np
 
 from . import _native as nat
 from ._native import NBINS, ICP_NSUMS, check, ptr
+from .device_memory import big_empty
 
 
 def _t():
@@ -134,7 +135,7 @@ def cdist(a, b, out=None):
     a, b = _cloud(a, "a"), _cloud(b, "b")
     n, m = a.shape[1], b.shape[1]
     if out is None:
-        out = torch.empty((n, m), dtype=torch.float64, device=a.device)
+        out = big_empty((n, m), torch.float64, a.device)
     elif not (out.is_cuda and out.dtype == torch.float64 and tuple(out.shape) == (n, m) and out.stride(1) == 1):
         raise ValueError("out must be float64 GPU [n, m] with unit column stride")
     check(nat.load().pm_cdist(ptr(a), n, ptr(b), m, ptr(out), out.stride(0), nat.stream_ptr()))
@@ -274,7 +275,7 @@ def chi2_cost(scA, scB, out=None):
     a, b = _desc(scA, "scA"), _desc(scB, "scB")
     nA, nB = a.shape[0], b.shape[0]
     if out is None:
-        out = torch.empty((nA, nB), dtype=torch.float64, device=a.device)
+        out = big_empty((nA, nB), torch.float64, a.device)
     elif not (out.is_cuda and out.dtype == torch.float64 and tuple(out.shape) == (nA, nB) and out.stride(1) == 1):
         raise ValueError("out must be float64 GPU [nA, nB] with unit column stride")
     check(nat.load().pm_chi2_cost(ptr(a), nA, ptr(b), nB, ptr(out), out.stride(0), nat.stream_ptr()))
@@ -355,7 +356,7 @@ def chi2_filter4(sc_m1, sc_f1, out=None, dtype=None):
     a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
     nM, nF = a.shape[0], b.shape[0]
     if out is None:
-        out = torch.empty((4, nM, nF), dtype=dtype or torch.float64, device=a.device)
+        out = big_empty((4, nM, nF), dtype or torch.float64, a.device)
     if (tuple(out.shape) != (4, nM, nF) or out.dtype not in (torch.float64, torch.float32) or out.device != a.device or out.stride(2) != 1
             or out.stride(1) < nF or out.stride(0) < nM * out.stride(1)):
         raise ValueError("out must be a float64 or float32 tensor [4, nM, nF] on the descriptors' device with unit column stride")
@@ -373,7 +374,7 @@ def chi2_filter_pair(sc_m1, sc_f1, pairing, out=None, dtype=None):
     a, b = _desc(sc_m1, "sc_m1"), _desc(sc_f1, "sc_f1")
     nM, nF = a.shape[0], b.shape[0]
     if out is None:
-        out = torch.empty((nM, nF), dtype=dtype or torch.float64, device=a.device)
+        out = big_empty((nM, nF), dtype or torch.float64, a.device)
     if (tuple(out.shape) != (nM, nF) or out.dtype not in (torch.float64, torch.float32) or out.device != a.device or out.stride(1) != 1
             or out.stride(0) < nF):
         raise ValueError("out must be a float64 or float32 tensor [nM, nF] on the descriptors' device with unit column stride")
@@ -465,7 +466,7 @@ def chi2_cost_pair(sc_m, sc_f, pairing, symmetric, out=None):
         raise ValueError("pairing must be 0..3")
     nM, nF = sc_m.shape[1], sc_f.shape[1]
     if out is None:
-        out = torch.empty((2, nM, nF), dtype=torch.float64, device=sc_m.device)
+        out = big_empty((2, nM, nF), torch.float64, sc_m.device)
     elif not (out.is_cuda and out.dtype == torch.float64 and tuple(out.shape) == (2, nM, nF) and out.is_contiguous()):
         raise ValueError("out must be a contiguous float64 GPU tensor [2, nM, nF]")
     if symmetric:
@@ -486,7 +487,7 @@ def chi2_cost_pair(sc_m, sc_f, pairing, symmetric, out=None):
 def _out8(out, nM, nF, device):
     torch = _t()
     if out is None:
-        return torch.empty((8, nM, nF), dtype=torch.float64, device=device)
+        return big_empty((8, nM, nF), torch.float64, device)
     if not (out.is_cuda and out.dtype == torch.float64 and tuple(out.shape) == (8, nM, nF) and out.stride(2) == 1
             and out.stride(0) >= nM * out.stride(1) and out.stride(1) >= nF):
         raise ValueError("out must be float64 GPU [8, nM, nF] with unit column stride")

@@ -26,6 +26,9 @@ SIGNATURES = {
     "pm_version": (_c_int, []),
     "pm_error_string": (ctypes.c_char_p, [_c_int]),
     "pm_last_hip_error": (_c_int, []),
+    "pm_device_alloc": (_c_int, [_c_int, _c_size_t, _c_void_p]),
+    "pm_device_free": (_c_int, [_c_int, _c_void_p]),
+    "pm_device_memory": (_c_int, [_c_int, _c_void_p, _c_void_p]),
     "pm_clock_probe": (_c_int, [_c_void_p, _c_int, ctypes.c_ulonglong, _c_void_p]),
     "pm_centroid_workspace": (_c_size_t, [_c_int]),
     "pm_centroid": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),

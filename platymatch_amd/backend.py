@@ -4,6 +4,7 @@ import numpy as np
 
 from . import _native as nat
 from .cost_buffers import kept_cost_bytes
+from .device_memory import idle_bytes
 
 RELAXED_VARIANT = 2            # pm_chi2_cost8_relaxed: 0 all computed, 1 94 x 94 term table, 2 64 x 64 table at three waves per SIMD (fastest at 50k)
 
@@ -111,7 +112,8 @@ class GpuBackend:
         registration of the same size into the streamed mode)."""
         import torch
         cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
-        return torch.cuda.mem_get_info(self.device)[0] + max(int(cached), 0) + kept_cost_bytes(self.device)   # (+ this stream's kept buffer: it IS the room)
+        # (+ this stream's kept buffer: it IS the room; + the idle raw blocks of device_memory.py: released when an allocation needs them)
+        return torch.cuda.mem_get_info(self.device)[0] + max(int(cached), 0) + kept_cost_bytes(self.device) + idle_bytes(self.device)
 
     def row_argmin(self, U):
         return self.K.row_argmin(U)

@@ -1,11 +1,14 @@
 """Several independent registrations (BASELINE config 5: "replicas only" — pairs never exchange data): worker threads with a HIP
 stream each on one GPU, pairs dealt to ranks largest first on several."""
+import contextlib
 import dataclasses
 import threading
 
 import numpy as np
 
 from . import _native as nat
+from .device_memory import idle_bytes, through_torch
+
 
 def batch_costs(sizes):
     """Relative cost of a registration of N x M nuclei, for sharing a batch out: the eight N x M cost matrices grow
@@ -52,7 +55,7 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
     in_flight = [0.0]
     budget = 0.0
     if on_gpu:
-        free_b = torch.cuda.mem_get_info(dev)[0] + max(int(torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)), 0)
+        free_b = torch.cuda.mem_get_info(dev)[0] + max(int(torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)), 0) + idle_bytes(dev)
         budget = 0.8 * free_b                # (what torch's allocator holds unused is there to be drawn on, as in GpuBackend.free_bytes)
 
     def need(k):
@@ -83,7 +86,8 @@ def _run_local(pairs, ks, workers, seeds, kwargs, timings=None, reports=None):
                 from . import lsap
                 lsap.set_pin_base(None if (workers > 1 and len(ks) > 1) else 0)     # several registrations side by side: placement left to the scheduler (measured)
                 stream = nat.side_stream(dev, ("batch worker", worker_slot()))   # persistent per worker thread
-                with torch.cuda.device(dev), torch.cuda.stream(stream):
+                side_by_side = through_torch() if (workers > 1 and len(ks) > 1) else contextlib.nullcontext()
+                with torch.cuda.device(dev), torch.cuda.stream(stream), side_by_side:
                     out = estimate_transform(pairs[k][0], pairs[k][1], seed=seeds[k], details=det, options=opts, **kwargs)
                     stream.synchronize()
             finally:

@@ -12,7 +12,7 @@ import numpy as np
 # registration of a process ran out of memory with 149 GB "reserved but unallocated").  Buffers below COST_CACHE_MIN_BYTES
 # (and every registration of a batch) go through the allocator as before.  release_cost_buffers() gives the memory back.
 _COST_CACHE = {}
-_COST_LOCK = threading.Lock()
+_COST_LOCK = threading.RLock()        # (re-entrant: an allocation that fails inside cost_buffer() releases the other streams' idle buffers)
 
 
 def _cost_key(device):
@@ -41,6 +41,7 @@ def cost_buffer(device, shape):
     """Lease a float64 [shape] view of this (device, stream)'s kept buffer, grown if it is too small (the old one is released
     first).  -> _CostLease, or None when another registration holds the buffer: the caller then takes a fresh allocation."""
     import torch
+    from .device_memory import big_empty
     need = int(np.prod(shape))
     key = _cost_key(device)
     with _COST_LOCK:
@@ -50,7 +51,8 @@ def cost_buffer(device, shape):
         if e is None or e["t"].numel() < need:
             _COST_CACHE.pop(key, None)
             e = None                                       # (released before the larger one is asked for)
-            e = {"t": torch.empty(need, dtype=torch.float64, device=device), "lease": None}
+            # (a raw block, device_memory.py: released = back with the driver at once, never split by torch for something small)
+            e = {"t": big_empty((need,), torch.float64, device, keep=False), "lease": None}
             _COST_CACHE[key] = e
         lease = _CostLease(key, e["t"][:need].view(*shape))
         e["lease"] = lease

@@ -30,6 +30,54 @@ int pm_clock_probe(unsigned long long *samples, int n_samples, unsigned long lon
     return pm::launch_status();
 }
 
+// ---- device memory outside any caching allocator (platymatch_amd/device_memory.py; a C caller's malloc / free) ----------------
+namespace pm {
+struct OnDevice {                                     // the calling thread's current device is put back on every path
+    int prev = -1;
+    hipError_t err;
+    explicit OnDevice(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+    }
+    ~OnDevice() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+static int hip_failure(hipError_t e) {
+    (void)hipGetLastError();                          // (a failed allocation leaves its code behind: the next launch_status must not see it)
+    g_last_hip_error = (int)e;
+    return e == hipErrorOutOfMemory ? PM_ERR_NO_MEMORY : PM_ERR_LAUNCH;
+}
+}  // namespace pm
+
+int pm_device_alloc(int device, size_t bytes, void **out) {
+    if (!out || bytes == 0 || device < 0) return PM_ERR_INVALID_ARG;
+    *out = nullptr;
+    pm::OnDevice here(device);
+    if (here.err != hipSuccess) return pm::hip_failure(here.err);
+    void *p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return pm::hip_failure(e);
+    *out = p;
+    return PM_OK;
+}
+
+int pm_device_free(int device, void *ptr) {
+    if (device < 0 || !ptr) return PM_ERR_INVALID_ARG;
+    pm::OnDevice here(device);
+    if (here.err != hipSuccess) return pm::hip_failure(here.err);
+    const hipError_t e = hipFree(ptr);                // (waits for the device's outstanding work: a block is never pulled from under a kernel)
+    return e == hipSuccess ? PM_OK : pm::hip_failure(e);
+}
+
+int pm_device_memory(int device, size_t *free_bytes, size_t *total_bytes) {
+    if (device < 0 || !free_bytes || !total_bytes) return PM_ERR_INVALID_ARG;
+    pm::OnDevice here(device);
+    if (here.err != hipSuccess) return pm::hip_failure(here.err);
+    const hipError_t e = hipMemGetInfo(free_bytes, total_bytes);
+    return e == hipSuccess ? PM_OK : pm::hip_failure(e);
+}
+
 int pm_version(void) { return PM_ABI_VERSION; }
 
 const char *pm_error_string(int code) {
@@ -39,6 +87,7 @@ const char *pm_error_string(int code) {
         case PM_ERR_WORKSPACE: return "workspace missing or smaller than pm_*_workspace() reports";
         case PM_ERR_LAUNCH: return "HIP reported an error while enqueuing work (see pm_last_hip_error)";
         case PM_ERR_UNSUPPORTED: return "not implemented on the device path";
+        case PM_ERR_NO_MEMORY: return "the device has no block of that size left (pm_device_alloc)";
         default: return "unknown error code";
     }
 }

@@ -14,6 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import _native as nat
+from .device_memory import big_empty
 
 
 def linear_sum_assignment(cost_matrix):
@@ -146,7 +147,7 @@ def transposed(U):
     ~0.4 s for the 19 GB of a 50 000 x 47 000 matrix, the kernel ~15 ms)."""
     torch = nat.torch_mod()
     with torch.cuda.device(U.device):        # the launch goes to a stream of the device that owns U, whatever the current device is
-        out = torch.empty((U.shape[1], U.shape[0]), dtype=torch.float64, device=U.device)
+        out = big_empty((U.shape[1], U.shape[0]), torch.float64, U.device)
         nat.check(nat.load().pm_transpose_f64(nat.ptr(U), U.shape[0], U.shape[1], U.stride(0), nat.ptr(out), out.stride(0), nat.stream_ptr(U)))
     return out
 
@@ -1376,7 +1377,7 @@ def solve_four_filtered(F4, exact_entries, exact_entries_t, cost_delta, exact_pa
         pool = queue.Queue()
         with torch.cuda.device(device):
             for _ in range(workers):
-                pool.put(torch.empty((min(n, m), max(n, m)), dtype=storage or torch.float64, device=device))
+                pool.put(big_empty((min(n, m), max(n, m)), storage or torch.float64, device))
     torch.cuda.current_stream(device).synchronize()       # the descriptors / F4 were produced on the caller's stream
     with ThreadPoolExecutor(max_workers=workers) as ex:
         list(ex.map(pair, range(4)))

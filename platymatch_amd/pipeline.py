@@ -30,6 +30,7 @@ _RNG_LOCK = threading.RLock()
 
 # (the kept cost buffers and their leases: cost_buffers.py)
 COST_CACHE_MIN_BYTES = 8 << 30     # cost buffers of at least this size are kept per (device, stream) between registrations (cost_buffers.py)
+from .device_memory import big_empty  # noqa: E402
 from .cost_buffers import _CostLease, _EarlyLease, cost_buffer, kept_cost_bytes, release_cost_buffers  # noqa: E402,F401
 
 
@@ -382,7 +383,7 @@ def iter_cost_blocks(be, mov, fix, rows_per_block, group=None):
     rank, _ = _world(group)
     rows = sc_m.shape[1]
     rows_per_block = max(1, min(int(rows_per_block), max(rows, 1)))
-    buf = torch.empty((8, rows_per_block, sc_f.shape[1]), dtype=torch.float64, device=sc_m.device)
+    buf = big_empty((8, rows_per_block, sc_f.shape[1]), torch.float64, sc_m.device)
     for r0 in range(0, rows, rows_per_block):
         r1 = min(rows, r0 + rows_per_block)
         out = buf[:, :r1 - r0]

@@ -13,7 +13,8 @@ Tie-prone families stay below --tie-max points, near-duplicates below 6 000 (the
 solver: minutes at 20 000); generic clouds go up to --max-points.
 Worker threads drive independent cases on their own HIP streams.
 Usage: python tools/auto_soak.py --seconds 600 [--cases N] [--max-points 20000] [--tie-max 2500] [--seed0 0] [--workers 4]
-                                 [--filter-from 8192]      (lower it to push small cases through the filter route too)"""
+                                 [--filter-from 8192]      (lower it to push small cases through the filter route too)
+                                 [--min-points 30000 --max-points 60000 --workers 1]      (large cases: the exact mode's 64 N M bytes per case)"""
 import argparse
 import os
 import sys
@@ -31,6 +32,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=300.0)
 ap.add_argument("--cases", type=int, default=10 ** 9)
 ap.add_argument("--max-points", type=int, default=20000)
+ap.add_argument("--min-points", type=int, default=0)      # > 0: LARGE cases only — generic clouds and near-duplicates displaced by >= 1e-7, sizes uniform in [min, max]
 ap.add_argument("--tie-max", type=int, default=2500)
 ap.add_argument("--seed0", type=int, default=0)
 ap.add_argument("--workers", type=int, default=4)
@@ -44,6 +46,8 @@ FAMILIES = ("generic", "near-duplicates", "lattice", "same cloud twice", "planar
 def make(seed):
     rng = np.random.default_rng(7919 * seed + 11)
     kind = FAMILIES[int(rng.choice(len(FAMILIES), p=[0.30, 0.34, 0.10, 0.08, 0.08, 0.10]))]
+    if args.min_points:
+        kind = "generic" if rng.random() < 0.6 else "near-duplicates"
     # (near-duplicates carry nearly or exactly tied cost rows in all eight hypotheses: where the exact mode cannot prove uniqueness
     # it runs the dense host solver — seconds at 6 000 points, minutes at 20 000)
     hi = args.max_points if kind == "generic" else (min(args.max_points, 6000) if kind == "near-duplicates" else min(args.max_points, args.tie_max))
@@ -52,6 +56,8 @@ def make(seed):
         if hi > 8192 and rng.random() < 1.0 / 12.0:
             return int(rng.integers(8192, hi + 1))
         return int(np.exp(rng.uniform(np.log(LO), np.log(min(hi, 6000)))))
+    if args.min_points:
+        size = lambda: int(rng.integers(args.min_points, args.max_points + 1))      # noqa: E731
     n = size()
     m = n if rng.random() < 0.35 else size()
     big = max(n, m)
@@ -86,7 +92,7 @@ def make(seed):
             kk = min(k, cloud.shape[1] // 3)
             src = rng.choice(cloud.shape[1], size=kk, replace=False)
             dst = rng.choice(cloud.shape[1], size=kk, replace=False)
-            cloud[:, dst] = cloud[:, src] + rng.normal(size=(3, kk)) * size_ * 10.0 ** rng.uniform(-12, -4, size=(1, kk))
+            cloud[:, dst] = cloud[:, src] + rng.normal(size=(3, kk)) * size_ * 10.0 ** rng.uniform(-7 if args.min_points else -12, -4, size=(1, kk))
     scale = float(rng.choice([1.0, 1.0, 1e-3, 1e3]))
     return np.ascontiguousarray(mv * scale), np.ascontiguousarray(fx * scale), kind
 
@@ -144,6 +150,9 @@ def worker(slot):
                 state["done"] += 1
                 if bad:
                     fails.append(bad)
+                    print("MISMATCH " + bad, flush=True)
+                if args.min_points:
+                    print("    %s: %s" % (tag, "raised alike (%s)" % err_e if want is None else "; ".join(sorted(set(modes)))), flush=True)
 
 
 threads = [threading.Thread(target=worker, args=(k,)) for k in range(max(1, args.workers))]
