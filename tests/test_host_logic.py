@@ -166,3 +166,26 @@ def test_batch_cost_model_orders_pairs_largest_first():
     assert P.batch_assignment(sizes, 1) == [0, 0, 0, 0]
     owner = P.batch_assignment(sizes, 2)
     assert owner[1] != owner[2]                                              # the two largest pairs go to different ranks
+
+
+def test_matrix_memory_policy_on_the_host_side():
+    """device_memory.big_empty: below BIG_BLOCK_BYTES (and for anything that is not a GPU tensor) torch's own allocation, whatever
+    the policy switch says; the batch switch nests and is per thread; nothing idle without a GPU."""
+    import threading
+    import torch
+    from platymatch_amd import device_memory as D
+    assert D.BIG_BLOCK_BYTES == 4 << 30 and 0.0 < D.MAX_IDLE_FRACTION < 1.0
+    t = D.big_empty((3, 5), torch.float32, "cpu")
+    assert tuple(t.shape) == (3, 5) and t.dtype == torch.float32 and t.device.type == "cpu"
+    assert D.big_empty(7, torch.float64, "cpu").shape == (7,)
+    assert D.idle_bytes() == 0 and D.trim() == 0
+    seen = []
+    with D.through_torch():
+        with D.through_torch():
+            seen.append(D._THREAD.depth)
+            th = threading.Thread(target=lambda: seen.append(getattr(D._THREAD, "depth", 0)))
+            th.start()
+            th.join()
+        seen.append(D._THREAD.depth)
+    seen.append(D._THREAD.depth)
+    assert seen == [2, 0, 1, 0]
