@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--icp", type=int, default=50)
     ap.add_argument("--json", default=None)
     ap.add_argument("--sequential-too", action="store_true", help="also time workers=1 (one GPU only)")
-    ap.add_argument("--cost-mode", default="exact", choices=("exact", "relaxed", "filter"), help="estimate_transform(cost_mode=...)")
+    ap.add_argument("--cost-mode", default="auto", choices=("auto", "exact", "relaxed", "filter"), help="estimate_transform(cost_mode=...)")
     ap.add_argument("--unseeded", action="store_true", help="no RANSAC seeds: index sets drawn on the device (the default for callers who do not seed)")
     args = ap.parse_args()
     pi.VERBOSE = False
