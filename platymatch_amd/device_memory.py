@@ -82,8 +82,8 @@ def _retire(ptr, nbytes, dev_index, stream, keep):
         if keep:
             _IDLE[ptr] = (dev_index, stream, nbytes)
             cap = MAX_IDLE_FRACTION * _TOTAL.get(dev_index, 0)
-            while sum(b for d, _, b in _IDLE.values() if d == dev_index) > cap:
-                old = next(p for p, (d, _, _) in _IDLE.items() if d == dev_index)      # oldest of this device
+            while sum(b for d, _, b in list(_IDLE.values()) if d == dev_index) > cap:      # (list(): a collector-run __del__ may re-enter)
+                old = next(p for p, (d, _, _) in list(_IDLE.items()) if d == dev_index)      # oldest of this device
                 drop.append((old, _IDLE.pop(old)[0]))
         else:
             drop.append((ptr, dev_index))
@@ -95,16 +95,16 @@ def idle_bytes(device=None):
     """Bytes of idle raw blocks (of one device): room a new allocation can draw on, like torch's reserved-but-unused memory."""
     idx = None if device is None else _resolve(device).index
     with _LOCK:
-        return sum(b for d, _, b in _IDLE.values() if idx is None or d == idx)
+        return sum(b for d, _, b in list(_IDLE.values()) if idx is None or d == idx)
 
 
 def trim(device=None):
     """Every idle raw block (of one device) back to the driver -> bytes given back."""
     idx = None if device is None else _resolve(device).index
     with _LOCK:
-        gone = [(p, v) for p, v in _IDLE.items() if idx is None or v[0] == idx]
+        gone = [(p, v) for p, v in list(_IDLE.items()) if idx is None or v[0] == idx]
         for p, _ in gone:
-            del _IDLE[p]
+            _IDLE.pop(p, None)
         _STATS["trims"] += 1
     for p, (d, _, _) in gone:
         _free(d, p)
@@ -122,7 +122,7 @@ def release_everything_idle(device=None):
 
 def stats():
     with _LOCK:
-        return dict(_STATS, idle_blocks=len(_IDLE), idle_bytes=sum(b for _, _, b in _IDLE.values()))
+        return dict(_STATS, idle_blocks=len(_IDLE), idle_bytes=sum(b for _, _, b in list(_IDLE.values())))
 
 
 def _raw(nbytes, dev, keep):
@@ -135,9 +135,9 @@ def _raw(nbytes, dev, keep):
             free_b, total_b = ctypes.c_size_t(), ctypes.c_size_t()
             nat.check(lib.pm_device_memory(idx, ctypes.byref(free_b), ctypes.byref(total_b)))
             _TOTAL[idx] = total_b.value
-        hit = next((p for p, v in _IDLE.items() if v == (idx, stream, nbytes)), None)
+        hit = next((p for p, v in list(_IDLE.items()) if v == (idx, stream, nbytes)), None)
         if hit is not None:
-            del _IDLE[hit]
+            _IDLE.pop(hit, None)
             _STATS["reused"] += 1
             return _Block(hit, nbytes, idx, stream, keep)
     out = ctypes.c_void_p()
