@@ -179,6 +179,10 @@ int pm_shape_context_neighbors_binned(const double *nb, int n, double mean_dist,
                                       int32_t *n_unsure, void *stream);
 
 /* ---- chi-square cost ----------------------------------------------------------------------- */
+/* Sizes: every build of this section covers its matrix with tiles of 16 x 64 entries, one 256-thread workgroup each.  A launch
+ * holds fewer than 2^32 work-items, i.e. ~16.7 M tiles (~130 000 x 130 000 entries); larger matrices are written by several
+ * launches over bands of tile rows, enqueued back to back on `stream` — same bits, nothing for the caller to do (140 000 and
+ * 200 000 nuclei run this way).  PM_ERR_INVALID_ARG only if ONE tile row is wider than a launch (nF > 1.07e9). */
 
 /* get_unary_distance (shape_context.py:88-99) for every pair: out[i*ld + j] =
  * 0.5 * sum_k (a_ik - b_jk)^2 / (a_ik + b_jk), bins with a == b skipped, summed k = 0..359
