@@ -189,8 +189,10 @@ def rank_devices(dist, group, dev, world, rank, ident=None):
     import torch
     if ident is None:
         props = torch.cuda.get_device_properties(dev)
-        ident = "%s | %s" % (props.name, str(getattr(props, "uuid", "")) or "pci %s:%s.%s" % (
-            getattr(props, "pci_domain_id", "?"), getattr(props, "pci_bus_id", "?"), getattr(props, "pci_device_id", "?")))
+        # uuid AND PCI address: two ranks on one card agree in both, two cards differ in the address even where a
+        # driver reports one uuid for all of them (a legitimate N-GPU run must never be refused as a rehearsal)
+        ident = "%s | %s | pci %s:%s.%s" % (props.name, str(getattr(props, "uuid", "")), getattr(props, "pci_domain_id", "?"),
+                                            getattr(props, "pci_bus_id", "?"), getattr(props, "pci_device_id", "?"))
     text = ident.encode()[:120]
     mine = torch.zeros(128, dtype=torch.uint8)
     mine[:len(text)] = torch.frombuffer(bytearray(text), dtype=torch.uint8)
