@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector float64 spec peak
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector float32 spec peak (packed: two lanes' worth per instruction)
+FILTER_CYCLES_PER_TERM = (192 * 8 + 373 * 4) / 192.0   # filter4_kernel's issue cycles per wave64 term (ISA census of its stage loop)
 
 A_GT = np.array([[9.08173020e-01, -2.58092254e-01, 2.21387350e-01, 4.98532315e+00],
                  [-2.85490902e-02, 5.66865806e-01, 7.60292965e-01, -2.13218259e+02],
@@ -651,7 +652,11 @@ def main():
                         "roofline": {"bound": "fp32_packed_valu", "achieved": 5.0 * 4 * 360 * n * m / (min(ts) * 1e-3) / 1e12, "peak": FP32_VALU_PEAK_TFLOPS,
                                      "unit": "TFLOP/s", "frac": 5.0 * 4 * 360 * n * m / (min(ts) * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
                                      "hbm_achieved": 16.0 * n * m / (min(ts) * 1e-3) / 1e9, "hbm_unit": "GB/s",
-                                     "hbm_frac": 16.0 * n * m / (min(ts) * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": 16.0 * n * m + 2880.0 * (n + m)},
+                                     "hbm_frac": 16.0 * n * m / (min(ts) * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": 16.0 * n * m + 2880.0 * (n + m),
+                                     # the launch against ITS OWN instruction stream (profiles/r05_filter_table.txt: per wave and stage of 192
+                                     # terms 192 v_rcp_f32 at ~8 cycles + 373 other instructions at 4): what binds it is issue, not the peak above
+                                     "issue_bound_ms": FILTER_CYCLES_PER_TERM * 4 * 360 * n * m / 64.0 / 1024.0 / 2.4e9 * 1e3,
+                                     "frac_of_issue_bound": FILTER_CYCLES_PER_TERM * 4 * 360 * n * m / 64.0 / 1024.0 / 2.4e9 * 1e3 / min(ts)},
                         "hypotheses_settled_without_an_exact_matrix": int(sum(through)),
                         "equal_to_exact_matrices_assignments": [bool(x is not None and y is not None and np.array_equal(x[1], y[1]))
                                                                 for x, y in zip(lsa_f, lsa)],

@@ -559,12 +559,16 @@ def certify_listed(M, u, v, col4row, exact_entries, cost_delta, infos=None):
             out.append(False)
             continue
         u2 = C[:nr] - v[c4r]                                  # the exact matched entries are tight to the bit
-        if float(np.abs(u2 - u).max()) > widen + delta:       # the premise |M - C| <= cost_delta, checked where C is known
+        # the premise |M - C| <= cost_delta, checked where C is known: u is tight on M's matched entries to within delta (`loose`
+        # above; a FilteredMatrix's core holds exact costs, u2 = u to rounding), so |u2 - u| <= cost_delta + delta — and no more than
+        # that may be granted: an unlisted entry's exact reduced cost is its approximate one (> eps_collect + 2 cost_delta + delta)
+        # + (C - M) - (u2 - u), which stays above eps_collect only under this bound
+        if float(np.abs(u2 - u).max()) > float(cost_delta) + delta:
             info["cost_delta_exceeded"] = float(np.abs(u2 - u).max())
             out.append(False)
             continue
         redC = (C[nr:] - v[tight[:, 1]]) - u2[tight[:, 0]]
-        if len(redC) and float(np.abs(redC - red).max()) > 2.0 * widen + delta:      # the same premise on the listed entries
+        if len(redC) and float(np.abs(redC - red).max()) > widen + 2.0 * delta:      # the same premise on the listed entries: (C - M) - (u2 - u)
             info["cost_delta_exceeded"] = float(np.abs(redC - red).max())
             out.append(False)
             continue
