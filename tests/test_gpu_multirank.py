@@ -128,5 +128,8 @@ def test_bench_line_survives_a_sharded_extra_that_does_not_return():
     assert len(line) == 1
     d = json.loads(line[0])
     assert d["value"] > 0 and d["n_gpus"] == 2
-    assert "timed out" in d["assignment_extra"]["error"] and d["assignment_extra"]["seconds"] is None
-    assert "skipped" in d["cpu_baseline"]
+    # rank 0 either sees its own watchdog fire ("timed out", no CPU baseline afterwards) or — when rank 1's fired first and rank 1 has
+    # left already — a collective of its extra fail at once ("Connection closed by peer"): the extra is lost either way, the line is not
+    err = d["assignment_extra"]["error"]
+    assert err and d["assignment_extra"]["seconds"] is None
+    assert ("timed out" in err and "skipped" in d["cpu_baseline"]) or "value" in d["cpu_baseline"], (err, d["cpu_baseline"])
