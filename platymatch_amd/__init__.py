@@ -25,6 +25,15 @@ def reserve(n, m=None, cost_mode='auto', device=None):
     return run(n, m, cost_mode=cost_mode, device=device)
 
 
+def warm_up(device=None):
+    """Pay the once-per-process first-use costs of the assignment stage's selection code (torch loads the code objects of its sorting
+    / gathering / indexing kernels at their first launch: 0.3-0.7 s) NOW — e.g. when a plug-in is loaded or detections have been
+    read, ahead of the first "Run" (lsap.warm_up; reserve() includes it).  Needs a GPU; a no-op ever after."""
+    from . import _native as nat, lsap
+    nat.load()
+    lsap.warm_up(nat.device(device))
+
+
 def release_memory(device=None):
     """Give the device memory this package holds without using back to the driver: the kept cost buffers no registration holds,
     the idle matrix blocks (device_memory.py) and torch's idle cache.  The next large registration pays its allocation again."""

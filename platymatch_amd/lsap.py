@@ -451,6 +451,56 @@ class FilteredMatrix:
         return cols, costs
 
 
+_WARM = {"lock": threading.Lock(), "done": set(), "threads": {}}
+
+
+def warm_up(device, wait=True):
+    """First use of the device-finished selection and listing code (FilteredMatrix._row_select_t / _threshold_select_t) on `device`,
+    on a 64 x 64 toy matrix and a stream of its own — once per process and device.  Why: torch loads the code objects of its own
+    kernels (stable sorting, gathering, masked indexing, bincount, cumsum ...) at their first launch — 0.3-0.7 s in a fresh process
+    (tools/cold_start.py --torch-warm), which the first registration of a process used to pay inside its assignment stage, with the
+    GPU idle.  It cannot be hidden INSIDE a registration — measured both ways (profiles/r05_cold_start.txt): started on a thread at
+    the entry of the first call the load only gets in the way of the first launches (the runtime loads one code object at a time:
+    2.5 s instead of ~1.9 on the same box), run while the filter build is in flight it waits for the build (a code object's device
+    memory is allocated with the device idle) and then costs the same.  So it is paid where the caller says: platymatch_amd.reserve()
+    and platymatch_amd.warm_up() run it AHEAD of the first registration (first 50 000-nucleus registration 1.40 -> 1.08-1.12 s).
+    wait=False: start the thread and return at once.  Nothing of a registration depends on it; a failure in here is dropped."""
+    torch = nat.torch_mod()
+    dev = nat.device(device)
+    if dev.type != "cuda":
+        return
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    dev = torch.device("cuda", key)
+
+    def work():
+        try:
+            with torch.cuda.device(dev), torch.cuda.stream(nat.side_stream(dev, ("warm-up",))):
+                n = 64
+                g = torch.arange(n * n, dtype=torch.float64, device=dev)
+                U = torch.remainder(g * 0.6180339887498949, 1.0).view(n, n).contiguous()      # (no generator is touched)
+                M = FilteredMatrix(DeviceMatrix(U.to(torch.float32)), lambda r, c: (U[torch.as_tensor(r, device=dev).long(), torch.as_tensor(c, device=dev).long()].cpu().numpy(),),
+                                   1e-6, exact_entries_t=lambda r, c: (U[r.long(), c.long()],))
+                v = np.zeros(n)
+                _, costs, _, _ = M._row_select_t(v, 8, with_diagonal=True)
+                M._row_select_t(None, 8)
+                M._threshold_select_t(costs[:, 0].copy(), v, np.arange(n, dtype=np.int32))
+                M.col_min()
+                torch.cuda.current_stream(dev).synchronize()
+        except Exception:        # noqa: BLE001 — a warm-up proves nothing and must cost nothing
+            pass
+
+    with _WARM["lock"]:
+        th = _WARM["threads"].get(key)
+        if key not in _WARM["done"]:
+            _WARM["done"].add(key)
+            th = _WARM["threads"][key] = threading.Thread(target=work, name="pm-warm-up")
+            th.start()
+    if wait and th is not None:
+        th.join()
+        with _WARM["lock"]:
+            _WARM["threads"].pop(key, None)
+
+
 def certify(M, u, v, col4row, info=None, min_eps=0.0):
     """Is (u, v, col4row) a certified UNIQUE optimum of the matrix M (nr <= nc)?  Dual feasibility and complementary
     slackness on every entry (pm_lsap_certificate), the free columns carrying the largest column dual (nr < nc), and no

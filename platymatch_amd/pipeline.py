@@ -23,6 +23,7 @@ import threading
 import numpy as np
 
 from . import _native as nat
+from . import lsap
 from .lsap import linear_sum_assignment, solve_many
 
 from ._pairings import HYPOTHESES, PAIRINGS  # noqa: E402
@@ -56,6 +57,7 @@ def reserve(n, m=None, cost_mode='auto', device=None):
             lease = cost_buffer(dev, ((int(want) + 7) // 8,))
             if lease is not None:
                 lease.release()
+    lsap.warm_up(dev)                             # (and the first-use costs of the assignment stage's selection code, ~0.3-0.7 s once)
     return kept_cost_bytes(dev)
 
 

@@ -377,3 +377,22 @@ def test_native_driver_gives_the_python_drivers_answers(dev, shape, monkeypatch)
     Un = U.copy()
     Un[3, 4] = np.nan
     assert L.solve_core(L.DeviceMatrix(dev(Un))) is None
+
+
+def test_warm_up_runs_the_selection_code_once_per_device_and_leaves_no_trace(dev):
+    """platymatch_amd.warm_up / lsap.warm_up: the first-use costs of the selection code (torch's own kernels behind it) paid on a toy
+    matrix ahead of the first registration — idempotent, touches no random generator, and a real solve afterwards is SciPy's."""
+    import torch
+    import platymatch_amd
+    from platymatch_amd import lsap as L
+    state = np.random.get_state()[1].copy()
+    gen = torch.cuda.get_rng_state().clone()
+    platymatch_amd.warm_up()
+    platymatch_amd.warm_up()                                          # a no-op ever after
+    assert torch.cuda.current_device() in L._WARM["done"] and not L._WARM["threads"]
+    assert np.array_equal(np.random.get_state()[1], state) and torch.equal(torch.cuda.get_rng_state(), gen)
+    L.warm_up("cpu")                                                  # nothing to warm: returns
+    rng = np.random.default_rng(11)
+    U = rng.random((1100, 1300))
+    r, c = L.solve_on_device(dev(U))
+    assert np.array_equal(c, scipy_lsa(U)[1])

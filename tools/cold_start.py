@@ -31,6 +31,24 @@ if "--reserve" in sys.argv:
     kept = platymatch_amd.reserve(n, n, mode)
     torch.cuda.synchronize()
     print("platymatch_amd.reserve(%d, %d, %r): %.2f s, %.1f GB kept" % (n, n, mode, time.perf_counter() - t0, kept / 1e9), flush=True)
+if "--torch-warm" in sys.argv:
+    # hypothesis test: how much of the first assignment stage is the first use of torch's own kernels (selection, sorting, indexing)?
+    t0 = time.perf_counter()
+    d = torch.device("cuda", torch.cuda.current_device())
+    x = torch.arange(4096, dtype=torch.float64, device=d).view(64, 64)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    o = torch.argsort(torch.where(x > 3, x, torch.full_like(x, float("inf"))), dim=1, stable=True)
+    g = torch.gather(x, 1, o)
+    c = torch.bincount(o.reshape(-1), minlength=64)
+    s_ = torch.cumsum(c, 0) - c
+    z = torch.cat([g.reshape(-1), x.reshape(-1)])[x.reshape(-1).repeat(2) > 1]
+    f = torch.stack([(~torch.isfinite(z)).any().to(torch.int32), (s_ > 0).any().to(torch.int32)]).cpu()
+    y = torch.full((8, 8), -1, dtype=torch.int32, device=d)
+    y[o[:8, 0].long().clamp(max=7), o[:8, 1].long().clamp(max=7)] = 1
+    torch.cuda.synchronize()
+    print("torch warm-up: first tensor %.3f s, first synchronize %.3f s, the op set %.3f s" % (t1 - t0, t2 - t1, time.perf_counter() - t2), flush=True)
 for rep in range(4):
     det = {"timing": True}
     t0 = time.perf_counter()
