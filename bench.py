@@ -533,19 +533,24 @@ def main():
     # is reported, never handed to the hours-long dense solver).  One GPU only (sharded runs hold row blocks, not matrices).
     assignment = None
     extra_hung = [False]
-    if world == 1 and not args.no_assignment:
-        from platymatch_amd import lsap as L
-        torch.cuda.synchronize()
-        t_as = time.perf_counter()
-        a_info = {}
-        lsa = L.solve_eight_on_device(U, info=a_info, allow_host=False)
-        t_as = time.perf_counter() - t_as
-        certified = [x is not None for x in lsa]
-        assignment = {"seconds": t_as, "hypotheses_certified_unique": int(sum(certified)), "routes": a_info.get("routes"),
-                      "pricing_rounds": [d.get("rounds") for d in a_info.get("details", [])[:4]],
-                      "dijkstra_steps": [d.get("steps") for d in a_info.get("details", [])[:4]],
-                      "note": "scipy.optimize.linear_sum_assignment's answer for the eight N x M matrices (_dock_widget.py:604-611) by a sparse "
-                              "core solved on the host and priced + certified against every entry on the device (DESIGN.md §4.3); not in `value`"}
+    try:
+        if world == 1 and not args.no_assignment:
+            from platymatch_amd import lsap as L
+            torch.cuda.synchronize()
+            t_as = time.perf_counter()
+            a_info = {}
+            lsa = L.solve_eight_on_device(U, info=a_info, allow_host=False)
+            t_as = time.perf_counter() - t_as
+            certified = [x is not None for x in lsa]
+            assignment = {"seconds": t_as, "hypotheses_certified_unique": int(sum(certified)), "routes": a_info.get("routes"),
+                          "pricing_rounds": [d.get("rounds") for d in a_info.get("details", [])[:4]],
+                          "dijkstra_steps": [d.get("steps") for d in a_info.get("details", [])[:4]],
+                          "note": "scipy.optimize.linear_sum_assignment's answer for the eight N x M matrices (_dock_widget.py:604-611) by a sparse "
+                                  "core solved on the host and priced + certified against every entry on the device (DESIGN.md §4.3); not in `value`"}
+    except Exception as e:      # noqa: BLE001 — an extra must not cost the headline line
+        import traceback
+        traceback.print_exc()
+        assignment = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if world > 1 and not args.no_assignment:
         # the eight assignments by the DEFAULT route of a sharded registration (cost_mode='auto': row blocks of the float32 filter on
@@ -592,78 +597,83 @@ def main():
     # from between 1 024 and 8 192 nuclei; pm_chi2_cost8_relaxed: no bit identity, every entry within delta of the exact one, used
     # only behind a certificate against the exact matrix's listed entries).  Launch time by HIP events on the launching stream.
     relaxed_extra = filter_extra = None
-    if world == 1 and symmetric[0] and not args.no_assignment:
-        ts = []
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            K.chi2_cost8_relaxed(sc_m_last[0][0], sc_f_last[0][0], out=U, variant=P.RELAXED_VARIANT)
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        # the eight assignments solved on the relaxed matrices and certified against the EXACT matrices on their matched and
-        # near-tight entries (pm_chi2_entries_sym, lsap.certify_listed): bounded like the leg above, nothing is rebuilt here
-        pairing_of = {p[0]: t for t, p in enumerate(K.PAIRINGS)}
-        a1, b1 = sc_m_last[0][0], sc_f_last[0][0]
+    try:
+        if world == 1 and symmetric[0] and not args.no_assignment:
+            ts = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                K.chi2_cost8_relaxed(sc_m_last[0][0], sc_f_last[0][0], out=U, variant=P.RELAXED_VARIANT)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            # the eight assignments solved on the relaxed matrices and certified against the EXACT matrices on their matched and
+            # near-tight entries (pm_chi2_entries_sym, lsap.certify_listed): bounded like the leg above, nothing is rebuilt here
+            pairing_of = {p[0]: t for t, p in enumerate(K.PAIRINGS)}
+            a1, b1 = sc_m_last[0][0], sc_f_last[0][0]
 
-        def exact_entries(h):
-            return lambda rows, cols: tuple(x.cpu().numpy() for x in K.chi2_entries(a1, b1, pairing_of[h], rows, cols))
-        r_info = {}
-        torch.cuda.synchronize()
-        t_rs = time.perf_counter()
-        lsa_r = L.solve_eight_on_device(U, info=r_info, allow_host=False, exact_entries=exact_entries, cost_delta=K.chi2_relaxed_delta(),
-                                        exact_rebuild=lambda h: None)
-        t_rs = time.perf_counter() - t_rs
-        on_relaxed = [str(d.get("cost_mode", "")).startswith("relaxed") for d in r_info.get("details", [])]
-        relaxed_extra = {"kernel": "pm::chi2_sym_kernel<4,3,-1,64,RELAX>", "launch_ms": min(ts), "exact_launch_ms": chi2_ms, "speedup": chi2_ms / min(ts),
-                         "per_entry_error_bound": K.chi2_relaxed_delta(),
-                         "assignment_seconds": t_rs, "hypotheses_certified_on_exact_entries": int(sum(on_relaxed)),
-                         "equal_to_exact_matrices_assignments": [bool(ok and x is not None and y is not None and np.array_equal(x[1], y[1]))
-                                                                 for ok, x, y in zip(on_relaxed, lsa_r, lsa)],
-                         "note": "NOT in `value` (the headline stays the exact build).  What estimate_transform's default cost_mode='auto' starts from below 8 192 nuclei: U = 0.5 (sum a + sum b) - 2 sum ab/(a+b), "
-                                 "v_rcp_f64 + one Newton step, four running sums per row (the twins coincide); an assignment solved on "
-                                 "these matrices counts only once it is proven to be the exact matrix's unique optimum from the exact "
-                                 "values of its matched and near-tight entries (a few N of them, evaluated by a small kernel), else that "
-                                 "pairing is rebuilt exactly (profiles/r04_chi2_relaxed.txt)"}
-        # third extra: the float32 FILTER build (cost_mode='filter') and the eight assignments solved through it — four approximate
-        # matrices select entries, every cost is exact; nothing exact is built
-        ts = []
-        Uf = U.view(torch.float32).reshape(-1)[:4 * n * m].view(4, n, m)       # float32 storage (the product's), carved out of the resident buffer
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            K.chi2_filter4(a1, b1, out=Uf)
-            e1.record()
+            def exact_entries(h):
+                return lambda rows, cols: tuple(x.cpu().numpy() for x in K.chi2_entries(a1, b1, pairing_of[h], rows, cols))
+            r_info = {}
             torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        f_info = {}
-        t_fs = time.perf_counter()
-        lsa_f = L.solve_four_filtered(Uf, lambda t: (lambda rows, cols: tuple(x.cpu().numpy() for x in K.chi2_entries(a1, b1, t, rows, cols))),
-                                      lambda t: (lambda rows, cols: K.chi2_entries(a1, b1, t, rows, cols, trusted=True)),
-                                      K.chi2_filter_delta() + 1e-13, lambda t: K.chi2_cost_pair(sc_m_last[0], sc_f_last[0], t, True),
-                                      info=f_info, allow_host=False)
-        t_fs = time.perf_counter() - t_fs
-        through = [str(d.get("cost_mode", "")).startswith("filter") for d in f_info.get("details", [])]
-        filter_extra = {"kernel": "pm::filter4_kernel<-1, float>", "launch_ms": min(ts), "exact_launch_ms": chi2_ms, "speedup": chi2_ms / min(ts),
-                        "per_entry_error_bound": K.chi2_filter_delta(), "assignment_seconds": t_fs,
-                        # its own roofline: packed-float32 VALU against the vector peak, counting the ALGORITHMIC
-                        # 5 flop per (pair, bin, pairing) — add, multiply, reciprocal, fused multiply-add — whether a term was computed
-                        # or read from the 94 x 94 float32 table; and the write rate of its 16 N M bytes
-                        "roofline": {"bound": "fp32_packed_valu", "achieved": 5.0 * 4 * 360 * n * m / (min(ts) * 1e-3) / 1e12, "peak": FP32_VALU_PEAK_TFLOPS,
-                                     "unit": "TFLOP/s", "frac": 5.0 * 4 * 360 * n * m / (min(ts) * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
-                                     "hbm_achieved": 16.0 * n * m / (min(ts) * 1e-3) / 1e9, "hbm_unit": "GB/s",
-                                     "hbm_frac": 16.0 * n * m / (min(ts) * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": 16.0 * n * m + 2880.0 * (n + m),
-                                     # the launch against ITS OWN instruction stream (profiles/r05_filter_table.txt: per wave and stage of 192
-                                     # terms 192 v_rcp_f32 at ~8 cycles + 373 other instructions at 4): what binds it is issue, not the peak above
-                                     "issue_bound_ms": FILTER_CYCLES_PER_TERM * 4 * 360 * n * m / 64.0 / 1024.0 / 2.4e9 * 1e3,
-                                     "frac_of_issue_bound": FILTER_CYCLES_PER_TERM * 4 * 360 * n * m / 64.0 / 1024.0 / 2.4e9 * 1e3 / min(ts)},
-                        "hypotheses_settled_without_an_exact_matrix": int(sum(through)),
-                        "equal_to_exact_matrices_assignments": [bool(x is not None and y is not None and np.array_equal(x[1], y[1]))
-                                                                for x, y in zip(lsa_f, lsa)],
-                        "note": "NOT in `value` (the headline stays the exact build).  What estimate_transform's default cost_mode='auto' does at this size: four matrices in packed float32 arithmetic only select "
-                                "entries for the assignment solver, whose costs and certificate are evaluated exactly "
-                                "(lsap.FilteredMatrix; profiles/r04_e2e.txt)"}
-        K.chi2_cost8_frame1(sc_m_last[0][0], sc_f_last[0][0], out=U)          # leave the exact matrices behind
+            t_rs = time.perf_counter()
+            lsa_r = L.solve_eight_on_device(U, info=r_info, allow_host=False, exact_entries=exact_entries, cost_delta=K.chi2_relaxed_delta(),
+                                            exact_rebuild=lambda h: None)
+            t_rs = time.perf_counter() - t_rs
+            on_relaxed = [str(d.get("cost_mode", "")).startswith("relaxed") for d in r_info.get("details", [])]
+            relaxed_extra = {"kernel": "pm::chi2_sym_kernel<4,3,-1,64,RELAX>", "launch_ms": min(ts), "exact_launch_ms": chi2_ms, "speedup": chi2_ms / min(ts),
+                             "per_entry_error_bound": K.chi2_relaxed_delta(),
+                             "assignment_seconds": t_rs, "hypotheses_certified_on_exact_entries": int(sum(on_relaxed)),
+                             "equal_to_exact_matrices_assignments": [bool(ok and x is not None and y is not None and np.array_equal(x[1], y[1]))
+                                                                     for ok, x, y in zip(on_relaxed, lsa_r, lsa)],
+                             "note": "NOT in `value` (the headline stays the exact build).  What estimate_transform's default cost_mode='auto' starts from below 8 192 nuclei: U = 0.5 (sum a + sum b) - 2 sum ab/(a+b), "
+                                     "v_rcp_f64 + one Newton step, four running sums per row (the twins coincide); an assignment solved on "
+                                     "these matrices counts only once it is proven to be the exact matrix's unique optimum from the exact "
+                                     "values of its matched and near-tight entries (a few N of them, evaluated by a small kernel), else that "
+                                     "pairing is rebuilt exactly (profiles/r04_chi2_relaxed.txt)"}
+            # third extra: the float32 FILTER build (cost_mode='filter') and the eight assignments solved through it — four approximate
+            # matrices select entries, every cost is exact; nothing exact is built
+            ts = []
+            Uf = U.view(torch.float32).reshape(-1)[:4 * n * m].view(4, n, m)       # float32 storage (the product's), carved out of the resident buffer
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                K.chi2_filter4(a1, b1, out=Uf)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            f_info = {}
+            t_fs = time.perf_counter()
+            lsa_f = L.solve_four_filtered(Uf, lambda t: (lambda rows, cols: tuple(x.cpu().numpy() for x in K.chi2_entries(a1, b1, t, rows, cols))),
+                                          lambda t: (lambda rows, cols: K.chi2_entries(a1, b1, t, rows, cols, trusted=True)),
+                                          K.chi2_filter_delta() + 1e-13, lambda t: K.chi2_cost_pair(sc_m_last[0], sc_f_last[0], t, True),
+                                          info=f_info, allow_host=False)
+            t_fs = time.perf_counter() - t_fs
+            through = [str(d.get("cost_mode", "")).startswith("filter") for d in f_info.get("details", [])]
+            filter_extra = {"kernel": "pm::filter4_kernel<-1, float>", "launch_ms": min(ts), "exact_launch_ms": chi2_ms, "speedup": chi2_ms / min(ts),
+                            "per_entry_error_bound": K.chi2_filter_delta(), "assignment_seconds": t_fs,
+                            # its own roofline: packed-float32 VALU against the vector peak, counting the ALGORITHMIC
+                            # 5 flop per (pair, bin, pairing) — add, multiply, reciprocal, fused multiply-add — whether a term was computed
+                            # or read from the 94 x 94 float32 table; and the write rate of its 16 N M bytes
+                            "roofline": {"bound": "fp32_packed_valu", "achieved": 5.0 * 4 * 360 * n * m / (min(ts) * 1e-3) / 1e12, "peak": FP32_VALU_PEAK_TFLOPS,
+                                         "unit": "TFLOP/s", "frac": 5.0 * 4 * 360 * n * m / (min(ts) * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                                         "hbm_achieved": 16.0 * n * m / (min(ts) * 1e-3) / 1e9, "hbm_unit": "GB/s",
+                                         "hbm_frac": 16.0 * n * m / (min(ts) * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": 16.0 * n * m + 2880.0 * (n + m),
+                                         # the launch against ITS OWN instruction stream (profiles/r05_filter_table.txt: per wave and stage of 192
+                                         # terms 192 v_rcp_f32 at ~8 cycles + 373 other instructions at 4): what binds it is issue, not the peak above
+                                         "issue_bound_ms": FILTER_CYCLES_PER_TERM * 4 * 360 * n * m / 64.0 / 1024.0 / 2.4e9 * 1e3,
+                                         "frac_of_issue_bound": FILTER_CYCLES_PER_TERM * 4 * 360 * n * m / 64.0 / 1024.0 / 2.4e9 * 1e3 / min(ts)},
+                            "hypotheses_settled_without_an_exact_matrix": int(sum(through)),
+                            "equal_to_exact_matrices_assignments": [bool(x is not None and y is not None and np.array_equal(x[1], y[1]))
+                                                                    for x, y in zip(lsa_f, lsa)],
+                            "note": "NOT in `value` (the headline stays the exact build).  What estimate_transform's default cost_mode='auto' does at this size: four matrices in packed float32 arithmetic only select "
+                                    "entries for the assignment solver, whose costs and certificate are evaluated exactly "
+                                    "(lsap.FilteredMatrix; profiles/r04_e2e.txt)"}
+            K.chi2_cost8_frame1(sc_m_last[0][0], sc_f_last[0][0], out=U)          # leave the exact matrices behind
+    except Exception as e:      # noqa: BLE001 — an extra must not cost the headline line
+        import traceback
+        traceback.print_exc()
+        filter_extra = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if rank == 0:
         final = (A.reshape(4, 4).cpu().numpy())
@@ -721,31 +731,36 @@ def main():
         if extra_hung[0]:
             out["cpu_baseline"] = {"skipped": "the sharded extra's watchdog fired: nothing further touches the device in this process"}
         elif not args.no_cpu_baseline:         # (rank 0, whatever the world: a SCALE line carries its baseline too, VERDICT r04 next #2b)
-            # the chi-square leg of the CPU baseline runs on the real clouds' descriptors (the GPU's, verified equal to the oracle's
-            # by the parity tests): >= 1 % of the N x M pairs of every matrix
-            r_rows = max(1, min(n, (n + 99) // 100 + 12))
-            real = (sc_m_last[0][:, :r_rows].cpu().numpy(), (sc_f_last[0] if sc_f_last[0].shape[0] == 4 else P.expand_frames(sc_f_last[0][0], 4)).cpu().numpy())
-            out["cpu_baseline"] = cpu_baseline(mv_h, fx_h, start_h, args.icp_iters, real=real)
-            if not args.no_cpu_config2:
-                # BASELINE config 2 complete on the host, TIMED (tools/cpu_config2.py), beside the same pair through the product
-                sys.path.insert(0, os.path.join(ROOT, "tools"))
-                import cpu_config2
-                c2 = cpu_config2.run(5000)
-                from conftest import synth_pair
-                from platymatch_amd.estimate_transform import perform_icp as pi
-                pi.VERBOSE = False
-                mv2, fx2, _ = synth_pair(5000, 42)
-                gpu_s = []
-                for _ in range(4):
-                    torch.cuda.synchronize()
-                    t_g = time.perf_counter()
-                    P.estimate_transform(mv2, fx2, ransac_trials=8000, ransac_error=16, icp_iterations=50, seed=0)
-                    torch.cuda.synchronize()
-                    gpu_s.append(time.perf_counter() - t_g)
-                out["cpu_baseline"]["config2_timed_s"] = c2["seconds"]
-                out["cpu_baseline"]["config2"] = dict(c2, gpu_same_pair_s={"first_call": gpu_s[0], "median_of_next_three": float(np.median(gpu_s[1:]))},
-                                                      note="a complete 5 000-nucleus registration (seeded: the reference's RANSAC index sets), host oracle against "
-                                                           "the product on this GPU; host arrays in, host arrays out")
+            try:
+                # the chi-square leg of the CPU baseline runs on the real clouds' descriptors (the GPU's, verified equal to the oracle's
+                # by the parity tests): >= 1 % of the N x M pairs of every matrix
+                r_rows = max(1, min(n, (n + 99) // 100 + 12))
+                real = (sc_m_last[0][:, :r_rows].cpu().numpy(), (sc_f_last[0] if sc_f_last[0].shape[0] == 4 else P.expand_frames(sc_f_last[0][0], 4)).cpu().numpy())
+                out["cpu_baseline"] = cpu_baseline(mv_h, fx_h, start_h, args.icp_iters, real=real)
+                if not args.no_cpu_config2:
+                    # BASELINE config 2 complete on the host, TIMED (tools/cpu_config2.py), beside the same pair through the product
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import cpu_config2
+                    c2 = cpu_config2.run(5000)
+                    from conftest import synth_pair
+                    from platymatch_amd.estimate_transform import perform_icp as pi
+                    pi.VERBOSE = False
+                    mv2, fx2, _ = synth_pair(5000, 42)
+                    gpu_s = []
+                    for _ in range(4):
+                        torch.cuda.synchronize()
+                        t_g = time.perf_counter()
+                        P.estimate_transform(mv2, fx2, ransac_trials=8000, ransac_error=16, icp_iterations=50, seed=0)
+                        torch.cuda.synchronize()
+                        gpu_s.append(time.perf_counter() - t_g)
+                    out["cpu_baseline"]["config2_timed_s"] = c2["seconds"]
+                    out["cpu_baseline"]["config2"] = dict(c2, gpu_same_pair_s={"first_call": gpu_s[0], "median_of_next_three": float(np.median(gpu_s[1:]))},
+                                                          note="a complete 5 000-nucleus registration (seeded: the reference's RANSAC index sets), host oracle against "
+                                                               "the product on this GPU; host arrays in, host arrays out")
+            except Exception as e:      # noqa: BLE001 — the baseline leg must not cost the headline line (whatever it got so far stays)
+                import traceback
+                traceback.print_exc()
+                out["cpu_baseline"] = dict(out.get("cpu_baseline") or {}, error="%s: %s" % (type(e).__name__, str(e)[:300]))
         print(json.dumps(out), flush=True)
     if extra_hung[0]:
         sys.stdout.flush()
@@ -768,7 +783,7 @@ def main():
 
         th = threading.Thread(target=close, name="pm-bench-close", daemon=True)
         th.start()
-        if not closed.wait(float(os.environ.get("PM_BENCH_CLOSE_TIMEOUT_S", "120"))):
+        if not closed.wait(float(os.environ.get("PM_BENCH_CLOSE_TIMEOUT_S", "300"))):
             sys.stderr.write("bench.py rank %d: closing barrier did not return; leaving without it\n" % rank)
             sys.stdout.flush()
             sys.stderr.flush()
