@@ -382,6 +382,12 @@ int pm_lsap_core_auction_resume(void *core, const double *price, const int32_t *
 int pm_lsap_core_solve(void *core);
 int pm_lsap_core_reprice(void *core, int k, const int32_t *cand_col, const double *cand_cost, double delta, int *n_violated);
 int pm_lsap_core_get(void *core, double *u, double *v, int32_t *col4row, long *stats4);
+/* How many pricing rounds pm_lsap_core_reprice settled from the COLUMN side (round 5): when the matching is complete and many
+ * violated rows meet on few columns — the signature of one huge alternating tree lifted by a solve's last augmentations — the
+ * offending columns' duals drop by their worst violation and only their holders are freed, instead of every violated row
+ * (a 50 000 x 50 000 filtered solve: 48 179 rows freed before, 1-2 thousand now).  PM_LSAP_COLUMN_REPAIR=0 in the environment
+ * switches it off, =force takes it whenever the matching is complete (tests).  -1 for a NULL core. */
+long pm_lsap_core_column_repairs(void *core);
 
 /* DEVICE: out[r] = U[r][col0 + r] for r < min(nr, nc - col0): the diagonal entries of a row block that starts at matrix row col0
  * (the safety edges of the core: with them it always holds a perfect matching). */

@@ -72,6 +72,7 @@ SIGNATURES = {
                                           _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "pm_lsap_core_reprice": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_double, _c_void_p]),
     "pm_lsap_core_get": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    "pm_lsap_core_column_repairs": (ctypes.c_long, [_c_void_p]),
     "pm_lsap_unique": (_c_int, [_c_int, _c_int, _c_void_p, _c_void_p, _c_double, _c_double, _c_void_p, _c_int]),
     "pm_mean_distance_rows": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "pm_mean_distance_finish": (_c_int, [_c_void_p, _c_int, _c_void_p, _c_void_p]),

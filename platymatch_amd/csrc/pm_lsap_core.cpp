@@ -77,6 +77,8 @@ struct Core {
                              pred(nc_), root_of_row(nc_, -1), root_stamp(nc_, 0), row_dist(nc_, 0.0) {
         free_rows.reserve(nc_);
         for (int i = 0; i < nc_; ++i) free_rows.push_back(i);
+        if (const char *e = std::getenv("PM_LSAP_COLUMN_REPAIR"))
+            column_repair_mode = (e[0] == '0') ? 0 : (e[0] == 'f' ? 2 : 1);         // "0" | "force" | anything else: by the criterion
     }
 
     bool has_edge(int i, int j) const {
@@ -681,8 +683,32 @@ struct Core {
     // the one minimising cost - v[col] over the whole row is present (pm_lsap_row_select with the current v).  Rows whose
     // minimum reduced cost is below -delta are repaired: the offenders join the core, u[i] drops to the dense row minimum
     // (feasible again), the row and its column are freed for re-augmentation.
+    //
+    // COLUMN-SIDE repair (round 5).  The last augmentations of a solve can lift the duals of one huge alternating tree: every
+    // row of the tree then undercuts the FEW columns outside it through dense entries the core never held — measured on a
+    // 50 000 x 50 000 filtered solve: 48 179 of 50 000 rows violated after the first complete solve, all of them freed, the
+    // second solve re-augmenting 48 k rows (0.12 s of a 0.49 s hypothesis).  Those violations meet on a handful of columns, and a
+    // violation c - u[i] - v[j] < 0 is cured just as well from the column's side: v[j] drops by the column's worst violation
+    // (every entry of column j only gains reduced cost: nothing else becomes infeasible, the dense matrix included), the
+    // offenders join the core, and only the column's HOLDER loses its tight edge and is freed — one row per offending column
+    // instead of one per offending row.  Taken when the matching is complete (so every column has a holder), the violated rows
+    // are many and the offending columns held by real rows at most half as many; rows with an offender in any other column
+    // (held by a dummy row of a rectangular problem) are repaired from the row side as before.  Either repair leaves feasible
+    // duals and tight matched edges, which is all the searches and the final certificate ask for.
+    int column_repair_mode = 1;                    // 0 never, 1 by the criterion, 2 whenever the matching is complete (PM_LSAP_COLUMN_REPAIR; tests)
+    long column_repairs = 0;
+    std::vector<double> col_viol;
+    std::vector<int32_t> viol_rows, viol_cols;
+    std::vector<unsigned char> row_by_column;
+
     int reprice(int k, const int32_t *cand_col, const double *cand_cost, double delta) {
-        int violated = 0;
+        // pass 1: which rows are violated, and do their offenders all sit in columns a real row holds?
+        viol_rows.clear();
+        viol_cols.clear();
+        row_by_column.assign((size_t)nr, 0);
+        if (col_viol.size() != (size_t)nc) col_viol.assign((size_t)nc, 0.0);
+        const bool complete = !cold && free_rows.empty() && column_repair_mode != 0;
+        long by_column_rows = 0;
         for (int i = 0; i < nr; ++i) {
             double best = std::numeric_limits<double>::infinity();
             for (int t = 0; t < k; ++t) {
@@ -692,18 +718,58 @@ struct Core {
                 if (red < best) best = red;
             }
             if (!(best - u[i] < -delta)) continue;
-            ++violated;
+            viol_rows.push_back(i);
+            if (!complete) continue;
+            bool ok = true;
+            for (int t = 0; t < k && ok; ++t) {
+                const int j = cand_col[(size_t)i * k + t];
+                if (j < 0) continue;
+                if (!((cand_cost[(size_t)i * k + t] - col[j].v) - u[i] < -delta)) continue;
+                const int holder = row4col[j];
+                ok = holder >= 0 && holder < nr;
+            }
+            if (!ok) continue;
+            row_by_column[i] = 1;
+            ++by_column_rows;
             for (int t = 0; t < k; ++t) {
                 const int j = cand_col[(size_t)i * k + t];
                 if (j < 0) continue;
-                if ((cand_cost[(size_t)i * k + t] - col[j].v) - u[i] < -delta) add_edge(i, j, cand_cost[(size_t)i * k + t]);
+                const double red = (cand_cost[(size_t)i * k + t] - col[j].v) - u[i];
+                if (!(red < -delta)) continue;
+                if (col_viol[j] == 0.0) viol_cols.push_back(j);
+                if (-red > col_viol[j]) col_viol[j] = -red;
             }
+        }
+        const bool by_column = complete && by_column_rows > 0 &&
+                               (column_repair_mode == 2 || (by_column_rows >= 64 && 2 * (long)viol_cols.size() <= by_column_rows));
+        // pass 2: the repairs
+        for (int i : viol_rows) {
+            const bool from_column = by_column && row_by_column[i];
+            double best = std::numeric_limits<double>::infinity();
+            for (int t = 0; t < k; ++t) {
+                const int j = cand_col[(size_t)i * k + t];
+                if (j < 0) continue;
+                const double red = cand_cost[(size_t)i * k + t] - col[j].v;
+                if (red < best) best = red;
+                if (red - u[i] < -delta) add_edge(i, j, cand_cost[(size_t)i * k + t]);
+            }
+            if (from_column) continue;
             u[i] = best;
             const int j = col4row[i];
             if (j >= 0) { row4col[j] = -1; col4row[i] = -1; }
             free_rows.push_back(i);
         }
-        return violated;
+        if (by_column) {
+            // (after the row-side repairs: they read v as the pricing pass saw it)
+            for (int j : viol_cols) {
+                col[j].v -= col_viol[j];
+                const int holder = row4col[j];
+                if (holder >= 0) { row4col[j] = -1; col4row[holder] = -1; free_rows.push_back(holder); }
+            }
+            ++column_repairs;
+        }
+        for (int j : viol_cols) col_viol[j] = 0.0;
+        return (int)viol_rows.size();
     }
 };
 
@@ -809,6 +875,11 @@ int pm_lsap_core_reprice(void *h, int k, const int32_t *cand_col, const double *
         return PM_ERR_WORKSPACE;
     }
     return PM_OK;
+}
+
+long pm_lsap_core_column_repairs(void *h) {
+    Core *c = static_cast<Core *>(h);
+    return c ? c->column_repairs : -1;
 }
 
 int pm_lsap_core_get(void *h, double *u, double *v, int32_t *col4row, long *stats4) {

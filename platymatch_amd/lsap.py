@@ -133,6 +133,10 @@ class _Core:
         nat.check(self.lib.pm_lsap_core_reprice(self.h, cols.shape[1], cols.ctypes.data, costs.ctypes.data, float(delta), ctypes.byref(n)))
         return n.value
 
+    def column_repairs(self):
+        """Pricing rounds this core settled from the column side (pm_lsap_core_column_repairs)."""
+        return int(self.lib.pm_lsap_core_column_repairs(self.h))
+
     def get(self):
         import ctypes
         u, v = np.empty(self.nr), np.empty(self.nc)
@@ -1047,7 +1051,8 @@ def solve_core(M, info=None):
                 t_core += time.perf_counter() - t_s
                 u, v, c4r, stats = core.get()
         if info is not None:
-            info.update(rounds=rounds, edges=stats[0], steps=stats[1], augmentations=stats[2], dummy_scans=stats[3], core_seconds=t_core)
+            info.update(rounds=rounds, edges=stats[0], steps=stats[1], augmentations=stats[2], dummy_scans=stats[3], core_seconds=t_core,
+                        column_repairs=core.column_repairs())
     return u, v, c4r
 
 

@@ -568,3 +568,35 @@ def test_fuzz_a_certified_answer_of_the_listed_certificate_is_the_exact_matrices
                 assert D[r2, c2].sum() > best + 1e-12, (case, flow, kind, i, D[r2, c2].sum() - best)
     assert said_yes["relaxed"] > 20 and said_yes["filter"] > 60, said_yes
     assert generic["filter"][1] >= 0.9 * generic["filter"][0], generic        # the filter flow settles generic matrices whatever its accuracy
+
+
+@pytest.mark.parametrize("mode", ["force", "auto", "0"])
+def test_column_side_repair_of_a_pricing_round_never_changes_the_certified_answer(mode, monkeypatch):
+    """pm_lsap_core_reprice, round 5: when the matching is complete and the violated rows meet on few columns (a starved core with a
+    handful of globally cheap columns: nearly every row undercuts them after the first solve — the shape of the 48 179-row pricing
+    round measured at 50 000 nuclei), the columns' duals are lowered and only their holders freed, instead of every violated row.
+    Forced for every complete matching, by its criterion, or switched off: the certified answer is SciPy's each time, on square and
+    rectangular problems."""
+    from platymatch_amd import lsap as L
+    monkeypatch.setenv("PM_LSAP_COLUMN_REPAIR", mode)
+    monkeypatch.setattr(L, "CORE_EDGES_PER_ROW", 4)                   # a starved core: pricing rounds are certain
+    taken = {"plain": 0, "cheap columns": 0}
+    for seed in range(24):
+        rng = np.random.default_rng(1000 + seed)
+        nr = int(rng.integers(150, 900))
+        nc = nr if seed % 2 == 0 else nr + int(rng.integers(1, 300))
+        U = rng.random((nr, nc))
+        kind = "cheap columns" if seed % 4 >= 2 else "plain"
+        if kind == "cheap columns":
+            U[:, rng.choice(nc, 5, replace=False)] *= 0.05
+        info = {}
+        sol = L.solve_core(HostMatrix(U), info)
+        assert sol is not None and L.certify(HostMatrix(U), *sol, info=info), (seed, info)
+        assert np.array_equal(sol[2], scipy_lsa(U)[1]), seed
+        taken[kind] += info["column_repairs"]
+    if mode == "0":
+        assert taken == {"plain": 0, "cheap columns": 0}
+    elif mode == "force":
+        assert taken["plain"] > 0 and taken["cheap columns"] > 0
+    else:
+        assert taken["cheap columns"] > 0, taken                     # (by its criterion: many violated rows on few real-held columns)
