@@ -600,3 +600,27 @@ def test_column_side_repair_of_a_pricing_round_never_changes_the_certified_answe
         assert taken["plain"] > 0 and taken["cheap columns"] > 0
     else:
         assert taken["cheap columns"] > 0, taken                     # (by its criterion: many violated rows on few real-held columns)
+
+
+def test_listed_certificate_grants_a_matched_entry_no_more_than_the_stated_bound():
+    """certify_listed's premise |R - C| <= cost_delta is checked on the matched entries (u' - u).  The proof that an UNLISTED entry
+    stays further than eps_collect from tight needs |u' - u| <= cost_delta + delta — not the 2 cost_delta + delta round 4 granted: a
+    matched entry that is off by 1.5 cost_delta is refused (cost_delta_exceeded), one off by 0.9 cost_delta passes."""
+    from platymatch_amd import lsap as L
+    rng = np.random.default_rng(77)
+    n = 200
+    C = rng.random((n, n)) * rng.random((1, n)) + 0.3 * rng.random((n, 1)) + 0.05 * rng.random((n, n))
+    cost_delta = 1e-9
+    M = HostMatrix(C)                                             # solved on the exact matrix: u is tight on C's matched entries
+    sol = L.solve_core(M)
+    c4r = sol[2]
+    for off, expect in ((0.9, True), (1.5, False)):
+        def entries(rows, cols):
+            out = C[rows, cols].copy()
+            hit = (np.asarray(rows) == 7) & (np.asarray(cols) == c4r[7])
+            out[hit] += off * cost_delta                          # the "exact" matrix differs from the solved one at ONE matched entry
+            return (out,)
+        info = {}
+        ok = L.certify_listed(M, *sol, exact_entries=entries, cost_delta=cost_delta, infos=[info])[0]
+        assert ok is expect or ok == expect, (off, info)
+        assert ("cost_delta_exceeded" in info) == (not expect), (off, info)
